@@ -1,0 +1,108 @@
+"""Parity cases shared by the golden generator (runs the live reference) and the
+tests (run the oracle / the HIP path).  No reference import here."""
+import copy
+
+import numpy as np
+
+from wekws_amd.utils import synth
+
+
+def _c(name, model, B=3, T=98, **kw):
+    d = dict(name=name, model=model, B=B, T=T, wseed=1234, xseed=0, cmvn=False, chunks=None,
+             cache="empty", softmax=False, odim=None)
+    d.update(kw)
+    return d
+
+
+CASES = [
+    # ---- one-shot, empty-cache sentinel (wekws/bin/score.py:125 call shape) ----
+    _c("ds_tcn_h256/full", "ds_tcn_h256"),
+    _c("ds_tcn_h256/full_cmvn", "ds_tcn_h256", cmvn=True, xseed=1),
+    _c("ds_tcn_h256/cmvn_novar", "ds_tcn_h256", cmvn=True, norm_var=False, xseed=1, B=2),
+    _c("ds_tcn_h256/odim1", "ds_tcn_h256", odim=1, B=2, xseed=2),
+    _c("ds_tcn_h64/full", "ds_tcn_h64"),
+    _c("tcn_h64/full", "tcn_h64"),
+    _c("mdtc_h64/full", "mdtc_h64"),
+    _c("mdtc_h64/full_cmvn", "mdtc_h64", cmvn=True, xseed=1),
+    _c("mdtc_small/full", "mdtc_small"),
+    _c("mdtc_h64_global12/full", "mdtc_h64_global12"),
+    _c("mdtc_small_global12/full", "mdtc_small_global12"),
+    _c("mdtc_small_last12/full", "mdtc_small_last12"),
+    _c("gru_2x128/full_h0zero", "gru_2x128", cache="zeros"),
+    _c("gru_2x128/full_h0rand", "gru_2x128", cache="random"),
+    _c("gru_1x128/full_h0rand", "gru_1x128", cache="random", B=2),
+    _c("ds_tcn_h64_ctc20/softmax", "ds_tcn_h64_ctc20", softmax=True, B=2),
+    _c("ds_tcn_h64_ctc20/logits", "ds_tcn_h64_ctc20", B=2),
+    # ---- ragged / edge lengths: T < padding, T = 1, T beyond one LDS tile ----
+    _c("ds_tcn_h256/T1", "ds_tcn_h256", T=1, B=2),
+    _c("ds_tcn_h256/T5", "ds_tcn_h256", T=5, B=2),
+    _c("ds_tcn_h256/T57", "ds_tcn_h256", T=57, B=1),
+    _c("ds_tcn_h256/T150", "ds_tcn_h256", T=150, B=2),
+    _c("ds_tcn_h256/T300", "ds_tcn_h256", T=300, B=1),
+    _c("mdtc_h64/T3", "mdtc_h64", T=3, B=2),
+    _c("mdtc_h64/T250", "mdtc_h64", T=250, B=2),
+    _c("mdtc_h64_global12/T250", "mdtc_h64_global12", T=250, B=2),
+    _c("tcn_h64/T150", "tcn_h64", T=150, B=2),
+    _c("gru_2x128/T1", "gru_2x128", T=1, B=2, cache="random"),
+    # ---- explicit caches: all-zero (== empty, tcn.py:49-52) and random ----
+    _c("ds_tcn_h256/cache_zero", "ds_tcn_h256", cache="zeros", B=2),
+    _c("ds_tcn_h256/cache_rand", "ds_tcn_h256", cache="random", B=2, T=30),
+    _c("mdtc_h64/cache_rand", "mdtc_h64", cache="random", B=2, T=30),
+    _c("tcn_h64/cache_rand", "tcn_h64", cache="random", B=2, T=30),
+    # ---- streaming traces (stream_kws_ctc.py:486-487 / keyword_spotting.cc:63-94) ----
+    _c("ds_tcn_h256/stream10", "ds_tcn_h256", B=2, T=100, chunks=[10] * 10),
+    _c("ds_tcn_h256/stream_mixed", "ds_tcn_h256", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47]),
+    _c("ds_tcn_h64/stream10", "ds_tcn_h64", B=2, T=50, chunks=[10] * 5),
+    _c("tcn_h64/stream_mixed", "tcn_h64", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47]),
+    _c("mdtc_h64/stream10", "mdtc_h64", B=2, T=100, chunks=[10] * 10),
+    _c("mdtc_h64/stream_mixed", "mdtc_h64", B=1, T=98, chunks=[1, 7, 10, 80]),
+    _c("mdtc_small/stream1", "mdtc_small", B=2, T=12, chunks=[1] * 12),
+    _c("mdtc_small_last12/stream10", "mdtc_small_last12", B=2, T=40, chunks=[10] * 4),
+    _c("gru_2x128/stream10", "gru_2x128", B=2, T=100, chunks=[10] * 10, cache="zeros"),
+    _c("gru_2x128/stream_mixed", "gru_2x128", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47], cache="random"),
+]
+
+
+def case_config(case):
+    cfg = copy.deepcopy(synth.MODEL_CONFIGS[case["model"]])
+    if case.get("odim"):
+        cfg["output_dim"] = case["odim"]
+    if case["cmvn"]:
+        # cmvn stats are injected as buffers (no cmvn_file on disk); "_cmvn" tells the
+        # builders to attach a GlobalCMVN whose mean/istd come from the state_dict.
+        cfg["cmvn"] = dict(norm_var=case.get("norm_var", True))
+        cfg["_cmvn"] = True
+    return cfg
+
+
+def case_input(case):
+    cfg = synth.MODEL_CONFIGS[case["model"]]
+    return synth.synth_feats(case["B"], case["T"], cfg["input_dim"], seed=case["xseed"],
+                             cmvn_like=case["cmvn"])
+
+
+def cache_shape(cfg, B):
+    bb = cfg["backbone"]
+    if bb["type"] == "gru":
+        return (bb["num_layers"], B, cfg["hidden_dim"])
+    if bb["type"] == "tcn":
+        k = bb.get("kernel_size", 8)
+        P = sum((k - 1) * 2 ** i for i in range(bb["num_layers"]))
+        return (B, cfg["hidden_dim"], P)
+    if bb["type"] == "mdtc":
+        k = bb["kernel_size"]
+        per_stack = sum((k - 1) * 2 ** j for j in range(bb["stack_size"]))
+        return (B, bb["hidden_dim"], (k - 1) + bb["num_stack"] * per_stack)
+    raise ValueError(bb["type"])
+
+
+def case_in_cache(case, cfg=None):
+    cfg = cfg or case_config(case)
+    mode = case["cache"]
+    if mode == "empty":
+        return None
+    shape = cache_shape(cfg, case["B"])
+    if mode == "zeros":
+        return np.zeros(shape, np.float32)
+    g = np.random.default_rng([0xCAC4E, case["xseed"]])
+    return g.standard_normal(shape).astype(np.float32)

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1-second utterances/s through the fused DS-TCN forward on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (KWSModel.forward: 40-d fbank features -> per-frame posteriors +
+streaming cache, exactly what wekws/bin/score.py:125 calls) over one batch of synthetic 1-s utterances
+already resident in HBM.  Workload (BASELINE.json metric / SURVEY.md section 8d): DS-TCN h256 (287,490 params,
+examples/hi_xiaowen/s0/conf/ds_tcn.yaml), B = 1024 utterances per GPU, T = 98 frames, fp32.
+Multi-GPU: utterance-parallel, one process per GPU, weights broadcast once over RCCL, no collective in the
+timed forward (weak scaling: 1024 utterances per GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (conv_stack_kernel<DS,256,7>): the fused path is compute-bound on the exact-f32
+                matrix pipe (55.09 MFLOP / 16,464 B per utterance = 3,346 FLOP/B >> machine balance 20), so the
+                binding roofline is the 157.3 TFLOP/s f32 MFMA peak; achieved = algorithmic FLOPs per launch /
+                mean kernel time measured with HIP events on the launch stream.  The HBM-side figures
+                (algorithmic GB/s vs 8 TB/s) are reported next to it as `hbm_*`.
+  cpu_baseline  the numpy oracle (oracle/kws_oracle.py, a port of the reference forward) timed on this box's
+                host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832}  # BASELINE.md section 2 (2 FLOP per MAC, T=98)
+BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4                          # features in + posteriors out = 16,464 B
+PEAK_F32_TFLOPS = 157.3                                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, sd, T, idim, target_s=12.0):
+    """Oracle (numpy port of the reference forward) on the host cores, bounded to ~target_s of work."""
+    from oracle import kws_oracle
+    from wekws_amd.utils import synth
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    nb = 16
+    x = synth.synth_feats(nb, T, idim, seed=0)
+    kws_oracle.forward(cfg, sd, x, None)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        kws_oracle.forward(cfg, sd, x, None)
+        n += nb
+        el = time.perf_counter() - t0
+        if el > target_s or n >= 4096:
+            break
+    return {"value": round(n / el, 1), "unit": "utts/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} utterances (batches of {nb}, T={T}) through oracle/kws_oracle.py in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="ds_tcn_h256")
+    ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from wekws_amd import pack, parallel
+    from wekws_amd.model.kws_model import init_model
+    from wekws_amd.utils import synth
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = dict(synth.MODEL_CONFIGS[args.model])
+    T, idim, B = 98, cfg["input_dim"], args.batch
+    model = init_model(cfg)
+    sd = None
+    if rank == 0:  # only rank 0 "loads the checkpoint"; the others receive the folded blob over RCCL
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    parallel.broadcast_weights(model, src=0, device=dev)
+
+    x = torch.from_numpy(synth.synth_feats(B, T, idim, seed=100 + rank)).to(dev)
+    for _ in range(args.warmup):
+        y, cache = model(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        y, cache = model(x)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(y).all()
+
+    if rank == 0:
+        total_utts = B * world * args.steps
+        value = total_utts / elapsed
+        flop = FLOP_PER_UTT.get(args.model)
+        launch_flop = flop * B if flop else None
+        ach_tf = launch_flop / (kern_ms * 1e-3) / 1e12 if flop else None
+        hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "1-sec utterances/sec (40-d fbank -> DS-TCN posteriors), whole job",
+            "value": round(value, 1), "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} (DS-TCN 4x256, k=8, 287,490 params) forward, {B} x 1-s utterances "
+                                   f"per GPU, T=98 frames x 40-d fbank in HBM -> (B,98,2) sigmoid posteriors + "
+                                   f"(B,256,105) streaming cache",
+                       "batch_per_gpu": B, "frames": T, "feat_dim": idim, "parallelism": f"utterance-parallel x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_stack_kernel<DS,256,NT=7>",
+                         "achieved": round(ach_tf, 3) if ach_tf else None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach_tf / PEAK_F32_TFLOPS, 4) if ach_tf else None, "traffic": None,
+                         "kernel_ms": round(kern_ms, 4), "flop_per_launch": launch_flop,
+                         "hbm_achieved_GBs": round(hbm_gbs, 2), "hbm_peak_GBs": PEAK_HBM_GBS,
+                         "hbm_frac": round(hbm_gbs / PEAK_HBM_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_UTT * B},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * wekws_hip.h -- C ABI of libwekws_hip.so, the MI355X (gfx950) implementation of the
+ * WeKws keyword-spotting inference hot path.
+ *
+ * The reference has no C ABI of its own; the path sits behind two call boundaries
+ * (paths relative to the reference tree):
+ *   - Python   wekws/model/kws_model.py:65-76   KWSModel.forward(x, in_cache) -> (y, out_cache)
+ *              wekws/model/kws_model.py:78-90   KWSModel.forward_softmax
+ *   - C++      runtime/core/kws/keyword_spotting.h:26-55   wekws::KeywordSpotting::{ctor,Reset,Forward}
+ *              runtime/core/frontend/fbank.h:138-198       wenet::Fbank::Compute
+ * Every entry point below names the reference interface it replaces.  INTEGRATION.md shows
+ * the ctypes / C++ stubs a reference maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain C, no torch / STL types; all tensors are caller-owned DEVICE pointers (float32,
+ *     contiguous unless a stride is given); the library owns only its device copy of the
+ *     weights and a small per-model workspace.
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream); no hidden synchronisation.
+ *   - return value: 0 on success, a negative WEKWS_HIP_E* code on failure; the message is
+ *     available from wekws_hip_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - a model is immutable after create: wekws_hip_forward is re-entrant across streams as
+ *     long as each call has its own x / y / cache buffers, EXCEPT for calls that need the
+ *     internal workspace (T > WEKWS_HIP_TILE_FRAMES, or the global head), which serialise on
+ *     the model's workspace and must be issued on one stream at a time.
+ */
+#ifndef WEKWS_HIP_H_
+#define WEKWS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WEKWS_HIP_ABI_VERSION 1
+
+/* frames one kernel launch keeps resident in LDS; longer inputs are processed as a sequence of
+ * tiles that hand the causal left context over through the streaming cache */
+#define WEKWS_HIP_TILE_FRAMES 112
+
+enum wekws_hip_error {
+  WEKWS_HIP_OK = 0,
+  WEKWS_HIP_EINVAL = -1,      /* bad argument / unsupported configuration */
+  WEKWS_HIP_ENOMEM = -2,      /* device allocation failed */
+  WEKWS_HIP_EDEVICE = -3,     /* HIP runtime error (no device, launch failure ...) */
+  WEKWS_HIP_EUNSUPPORTED = -4 /* valid reference config that this build has no kernel for */
+};
+
+/* backbone.type of the reference model config (wekws/model/kws_model.py:126-170) */
+enum wekws_hip_backbone {
+  WEKWS_HIP_BACKBONE_DS_TCN = 0, /* type: tcn, ds: true   (wekws/model/tcn.py:91-119)  */
+  WEKWS_HIP_BACKBONE_TCN = 1,    /* type: tcn, ds: false  (wekws/model/tcn.py:67-88)   */
+  WEKWS_HIP_BACKBONE_MDTC = 2,   /* type: mdtc            (wekws/model/mdtc.py:201-276) */
+  WEKWS_HIP_BACKBONE_GRU = 3     /* type: gru             (wekws/model/kws_model.py:128-133) */
+};
+
+/* classifier of the reference config (wekws/model/kws_model.py:175-199) */
+enum wekws_hip_head {
+  WEKWS_HIP_HEAD_LINEAR = 0,  /* LinearClassifier, per frame   (classifier.py:54-67) */
+  WEKWS_HIP_HEAD_GLOBAL = 1,  /* GlobalClassifier, mean over T (classifier.py:19-28) */
+  WEKWS_HIP_HEAD_LAST = 2,    /* LastClassifier, last frame    (classifier.py:31-40) */
+  WEKWS_HIP_HEAD_IDENTITY = 3 /* classifier.type: identity     (kws_model.py:188-189) */
+};
+
+enum wekws_hip_activation {
+  WEKWS_HIP_ACT_IDENTITY = 0,
+  WEKWS_HIP_ACT_SIGMOID = 1 /* kws_model.py:196-199 */
+};
+
+/*
+ * Model descriptor = the reference's configs['model'] dict (kws_model.py:97-214) as plain ints.
+ * The weights travel separately as ONE float32 blob with inference-time constants already
+ * folded by the host packer (wekws_amd/pack.py): GlobalCMVN into the first Linear, every
+ * eval-mode BatchNorm1d into the preceding conv, Dropout dropped.  Blob layout, in order
+ * (row-major, all float32):
+ *   preprocessing       Wpre[hdim][idim], bpre[hdim]
+ *                       (preproc_relu = 0 encodes NoSubsampling / CMVN-only as a diagonal Wpre)
+ *   DS_TCN  per block   wd[hdim][ksize], bd[hdim], Wp[hdim][hdim], bp[hdim]
+ *   TCN     per block   W[hdim][hdim][ksize], b[hdim]
+ *   MDTC    per block   wd[hdim][ksize], bd[hdim], W1[hdim][hdim], b1[hdim], W2[hdim][hdim], b2[hdim]
+ *                       (block order: preprocessor, then stack 0 block 0 ... as mdtc.py:247-275)
+ *   GRU     per layer   W_ih[3H][H], W_hh[3H][H], b_ih[3H], b_hh[3H]   (gate order r,z,n)
+ *   head LINEAR         Wc[odim][hdim], bc[odim]
+ *   head GLOBAL / LAST  W1[head_hidden][hdim], b1[head_hidden], W2[odim][head_hidden], b2[odim]
+ *   head IDENTITY       (nothing; odim == hdim)
+ */
+typedef struct wekws_hip_desc {
+  int32_t abi_version;  /* WEKWS_HIP_ABI_VERSION */
+  int32_t backbone;     /* enum wekws_hip_backbone */
+  int32_t idim;         /* input_dim  (feature dim, e.g. 40) */
+  int32_t hdim;         /* hidden_dim (channels of the backbone) */
+  int32_t odim;         /* output_dim (keywords / classes / tokens) */
+  int32_t num_layers;   /* tcn: num_layers; gru: num_layers; mdtc: unused (0) */
+  int32_t num_stack;    /* mdtc: num_stack, else 0 */
+  int32_t stack_size;   /* mdtc: stack_size, else 0 */
+  int32_t kernel_size;  /* tcn / mdtc conv kernel size, gru: 0 */
+  int32_t preproc_relu; /* 1: LinearSubsampling1 (Linear+ReLU, subsampling.py:39-61); 0: no ReLU */
+  int32_t head;         /* enum wekws_hip_head */
+  int32_t head_hidden;  /* GLOBAL / LAST: width of the MLP (64 in kws_model.py:181-186), else 0 */
+  int32_t activation;   /* enum wekws_hip_activation */
+  int32_t reserved[3];  /* must be 0 */
+} wekws_hip_desc;
+
+typedef struct wekws_hip_model wekws_hip_model;
+
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+const char* wekws_hip_last_error(void);
+
+/* ABI version the library was built with (== WEKWS_HIP_ABI_VERSION of its header). */
+int wekws_hip_abi_version(void);
+
+/* Number of float32 elements the weight blob for `desc` must hold; 0 if desc is invalid. */
+size_t wekws_hip_blob_elems(const wekws_hip_desc* desc);
+
+/*
+ * Replaces: init_model(configs) + load_state_dict + .to(device)   (kws_model.py:97-214,
+ * wekws/utils/checkpoint.py:23-36) and KeywordSpotting::KeywordSpotting(model_path)
+ * (runtime/core/kws/keyword_spotting.cc:28-45).
+ * host_blob: `n_elems` float32 on the HOST, layout above.  device: HIP device ordinal.
+ */
+int wekws_hip_create(const wekws_hip_desc* desc, const float* host_blob, size_t n_elems,
+                     int device, wekws_hip_model** out);
+
+void wekws_hip_destroy(wekws_hip_model* m);
+
+/* Streaming-cache geometry, as the exporter publishes it in the ONNX metadata
+ * (wekws/bin/export_onnx.py:55-77: cache_dim, cache_len).  Conv backbones: cache is
+ * (B, cache_dim = hdim, cache_len = sum of paddings); GRU: (num_layers, B, hdim) and
+ * cache_len = 0 (the reference cannot export GRU). */
+int wekws_hip_cache_dim(const wekws_hip_model* m);
+int wekws_hip_cache_len(const wekws_hip_model* m);
+/* float32 elements of the cache tensor for a batch of B streams */
+size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B);
+/* float32 elements of y for (B, T): B*T*odim for per-frame heads, B*odim for GLOBAL/LAST */
+size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T);
+
+/*
+ * Replaces: KWSModel.forward(x, in_cache) -> (y, out_cache)   (kws_model.py:65-76) and the body
+ * of KeywordSpotting::Forward (keyword_spotting.cc:63-94, one ORT Run with the carried cache).
+ *   x          (B, T, idim) device, contiguous
+ *   in_cache   device, wekws_hip_cache_elems(m,B) floats, or NULL = the reference's empty-cache
+ *              sentinel torch.zeros(0,0,0) (zero left context, tcn.py:49-52; zero h0 for GRU)
+ *   y          device: (B, T, odim) for LINEAR / IDENTITY heads, (B, odim) for GLOBAL / LAST
+ *   out_cache  device, same geometry as in_cache, or NULL if the caller does not need it;
+ *              must not alias in_cache
+ *   softmax    0: forward; 1: forward_softmax (softmax over the last axis, kws_model.py:89)
+ */
+int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache,
+                      float* y, float* out_cache, int softmax, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Fbank front-end  --  replaces wenet::Fbank::Compute (runtime/core/frontend/fbank.h:138-198)
+ * with the framing rule of FeaturePipeline::AcceptWaveform (feature_pipeline.cc:30-47).
+ * ------------------------------------------------------------------------------------------*/
+enum wekws_hip_window {
+  WEKWS_HIP_WINDOW_HAMMING = 0, /* the C++ runtime (fbank.h:90-96) */
+  WEKWS_HIP_WINDOW_POVEY = 1    /* torchaudio.compliance.kaldi default (processor.py:196-202) */
+};
+
+typedef struct wekws_hip_fbank_cfg {
+  int32_t num_bins;     /* 40 (or 80) */
+  int32_t sample_rate;  /* 16000 */
+  int32_t frame_length; /* samples, 400 */
+  int32_t frame_shift;  /* samples, 160 */
+  int32_t window;       /* enum wekws_hip_window */
+  int32_t reserved[3];
+} wekws_hip_fbank_cfg;
+
+typedef struct wekws_hip_fbank wekws_hip_fbank;
+
+int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip_fbank** out);
+void wekws_hip_fbank_destroy(wekws_hip_fbank* f);
+/* frames produced for nsamp samples: 1 + (nsamp - frame_length) / frame_shift, 0 if too short
+ * (fbank.h:141-142) */
+int wekws_hip_fbank_num_frames(const wekws_hip_fbank* f, int nsamp);
+/*
+ * pcm    (B, nsamp) device float32 in int16 scale (NOT divided by 32768; wav.h:98-102)
+ * feats  (B, num_frames, num_bins) device float32
+ */
+int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsamp, float* feats,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEKWS_HIP_H_ */

@@ -1,0 +1,61 @@
+"""ctypes access to the fbank oracles  --  TEST INFRASTRUCTURE, NOT PRODUCT (see oracle/fbank_oracle.c).
+
+fbank(wave, num_bins)      the plain-C restatement (oracle/_build/libfbank_oracle.so)
+ref_fbank(wave, num_bins)  the reference's own C++ front-end compiled into oracle/_ref/ (None if absent)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PORT = os.path.join(_HERE, "_build", "libfbank_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_fbank.so")
+_port = _ref = None
+
+
+def _load_port():
+    global _port
+    if _port is None:
+        if not os.path.exists(_PORT):
+            raise RuntimeError(f"{_PORT} missing: run `make -C oracle`")
+        _port = C.CDLL(_PORT)
+        _port.wekws_oracle_fbank.restype = C.c_int
+        _port.wekws_oracle_fbank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return _port
+
+
+def have_ref() -> bool:
+    return os.path.exists(_REF)
+
+
+def num_frames(nsamp, frame_length=400, frame_shift=160):
+    return 0 if nsamp < frame_length else 1 + (nsamp - frame_length) // frame_shift
+
+
+def fbank(wave, num_bins=40, sample_rate=16000, frame_length=400, frame_shift=160, window=0):
+    wave = np.ascontiguousarray(wave, dtype=np.float32)
+    nf = num_frames(wave.size, frame_length, frame_shift)
+    out = np.empty((nf, num_bins), np.float32)
+    if nf:
+        n = _load_port().wekws_oracle_fbank(wave.ctypes.data, wave.size, num_bins, sample_rate, frame_length,
+                                            frame_shift, window, out.ctypes.data)
+        assert n == nf
+    return out
+
+
+def ref_fbank(wave, num_bins=40, sample_rate=16000, first_push=0):
+    """Reference front-end (25 ms / 10 ms framing fixed by FeaturePipelineConfig, feature_pipeline.h:34-39)."""
+    global _ref
+    if not have_ref():
+        return None
+    if _ref is None:
+        _ref = C.CDLL(_REF)
+        _ref.ref_fbank.restype = C.c_int
+        _ref.ref_fbank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    wave = np.ascontiguousarray(wave, dtype=np.float32)
+    nf = num_frames(wave.size, sample_rate // 1000 * 25, sample_rate // 1000 * 10)
+    out = np.empty((nf, num_bins), np.float32)
+    n = _ref.ref_fbank(wave.ctypes.data, wave.size, num_bins, sample_rate, first_push, out.ctypes.data)
+    assert n == nf, (n, nf)
+    return out

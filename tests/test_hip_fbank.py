@@ -1,0 +1,53 @@
+"""GPU: the HIP fbank kernel (wekws_hip_fbank_compute) against the reference-recorded goldens and the C oracle.
+Tolerance: 1e-4 abs on log-mel values would hold against an exact FFT (SURVEY.md appendix C measured 2.9e-5
+between the reference's recurrence-twiddle FFT and float64); the reference's own float32 table error is of
+the same order, so the test allows 2e-4 abs (values span [-16, 26])."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank_oracle
+from tests.golden.fbank_cases import FBANK_CASES, fbank_input
+from wekws_amd.frontend import Fbank
+from wekws_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def fgolden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "fbank_golden.npz"))
+
+
+@pytest.mark.parametrize("case", FBANK_CASES, ids=[c["name"] for c in FBANK_CASES])
+def test_golden(case, fgolden):
+    pcm = fbank_input(case)
+    fb = Fbank(num_bins=case["num_bins"])
+    got = fb(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    ref = fgolden[case["name"]]
+    assert got.shape == ref.shape
+    assert float(np.abs(got - ref).max()) <= TOL
+
+
+def test_batch_1024_vs_oracle_sample():
+    pcm = synth.synth_pcm(1024, 16000, seed=9, kind="noise")
+    fb = Fbank(40)
+    got = fb(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert got.shape == (1024, 98, 40) and np.isfinite(got).all()
+    for i in (0, 1, 511, 1023):
+        assert float(np.abs(got[i] - fbank_oracle.fbank(pcm[i], 40)).max()) <= TOL
+    # shift property: frame t of the signal delayed by one hop == frame t+1 of the original
+    sh = fb(torch.from_numpy(np.ascontiguousarray(pcm[:4, 160:])).cuda()).cpu().numpy()
+    assert float(np.abs(sh[:, :97] - got[:4, 1:98]).max()) <= 1e-5
+
+
+def test_short_and_empty():
+    fb = Fbank(40)
+    assert fb(torch.zeros(2, 399, device="cuda")).shape == (2, 0, 40)
+    assert fb(torch.zeros(0, 16000, device="cuda")).shape == (0, 98, 40)
+    with pytest.raises(ValueError):
+        fb(torch.zeros(2, 16000))

@@ -1,0 +1,174 @@
+"""GPU parity tests: the HIP path (wekws_amd.KWSModel -> ctypes -> libwekws_hip.so) against
+  (a) the golden vectors recorded from the live reference PyTorch CPU forward (tests/golden),
+  (b) the numpy oracle on other seeds / shapes,
+  (c) size-independent properties at BASELINE's full batch sizes (streaming == one-shot, batch-composition
+      invariance, empty cache == zero cache).
+Tolerance: north_star's 1e-4 abs on posterior scores; logits / cache activations use 1e-4 relative to
+max(1, max|ref|) since they are unnormalised."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kws_oracle
+from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
+from wekws_amd.model.kws_model import init_model
+from wekws_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+POSTERIOR_TOL = 1e-4
+
+
+def tol_for(ref):
+    return POSTERIOR_TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def build(cfg, sd, device="cuda"):
+    m = init_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return m.to(device).eval()
+
+
+def run(model, x, cache=None, softmax=False, chunks=None):
+    dev = next(model.parameters()).device
+    xt = torch.from_numpy(x).to(dev)
+    fwd = model.forward_softmax if softmax else model.forward
+    c = None if cache is None else torch.from_numpy(cache).to(dev)
+    if chunks:
+        ys, t = [], 0
+        for n in chunks:
+            y, c = fwd(xt[:, t:t + n]) if c is None else fwd(xt[:, t:t + n], c)
+            ys.append(y)
+            t += n
+        y = torch.cat(ys, dim=1)
+    else:
+        y, c = fwd(xt) if c is None else fwd(xt, c)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), c.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def models():
+    cache = {}
+
+    def get(case):
+        key = (case["model"], case.get("odim"), case["cmvn"], case.get("norm_var", True), case["wseed"])
+        if key not in cache:
+            cfg, sd = case_weights(case)
+            cache[key] = (cfg, sd, build(cfg, sd))
+        return cache[key]
+    return get
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_golden(case, golden, models):
+    """HIP vs the live-reference golden vectors (41 cases: every backbone/head, ragged T, caches, streaming)."""
+    cfg, sd, model = models(case)
+    x = case_input(case)
+    y, cache = run(model, x, case_in_cache(case, cfg), softmax=case.get("softmax", False), chunks=case.get("chunks"))
+    gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
+    assert y.shape == gy.shape
+    assert max_abs(y, gy) <= tol_for(gy), f"y err {max_abs(y, gy):.3e}"
+    c = cache if cfg["backbone"]["type"] == "gru" else cache[:1]
+    assert c.shape == gc.shape
+    assert max_abs(c, gc) <= tol_for(gc), f"cache err {max_abs(c, gc):.3e}"
+
+
+@pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 5, 98), ("ds_tcn_h64", 7, 33), ("tcn_h64", 3, 98),
+                                      ("mdtc_h64", 5, 98), ("mdtc_small", 9, 61), ("mdtc_h64_global12", 5, 130),
+                                      ("mdtc_small_last12", 6, 98), ("gru_2x128", 19, 40), ("gru_1x128", 3, 98)])
+def test_vs_oracle_other_seeds(name, B, T):
+    """Different weights (wseed 77) / inputs (xseed 5) / odd batch sizes than the goldens, vs the numpy oracle."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 77)
+    x = synth.synth_feats(B, T, cfg["input_dim"], seed=5)
+    model = build(cfg, sd)
+    y, cache = run(model, x)
+    ry, rc = kws_oracle.forward(cfg, sd, x, None)
+    assert max_abs(y, ry) <= tol_for(ry)
+    assert max_abs(cache, rc) <= tol_for(rc)
+
+
+@pytest.mark.parametrize("name,B", [("ds_tcn_h256", 1024), ("mdtc_h64", 1024), ("mdtc_h64_global12", 1024),
+                                    ("gru_2x128", 256)])
+def test_full_batch_properties(name, B):
+    """BASELINE-size batches (configs 1-3): spot-check 6 utterances against the oracle, and check the
+    size-independent properties: a sub-batch gives bit-identical rows; 10-frame streaming == one-shot."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    T = 98 if cfg["backbone"]["type"] != "gru" else 50
+    x = synth.synth_feats(B, T, cfg["input_dim"], seed=3)
+    model = build(cfg, sd)
+    y, cache = run(model, x)
+    assert np.isfinite(y).all() and np.isfinite(cache).all()
+    idx = np.array([0, 1, B // 3, B // 2, B - 2, B - 1])
+    ry, rc = kws_oracle.forward(cfg, sd, x[idx], None)
+    assert max_abs(y[idx], ry) <= tol_for(ry)
+    gru = cfg["backbone"]["type"] == "gru"
+    csel = cache[:, idx] if gru else cache[idx]
+    assert max_abs(csel, rc) <= tol_for(rc)
+    # batch-composition invariance: utterances are independent, so any sub-batch reproduces its rows exactly
+    ys, cs = run(model, np.ascontiguousarray(x[idx]))
+    assert np.array_equal(ys, y[idx])
+    assert np.array_equal(cs, csel)
+    # streaming in 10-frame chunks == one-shot (per-frame heads only)
+    if "classifier" not in cfg:
+        chunks = [10] * (T // 10) + ([T % 10] if T % 10 else [])
+        yst, cst = run(model, x, chunks=chunks)
+        assert max_abs(yst, y) <= 2e-5
+        assert max_abs(cst, cache) <= 2e-5 * max(1.0, float(np.abs(cache).max()))
+
+
+def test_empty_cache_equals_zero_cache():
+    from wekws_amd import pack
+    for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+        model = build(cfg, sd)
+        x = synth.synth_feats(4, 37, cfg["input_dim"], seed=9)
+        y0, c0 = run(model, x)
+        y1, c1 = run(model, x, np.zeros(pack.cache_shape(pack.parse_config(cfg), 4), np.float32))
+        assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
+
+
+def test_long_input_tiling_matches_oracle():
+    """T > 112 goes through several LDS tiles that hand the context over via the workspace cache."""
+    from wekws_amd import pack
+    for name, T in (("ds_tcn_h64", 500), ("mdtc_small_global12", 333), ("tcn_h64", 225)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 5)
+        model = build(cfg, sd)
+        x = synth.synth_feats(3, T, cfg["input_dim"], seed=11)
+        y, cache = run(model, x)
+        ry, rc = kws_oracle.forward(cfg, sd, x, None)
+        assert max_abs(y, ry) <= tol_for(ry)
+        assert max_abs(cache, rc) <= tol_for(rc)
+
+
+def test_no_cpu_fallback():
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"])
+    m = init_model(cfg)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 10, 40))
+    m = m.to("cuda")
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 10, 41, device="cuda"))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 10, 40, device="cuda"), torch.zeros(1, 64, 3, device="cuda"))
+
+
+def test_weight_update_repacks():
+    """load_state_dict after the first forward must be honoured (handle is keyed on tensor versions)."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"])
+    x = synth.synth_feats(2, 20, 40, seed=1)
+    sd1 = synth.synth_state_dict(pack.model_spec(cfg), 1)
+    sd2 = synth.synth_state_dict(pack.model_spec(cfg), 2)
+    model = build(cfg, sd1)
+    y1, _ = run(model, x)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    y2, _ = run(model, x)
+    r2, _ = kws_oracle.forward(cfg, sd2, x, None)
+    assert max_abs(y2, r2) <= POSTERIOR_TOL and max_abs(y1, y2) > 1e-3

@@ -1,0 +1,34 @@
+"""The numpy oracle (oracle/kws_oracle.py) against every golden vector recorded from the LIVE reference
+(tests/golden/make_golden.py).  CPU only.  Also pins wekws_amd.pack.model_spec: the seeded weights are
+generated from OUR state_dict spec and their checksum must equal the one recorded from the reference's
+own state_dict."""
+import numpy as np
+import pytest
+
+from oracle import kws_oracle
+from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
+from wekws_amd.utils import synth
+
+Y_TOL = 5e-6      # oracle vs reference on posteriors / logits (float32 summation-order noise)
+CACHE_TOL = 2e-5  # MDTC activations are unnormalised and grow to O(10)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_golden(case, golden):
+    cfg, sd = case_weights(case)
+    name = case["name"]
+    assert abs(synth.checksum(sd) - float(golden[name + "/wsum"])) < 1e-6 * float(golden[name + "/wsum"]), \
+        "state_dict spec / synthetic weight stream differs from the one the golden was made with"
+    x = case_input(case)
+    assert abs(np.abs(x.astype(np.float64)).sum() - float(golden[name + "/xsum"])) < 1e-9 * float(golden[name + "/xsum"])
+    cache0 = case_in_cache(case, cfg)
+    if case.get("chunks"):
+        y, cache = kws_oracle.forward_streaming(cfg, sd, x, case["chunks"], cache0) if not case.get("softmax") else (None, None)
+    else:
+        y, cache = kws_oracle.forward(cfg, sd, x, cache0, softmax=case.get("softmax", False))
+    gy, gc = golden[name + "/y"], golden[name + "/cache"]
+    assert y.shape == gy.shape
+    assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+    c = cache if cfg["backbone"]["type"] == "gru" else cache[:1]
+    assert c.shape == gc.shape
+    assert max_abs(c, gc) <= CACHE_TOL * max(1.0, float(np.abs(gc).max()))

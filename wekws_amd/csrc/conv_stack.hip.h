@@ -1,0 +1,515 @@
+// Fused conv-backbone forward for gfx950 (MI355X): preprocessing Linear -> residual conv blocks ->
+// classifier head, ONE kernel launch per (batch, <=112-frame tile).  Activations never leave the CU:
+// the (channels x frames) tile of every utterance lives in LDS, the 1x1 / dense convolutions run on
+// the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), the depthwise dilated taps, folded BatchNorm,
+// ReLU, residual and sigmoid run on the VALU around them.
+//
+// Reference semantics implemented here (paths relative to the reference tree):
+//   KWSModel.forward                       wekws/model/kws_model.py:65-76
+//   LinearSubsampling1.forward             wekws/model/subsampling.py:53-57
+//   TCN.forward / Block.forward            wekws/model/tcn.py:139-166, :35-61
+//   DsCnnBlock.cnn / CnnBlock.cnn          wekws/model/tcn.py:101-114, :75-84
+//   MDTC.forward / TCNStack / TCNBlock     wekws/model/mdtc.py:242-276, :181-198, :95-121
+//   DSDilatedConv1d.forward                wekws/model/mdtc.py:55-59
+//   Linear/Global/Last classifiers         wekws/model/classifier.py:63-67, :26-28, :38-40
+//
+// Work decomposition (wave64, 512-thread workgroups = 2 waves per SIMD):
+//   - a workgroup owns U utterances (C=256/128: 1, C=64: 2, C=32: 4);
+//   - GEMM view of a 1x1 conv:  D[o][t] = sum_c W[o][c] * a[c][t];  MFMA A operand = weights
+//     (pre-packed on the host into per-lane fragment order, streamed from L2 with 16-byte loads),
+//     B operand = activations read from LDS rows (channel-major, row stride == 16 mod 32 so that the
+//     4-row x 16-frame fragment read is bank-conflict free), D = 4 consecutive output channels of one
+//     frame per lane;
+//   - each wave owns OW o-tiles (16 output channels each) x NT t-tiles (16 frames each) of one
+//     utterance and keeps those accumulators in registers for a whole layer;
+//   - the K dimension is produced in chunks of KC rows into a double-buffered LDS slab by all waves
+//     (depthwise taps from the resident tile, causal halo from the streaming cache in global memory
+//     or zeros), one barrier per chunk, so VALU/LDS production of chunk n+1 overlaps the MFMAs of
+//     chunk n issued by the partner wave on the same SIMD.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wekws {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { KIND_DS = 0, KIND_TCN = 1, KIND_MDTC = 2 };
+enum : int { HEAD_LINEAR = 0, HEAD_GLOBAL = 1, HEAD_LAST = 2, HEAD_IDENTITY = 3 };
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+
+// One residual block.  Offsets are in floats from StackParams::w.
+struct BlockDesc {
+  int32_t dil;        // dilation
+  int32_t pad;        // (ksize-1)*dil  == frames of left context == this block's cache slice length
+  int32_t cache_off;  // offset of this block's slice inside the cache's last axis
+  int32_t zadd;       // MDTC: 1 if the block closes a stack (output is added to the stack sum)
+  uint32_t dw_w;      // DS/MDTC: folded depthwise weights [C][ksize]
+  uint32_t dw_b;      // DS/MDTC: folded depthwise bias [C]
+  uint32_t a1;        // packed MFMA A operand of the first GEMM (DS: pointwise, TCN: dense conv, MDTC: pointwise)
+  uint32_t b1;        // its folded bias [C]
+  uint32_t a2;        // MDTC: packed A of conv2
+  uint32_t b2;        // MDTC: folded bias of conv2 [C]
+};
+
+struct StackParams {
+  const float* w;           // device weights (folded + packed)
+  const BlockDesc* blocks;  // device array
+  int32_t nblocks;
+  int32_t idim;             // feature dim
+  int32_t kpre;             // idim rounded up to 16
+  int32_t ksize;
+  int32_t odim;
+  int32_t pre_relu;
+  uint32_t pre_a, pre_b;    // packed A [C/16][kpre/16][64][4], bias [C]
+  int32_t head;             // HEAD_*
+  int32_t head_hidden;
+  int32_t sigmoid;
+  uint32_t head_w, head_b;  // LINEAR: Wc[odim][C], bc;  GLOBAL/LAST: W1[hh][C], b1
+  uint32_t head_w2, head_b2;  // GLOBAL/LAST: W2[odim][hh], b2
+  int32_t cache_len;        // P = sum of pads
+};
+
+struct CallArgs {
+  const float* x;         // first frame of this tile, utterance 0
+  int64_t xs_b;           // floats between utterances in x
+  const float* in_cache;  // (B, C, P) or nullptr
+  float* out_cache;       // (B, C, P) or nullptr
+  float* y;               // first output row of this tile (per-frame heads) / (B, odim) (GLOBAL/LAST)
+  int64_t ys_b;           // floats between utterances in y
+  float* gsum;            // GLOBAL head, multi-tile: running per-channel sums (B, C) or nullptr
+  int32_t B;
+  int32_t T;              // frames in this tile (1..16*NT)
+  int32_t T_total;        // frames of the whole call (GLOBAL mean divisor)
+  int32_t first_tile, last_tile;
+};
+
+template <int KIND, int C, int NT>
+struct Geom {
+  static constexpr int U = (C >= 128) ? 1 : (128 / C);              // utterances per workgroup
+  static constexpr int OT = C / 16;                                  // o-tiles per utterance
+  static constexpr int OW = (OT * U >= 16) ? 2 : 1;                  // o-tiles per wave
+  static constexpr int WO = OT / OW;                                 // waves along o
+  static constexpr int WU = kWaves / WO;                             // waves along utterances
+  static_assert(WO * WU == kWaves && WU == U, "wave decomposition");
+  static constexpr int SS = (NT % 2) ? 16 * NT : 16 * NT + 16;       // LDS row stride (== 16 mod 32)
+  static constexpr int KC = (C >= 64) ? 32 : 16;                     // K rows per produced chunk
+  static constexpr int R = (KIND == KIND_MDTC) ? (C > 2 * KC ? C : 2 * KC) : 2 * KC;  // slab rows / utt
+  static constexpr int H_FLOATS = U * C * SS;
+  static constexpr int S_FLOATS = U * R * SS;
+  static constexpr size_t LDS_BYTES = size_t(H_FLOATS + S_FLOATS) * 4;
+};
+
+// ---------------------------------------------------------------------------------------------
+// MFMA over `nk16` groups of 16 K-rows.  ap: this lane's float4 pointer to (otile 0 of the wave,
+// first 16-row group); consecutive groups are 64 float4 apart, consecutive o-tiles ot_stride apart.
+// bl: LDS pointer to (first K row + lane>>4, frame lane&15) of the wave's utterance.
+// ---------------------------------------------------------------------------------------------
+template <int OW, int NT, int SS>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[OW][NT], const float4* __restrict__ ap,
+                                          int ot_stride, const float* bl, int nk16) {
+  for (int g = 0; g < nk16; ++g) {
+    float4 a[OW];
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) a[ow] = ap[ow * ot_stride + g * 64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float b[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) b[tt] = bl[(g * 16 + s * 4) * SS + tt * 16];
+#pragma unroll
+      for (int ow = 0; ow < OW; ++ow) {
+        const float av = s == 0 ? a[ow].x : s == 1 ? a[ow].y : s == 2 ? a[ow].z : a[ow].w;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[tt], acc[ow][tt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int OW, int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[OW][NT]) {
+#pragma unroll
+  for (int ow = 0; ow < OW; ++ow)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[ow][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int C, int NT>
+__global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackParams P, const CallArgs A) {
+  using G = Geom<KIND, C, NT>;
+  constexpr int U = G::U, OW = G::OW, SS = G::SS, KC = G::KC, R = G::R;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const hbuf = lds;                 // [U][C][SS]   resident activations h_i
+  float* const slab = lds + G::H_FLOATS;   // [U][R][SS]   GEMM B-operand rows
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wo = wave % G::WO;             // which o-tile group
+  const int wu = wave / G::WO;             // which utterance of the workgroup
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b0 = blockIdx.x * U;           // first utterance of this workgroup
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int ks = P.ksize;
+
+  // producer mapping: 16 lanes share a row, each lane covers frames tl, tl+16, ...
+  const int pg = tid >> 4, tl = tid & 15;
+
+  // this wave's accumulator geometry
+  const int o_base = wo * OW * 16;         // first output channel of the wave
+  float* const h_w = hbuf + wu * C * SS;   // the wave's utterance tile
+  const float* const slab_w = slab + wu * R * SS + lq * SS + l15;
+  const bool utt_ok = (b0 + wu) < A.B;
+
+  f32x4 acc[OW][NT];
+  f32x4 zsum[KIND == KIND_MDTC ? OW : 1][KIND == KIND_MDTC ? NT : 1];
+  if constexpr (KIND == KIND_MDTC) zero_acc(zsum);
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+    zero_acc(acc);
+    const int ot_stride = (P.kpre / 16) * 64;
+    const float4* ap = reinterpret_cast<const float4*>(W + P.pre_a) + (wo * OW) * ot_stride + lane;
+    for (int k0 = 0; k0 < P.kpre; k0 += R) {
+      const int rows = min(R, P.kpre - k0);
+      __syncthreads();
+      // slab[u][r][t] = x[b0+u][t][k0+r]  (zero beyond idim / T / B): coalesced global read over (t,k)
+      for (int u = 0; u < U; ++u) {
+        const bool ok = (b0 + u) < A.B;
+        const float* xu = A.x + int64_t(b0 + u) * A.xs_b;
+        for (int e = tid; e < 16 * NT * rows; e += kThreads) {
+          const int t = e / rows, r = e - t * rows;
+          const int k = k0 + r;
+          float v = 0.f;
+          if (ok && t < T && k < P.idim) v = xu[int64_t(t) * P.idim + k];
+          slab[(u * R + r) * SS + t] = v;
+        }
+      }
+      __syncthreads();
+      mfma_rows<OW, NT, SS>(acc, ap + (k0 / 16) * 64, ot_stride, slab_w, rows / 16);
+    }
+    // epilogue -> h
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+      const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+          if (P.pre_relu) v = fmaxf(v, 0.f);
+          h_w[(o + r) * SS + t] = (t < T) ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ======================================= residual blocks =======================================
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    const BlockDesc bd = P.blocks[bi];
+    const int d = bd.dil, pad = bd.pad;
+
+    // ---- streaming cache hand-over: new_cache = last `pad` frames of [cache | h]  (tcn.py:54, mdtc.py:112)
+    if (A.out_cache) {
+      for (int e = tid; e < U * C * pad; e += kThreads) {
+        const int p = e % pad;
+        const int uc = e / pad;
+        const int u = uc / C, c = uc - u * C;
+        if (b0 + u < A.B) {
+          const int src = T + p - pad;  // index into h (negative: still inside the old cache)
+          float v;
+          if (src >= 0) v = hbuf[(u * C + c) * SS + src];
+          else v = A.in_cache ? A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + T + p] : 0.f;
+          A.out_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p] = v;
+        }
+      }
+    }
+
+    // left-context fetch for frame index idx < 0 (relative to the tile start)
+    auto halo = [&](int u, int c, int idx) -> float {
+      if (!A.in_cache || (b0 + u) >= A.B) return 0.f;
+      return A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + pad + idx];
+    };
+
+    // ---- producer of K-chunk n into slab buffer `buf` (rows buf*KC .. buf*KC+KC-1 of every utterance)
+    auto produce = [&](int n, int buf) {
+      for (int item = pg; item < U * KC; item += kThreads / 16) {
+        const int u = item / KC, r = item - u * KC;
+        float* dst = slab + (u * R + buf * KC + r) * SS;
+        if constexpr (KIND == KIND_TCN) {
+          // dense conv as GEMM over K' = (c, j):  row = h[c][t - (ks-1-j)*d]      (tcn.py:76-80)
+          const int kk = n * KC + r;
+          const int c = kk / ks, j = kk - c * ks;
+          const int sh = (ks - 1 - j) * d;
+          const float* hc = hbuf + (u * C + c) * SS;
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            const int t = tl + 16 * m;
+            const int idx = t - sh;
+            float v = (idx >= 0) ? hc[idx] : halo(u, c, idx);
+            dst[t] = (t < T) ? v : 0.f;
+          }
+        } else {
+          // depthwise dilated conv + folded BN (+ReLU for DS-TCN)        (tcn.py:102-109, mdtc.py:55-58)
+          const int c = n * KC + r;
+          const float* hc = hbuf + (u * C + c) * SS;
+          const float* wd = W + bd.dw_w + c * ks;
+          const float bias = W[bd.dw_b + c];
+          float o[NT];
+#pragma unroll
+          for (int m = 0; m < NT; ++m) o[m] = bias;
+          for (int j = 0; j < ks; ++j) {
+            const float wj = wd[j];
+            const int sh = (ks - 1 - j) * d;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+              const int idx = tl + 16 * m - sh;
+              const float v = (idx >= 0) ? hc[idx] : halo(u, c, idx);
+              o[m] = fmaf(wj, v, o[m]);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            const int t = tl + 16 * m;
+            float v = o[m];
+            if (KIND == KIND_DS) v = fmaxf(v, 0.f);
+            dst[t] = (t < T) ? v : 0.f;
+          }
+        }
+      }
+    };
+
+    // ---- GEMM 1 over K (= C, or C*ksize for the dense conv), double-buffered chunks
+    const int K1 = (KIND == KIND_TCN) ? C * ks : C;
+    const int nch = K1 / KC;
+    const int ot_stride1 = (K1 / 16) * 64;
+    const float4* ap1 = reinterpret_cast<const float4*>(W + bd.a1) + (wo * OW) * ot_stride1 + lane;
+    zero_acc(acc);
+    produce(0, 0);
+    __syncthreads();
+    for (int n = 0; n < nch; ++n) {
+      if (n + 1 < nch) produce(n + 1, (n + 1) & 1);
+      mfma_rows<OW, NT, SS>(acc, ap1 + n * (KC / 16) * 64, ot_stride1, slab_w + (n & 1) * KC * SS, KC / 16);
+      __syncthreads();
+    }
+
+    if constexpr (KIND == KIND_MDTC) {
+      // ---- mid = ReLU(BN1(pointwise))  -> slab rows [0, C) ; then conv2 (1x1) + BN2      (mdtc.py:113-116)
+      float* mid_w = slab + wu * R * SS;
+#pragma unroll
+      for (int ow = 0; ow < OW; ++ow) {
+        const int o = o_base + ow * 16 + lq * 4;
+        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const int t = tt * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+            mid_w[(o + r) * SS + t] = (t < T) ? fmaxf(v, 0.f) : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+      const int ot_stride2 = (C / 16) * 64;
+      const float4* ap2 = reinterpret_cast<const float4*>(W + bd.a2) + (wo * OW) * ot_stride2 + lane;
+      zero_acc(acc);
+      mfma_rows<OW, NT, SS>(acc, ap2, ot_stride2, slab_w, C / 16);
+    }
+
+    // ---- epilogue: bias (+ReLU) + residual, in place into h
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+      const float4 bias = *reinterpret_cast<const float4*>(W + (KIND == KIND_MDTC ? bd.b2 : bd.b1) + o);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+          float* hp = h_w + (o + r) * SS + t;
+          if constexpr (KIND == KIND_MDTC) {
+            v = fmaxf(v + *hp, 0.f);        // ReLU(out + inputs)            (mdtc.py:117-118)
+            if (bd.zadd) zsum[ow][tt][r] += v;  // sum of stack outputs       (mdtc.py:270-273)
+          } else {
+            v = fmaxf(v, 0.f) + *hp;        // y + x, nothing after the add   (tcn.py:60)
+          }
+          if (t < T) *hp = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (KIND == KIND_MDTC) {
+    // backbone output = sum of the stack outputs: overwrite the resident tile with it
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t < T) h_w[(o + r) * SS + t] = zsum[ow][tt][r];
+      }
+    }
+    __syncthreads();
+  }
+  (void)utt_ok;
+
+  // ============================================ head ============================================
+  const int K = P.odim;
+  if (P.head == HEAD_LINEAR) {
+    // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
+    for (int e = tid; e < U * K * T; e += kThreads) {
+      const int t = e % T;
+      const int uk = e / T;
+      const int u = uk / K, k = uk - u * K;
+      if (b0 + u >= A.B) continue;
+      const float* hc = hbuf + u * C * SS + t;
+      const float* wk = W + P.head_w + k * C;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int c = 0; c < C; c += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
+        s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
+        s1 = fmaf(w4.y, hc[(c + 1) * SS], s1);
+        s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
+        s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
+      }
+      float v = (s0 + s1) + (s2 + s3) + W[P.head_b + k];
+      if (P.sigmoid) v = sigmoidf_(v);
+      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
+    }
+  } else if (P.head == HEAD_IDENTITY) {
+    for (int e = tid; e < U * T * C; e += kThreads) {
+      const int c = e % C;
+      const int ut = e / C;
+      const int u = ut / T, t = ut - u * T;
+      if (b0 + u >= A.B) continue;
+      float v = hbuf[(u * C + c) * SS + t];
+      if (P.sigmoid) v = sigmoidf_(v);
+      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * C + c] = v;
+    }
+  } else {
+    // GLOBAL: m = mean_t h ; LAST: m = h[:, -1]  ->  W2 ReLU(W1 m + b1) + b2   (classifier.py:26-28, :38-40)
+    float* mvec = slab;                 // [U][C]
+    float* hid = slab + U * C;          // [U][head_hidden]
+    const int HH = P.head_hidden;
+    for (int e = tid; e < U * C; e += kThreads) {
+      const int u = e / C, c = e - u * C;
+      const float* hc = hbuf + (u * C + c) * SS;
+      float s;
+      if (P.head == HEAD_GLOBAL) {
+        s = 0.f;
+        for (int t = 0; t < T; ++t) s += hc[t];
+        if (A.gsum && (b0 + u) < A.B) {
+          float* gp = A.gsum + int64_t(b0 + u) * C + c;
+          if (!A.first_tile) s += *gp;
+          if (!A.last_tile) *gp = s;
+        }
+        s = s / float(A.T_total);
+      } else {
+        s = hc[T - 1];
+      }
+      mvec[e] = s;
+    }
+    __syncthreads();
+    if (A.last_tile) {
+      for (int e = tid; e < U * HH; e += kThreads) {
+        const int u = e / HH, j = e - u * HH;
+        const float* w1 = W + P.head_w + j * C;
+        float s = W[P.head_b + j];
+        for (int c = 0; c < C; ++c) s = fmaf(w1[c], mvec[u * C + c], s);
+        hid[e] = fmaxf(s, 0.f);
+      }
+      __syncthreads();
+      for (int e = tid; e < U * K; e += kThreads) {
+        const int u = e / K, k = e - u * K;
+        if (b0 + u >= A.B) continue;
+        const float* w2 = W + P.head_w2 + k * HH;
+        float s = W[P.head_b2 + k];
+        for (int j = 0; j < HH; ++j) s = fmaf(w2[j], hid[u * HH + j], s);
+        if (P.sigmoid) s = sigmoidf_(s);
+        A.y[int64_t(b0 + u) * A.ys_b + k] = s;
+      }
+    }
+  }
+}
+
+// Row softmax over the last axis (KWSModel.forward_softmax, kws_model.py:89): one wave per row.
+static __global__ void softmax_rows_kernel(float* y, int64_t rows, int K) {
+  const int64_t row = int64_t(blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* p = y + row * K;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += __expf(p[k] - mx);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float inv = 1.0f / s;
+  for (int k = lane; k < K; k += 64) p[k] = __expf(p[k] - mx) * inv;
+}
+
+// launcher implemented per KIND in conv_stack_{ds,tcn,mdtc}.hip
+template <int KIND>
+int launch_conv_stack(int C, int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+template <> int launch_conv_stack<KIND_DS>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+template <> int launch_conv_stack<KIND_TCN>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+template <> int launch_conv_stack<KIND_MDTC>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+
+template <int KIND, int C, int NT>
+inline int launch_one(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  using G = Geom<KIND, C, NT>;
+  static bool attr_set = false;
+  auto kern = conv_stack_kernel<KIND, C, NT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(G::LDS_BYTES)) != hipSuccess)
+      return -3;
+    attr_set = true;
+  }
+  const int grid = (A.B + G::U - 1) / G::U;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+#define WEKWS_DISPATCH_NT(KIND, CC)                                            \
+  switch (nt) {                                                                \
+    case 1: return launch_one<KIND, CC, 1>(P, A, stream);                      \
+    case 2: return launch_one<KIND, CC, 2>(P, A, stream);                      \
+    case 4: return launch_one<KIND, CC, 4>(P, A, stream);                      \
+    case 7: return launch_one<KIND, CC, 7>(P, A, stream);                      \
+    default: return -1;                                                        \
+  }
+
+// hidden dims with a compiled kernel: the reference recipes use 32 / 64 / 256 (128 for GRU);
+// MDTC keeps a second full-width tile in LDS, which does not fit at C = 256.
+#define WEKWS_DEFINE_LAUNCHER(KIND, WITH256)                                   \
+  template <>                                                                  \
+  int launch_conv_stack<KIND>(int C, int nt, const StackParams& P, const CallArgs& A, hipStream_t stream) { \
+    switch (C) {                                                               \
+      case 32: WEKWS_DISPATCH_NT(KIND, 32)                                     \
+      case 64: WEKWS_DISPATCH_NT(KIND, 64)                                     \
+      case 128: WEKWS_DISPATCH_NT(KIND, 128)                                   \
+      case 256: if constexpr (WITH256) { WEKWS_DISPATCH_NT(KIND, 256) } else return -4; \
+      default: return -4;                                                      \
+    }                                                                          \
+  }
+
+}  // namespace wekws

@@ -1,0 +1,482 @@
+// libwekws_hip.so -- C ABI (include/wekws_hip.h) over the gfx950 kernels.
+// Host side only: descriptor validation, weight-blob parsing, MFMA fragment pre-packing, upload,
+// tiling of long inputs, kernel dispatch.  No torch, no STL types across the boundary.
+#include "../../include/wekws_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "conv_stack.hip.h"
+#include "fbank.hip.h"
+#include "gru.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "%s: %s", \
+                  #expr, hipGetErrorString(e_));                                               \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Host-side builder of the device weight image; every section starts 16-byte aligned.
+struct Image {
+  std::vector<float> data;
+  uint32_t reserve(size_t n) {
+    size_t off = (data.size() + 3) / 4 * 4;
+    data.resize(off + n, 0.f);
+    return uint32_t(off);
+  }
+  uint32_t put(const float* src, size_t n) {
+    uint32_t off = reserve(n);
+    std::memcpy(data.data() + off, src, n * sizeof(float));
+    return off;
+  }
+  // A operand of v_mfma_f32_16x16x4_f32 for D[o][t] = sum_k W[o][k] B[k][t]:
+  // element (otile, g, lane, s) = W[otile*16 + (lane&15)][g*16 + s*4 + (lane>>4)], zero beyond the source.
+  uint32_t put_packed_a(const float* Wsrc, int O, int Ksrc, int ld) {
+    const int Op = round_up(O, 16), Kp = round_up(Ksrc, 16);
+    uint32_t off = reserve(size_t(Op) * Kp);
+    float* dst = data.data() + off;
+    for (int ot = 0; ot < Op / 16; ++ot)
+      for (int g = 0; g < Kp / 16; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int o = ot * 16 + (lane & 15), k = g * 16 + s * 4 + (lane >> 4);
+            const float v = (o < O && k < Ksrc) ? Wsrc[size_t(o) * ld + k] : 0.f;
+            dst[((size_t(ot) * (Kp / 16) + g) * 64 + lane) * 4 + s] = v;
+          }
+    return off;
+  }
+};
+
+struct Workspace {
+  float* cache[2] = {nullptr, nullptr};
+  size_t cache_elems = 0;
+  float* gsum = nullptr;
+  size_t gsum_elems = 0;
+  float* gru_seq = nullptr;  // unused for now
+};
+
+bool desc_conv(const wekws_hip_desc& d) {
+  return d.backbone == WEKWS_HIP_BACKBONE_DS_TCN || d.backbone == WEKWS_HIP_BACKBONE_TCN ||
+         d.backbone == WEKWS_HIP_BACKBONE_MDTC;
+}
+
+int n_blocks(const wekws_hip_desc& d) {
+  if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) return 1 + d.num_stack * d.stack_size;
+  return d.num_layers;
+}
+
+// validates and returns the blob size (floats); 0 with g_err set if invalid
+size_t blob_elems(const wekws_hip_desc& d) {
+  if (d.abi_version != WEKWS_HIP_ABI_VERSION) { fail(WEKWS_HIP_EINVAL, "desc.abi_version %d != %d", d.abi_version, WEKWS_HIP_ABI_VERSION); return 0; }
+  if (d.idim <= 0 || d.hdim <= 0 || d.odim <= 0) { fail(WEKWS_HIP_EINVAL, "idim/hdim/odim must be positive"); return 0; }
+  if (d.reserved[0] || d.reserved[1] || d.reserved[2]) { fail(WEKWS_HIP_EINVAL, "desc.reserved must be 0"); return 0; }
+  const size_t C = d.hdim, K = d.odim, ks = d.kernel_size;
+  size_t n = C * d.idim + C;  // preprocessing
+  switch (d.backbone) {
+    case WEKWS_HIP_BACKBONE_DS_TCN:
+      if (d.num_layers <= 0 || d.kernel_size <= 0) { fail(WEKWS_HIP_EINVAL, "tcn: num_layers/kernel_size"); return 0; }
+      n += size_t(d.num_layers) * (C * ks + C + C * C + C);
+      break;
+    case WEKWS_HIP_BACKBONE_TCN:
+      if (d.num_layers <= 0 || d.kernel_size <= 0) { fail(WEKWS_HIP_EINVAL, "tcn: num_layers/kernel_size"); return 0; }
+      n += size_t(d.num_layers) * (C * C * ks + C);
+      break;
+    case WEKWS_HIP_BACKBONE_MDTC:
+      if (d.num_stack <= 0 || d.stack_size <= 0 || d.kernel_size <= 0) { fail(WEKWS_HIP_EINVAL, "mdtc: num_stack/stack_size/kernel_size"); return 0; }
+      n += size_t(n_blocks(d)) * (C * ks + C + 2 * (C * C + C));
+      break;
+    case WEKWS_HIP_BACKBONE_GRU:
+      if (d.num_layers <= 0) { fail(WEKWS_HIP_EINVAL, "gru: num_layers"); return 0; }
+      n += size_t(d.num_layers) * (2 * 3 * C * C + 2 * 3 * C);
+      break;
+    default:
+      fail(WEKWS_HIP_EINVAL, "unknown backbone %d", d.backbone);
+      return 0;
+  }
+  switch (d.head) {
+    case WEKWS_HIP_HEAD_LINEAR: n += K * C + K; break;
+    case WEKWS_HIP_HEAD_GLOBAL:
+    case WEKWS_HIP_HEAD_LAST:
+      if (d.head_hidden <= 0) { fail(WEKWS_HIP_EINVAL, "head_hidden must be positive"); return 0; }
+      n += size_t(d.head_hidden) * C + d.head_hidden + K * size_t(d.head_hidden) + K;
+      break;
+    case WEKWS_HIP_HEAD_IDENTITY:
+      if (d.odim != d.hdim) { fail(WEKWS_HIP_EINVAL, "identity head needs odim == hdim"); return 0; }
+      break;
+    default:
+      fail(WEKWS_HIP_EINVAL, "unknown head %d", d.head);
+      return 0;
+  }
+  return n;
+}
+
+}  // namespace
+
+struct wekws_hip_model {
+  wekws_hip_desc desc;
+  int device = 0;
+  float* d_w = nullptr;
+  wekws::BlockDesc* d_blocks = nullptr;
+  wekws::StackParams sp{};
+  wekws::GruParams gp{};
+  int cache_len = 0;
+  Workspace ws;
+  std::mutex ws_mu;
+};
+
+struct wekws_hip_fbank {
+  wekws::FbankParams fp{};
+  int device = 0;
+  float* d_tables = nullptr;
+};
+
+extern "C" {
+
+const char* wekws_hip_last_error(void) { return g_err.c_str(); }
+int wekws_hip_abi_version(void) { return WEKWS_HIP_ABI_VERSION; }
+
+size_t wekws_hip_blob_elems(const wekws_hip_desc* desc) {
+  if (!desc) { fail(WEKWS_HIP_EINVAL, "desc is NULL"); return 0; }
+  return blob_elems(*desc);
+}
+
+int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_elems, int device,
+                     wekws_hip_model** out) {
+  if (!desc || !blob || !out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  const wekws_hip_desc& d = *desc;
+  const size_t need = blob_elems(d);
+  if (!need) return WEKWS_HIP_EINVAL;
+  if (need != n_elems) return fail(WEKWS_HIP_EINVAL, "weight blob has %zu floats, descriptor needs %zu", n_elems, need);
+  const int C = d.hdim, ks = d.kernel_size, K = d.odim;
+  if (desc_conv(d)) {
+    if (C != 32 && C != 64 && C != 128 && C != 256)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for 32/64/128/256", C);
+    if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim 256 does not fit the LDS tile");
+    if (d.backbone == WEKWS_HIP_BACKBONE_TCN && (C * ks) % 32)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "tcn: hidden_dim*kernel_size must be a multiple of 32");
+  } else {
+    if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128", C);
+    if (d.num_layers > wekws::kGruMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "gru num_layers %d > %d", d.num_layers, wekws::kGruMaxLayers);
+    if (d.head != WEKWS_HIP_HEAD_LINEAR) return fail(WEKWS_HIP_EUNSUPPORTED, "gru: only the per-frame linear head is built");
+  }
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
+  if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
+  m->desc = d;
+  m->device = device;
+
+  Image img;
+  img.reserve(4);  // offset 0 is never a valid section
+  const float* p = blob;
+  wekws::StackParams& sp = m->sp;
+  std::vector<wekws::BlockDesc> blocks;
+
+  // ---- preprocessing
+  const uint32_t pre_a = img.put_packed_a(p, C, d.idim, d.idim);
+  p += size_t(C) * d.idim;
+  const uint32_t pre_b = img.put(p, C);
+  p += C;
+
+  if (desc_conv(d)) {
+    sp.idim = d.idim;
+    sp.kpre = round_up(d.idim, 16);
+    sp.ksize = ks;
+    sp.odim = K;
+    sp.pre_relu = d.preproc_relu;
+    sp.pre_a = pre_a;
+    sp.pre_b = pre_b;
+    const int nb = n_blocks(d);
+    int off = 0;
+    for (int i = 0; i < nb; ++i) {
+      wekws::BlockDesc b{};
+      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
+        b.dil = (i == 0) ? 1 : (1 << ((i - 1) % d.stack_size));          // mdtc.py:151-156, :229-237
+        b.zadd = (i > 0 && (i - 1) % d.stack_size == d.stack_size - 1);  // mdtc.py:270-273
+      } else {
+        b.dil = 1 << i;                                                   // tcn.py:131-137
+      }
+      b.pad = (ks - 1) * b.dil;
+      b.cache_off = off;
+      off += b.pad;
+      if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
+        b.a1 = img.put_packed_a(p, C, C * ks, C * ks);
+        p += size_t(C) * C * ks;
+        b.b1 = img.put(p, C);
+        p += C;
+      } else {
+        b.dw_w = img.put(p, size_t(C) * ks);
+        p += size_t(C) * ks;
+        b.dw_b = img.put(p, C);
+        p += C;
+        b.a1 = img.put_packed_a(p, C, C, C);
+        p += size_t(C) * C;
+        b.b1 = img.put(p, C);
+        p += C;
+        if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
+          b.a2 = img.put_packed_a(p, C, C, C);
+          p += size_t(C) * C;
+          b.b2 = img.put(p, C);
+          p += C;
+        }
+      }
+      blocks.push_back(b);
+    }
+    m->cache_len = off;
+    sp.cache_len = off;
+    sp.nblocks = nb;
+    sp.head = d.head;
+    sp.head_hidden = d.head_hidden;
+    sp.sigmoid = d.activation == WEKWS_HIP_ACT_SIGMOID;
+    if (d.head == WEKWS_HIP_HEAD_LINEAR) {
+      sp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
+      sp.head_b = img.put(p, K); p += K;
+    } else if (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST) {
+      const int HH = d.head_hidden;
+      sp.head_w = img.put(p, size_t(HH) * C); p += size_t(HH) * C;
+      sp.head_b = img.put(p, HH); p += HH;
+      sp.head_w2 = img.put(p, size_t(K) * HH); p += size_t(K) * HH;
+      sp.head_b2 = img.put(p, K); p += K;
+    }
+  } else {
+    wekws::GruParams& gp = m->gp;
+    gp.idim = d.idim;
+    gp.kpre = round_up(d.idim, 16);
+    gp.odim = K;
+    gp.pre_relu = d.preproc_relu;
+    gp.pre_a = pre_a;
+    gp.pre_b = pre_b;
+    gp.nlayers = d.num_layers;
+    gp.sigmoid = d.activation == WEKWS_HIP_ACT_SIGMOID;
+    for (int l = 0; l < d.num_layers; ++l) {
+      const float* wih = p; p += size_t(3) * C * C;
+      const float* whh = p; p += size_t(3) * C * C;
+      const float* bih = p; p += 3 * C;
+      const float* bhh = p; p += 3 * C;
+      gp.layer[l].a_ih = img.put_packed_a(wih, 3 * C, C, C);
+      gp.layer[l].a_hh = img.put_packed_a(whh, 3 * C, C, C);
+      gp.layer[l].b_ih = img.put(bih, 3 * C);
+      gp.layer[l].b_hh = img.put(bhh, 3 * C);
+    }
+    gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
+    gp.head_b = img.put(p, K); p += K;
+    m->cache_len = 0;
+  }
+  if (size_t(p - blob) != n_elems) {
+    delete m;
+    return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
+  }
+
+  auto cleanup = [&]() {
+    if (m->d_w) (void)hipFree(m->d_w);
+    if (m->d_blocks) (void)hipFree(m->d_blocks);
+    delete m;
+  };
+  hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !blocks.empty()) {
+    e = hipMalloc(&m->d_blocks, blocks.size() * sizeof(wekws::BlockDesc));
+    if (e == hipSuccess)
+      e = hipMemcpy(m->d_blocks, blocks.data(), blocks.size() * sizeof(wekws::BlockDesc), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "weight upload: %s", hipGetErrorString(e));
+  }
+  sp.w = m->d_w;
+  sp.blocks = m->d_blocks;
+  m->gp.w = m->d_w;
+  *out = m;
+  return WEKWS_HIP_OK;
+}
+
+void wekws_hip_destroy(wekws_hip_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->d_w) (void)hipFree(m->d_w);
+  if (m->d_blocks) (void)hipFree(m->d_blocks);
+  for (float* c : m->ws.cache) if (c) (void)hipFree(c);
+  if (m->ws.gsum) (void)hipFree(m->ws.gsum);
+  delete m;
+}
+
+int wekws_hip_cache_dim(const wekws_hip_model* m) { return m ? m->desc.hdim : 0; }
+int wekws_hip_cache_len(const wekws_hip_model* m) { return m ? m->cache_len : 0; }
+
+size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
+  if (!m || B <= 0) return 0;
+  if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * m->desc.hdim;
+  return size_t(B) * m->desc.hdim * m->cache_len;
+}
+
+size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  if (m->desc.head == WEKWS_HIP_HEAD_GLOBAL || m->desc.head == WEKWS_HIP_HEAD_LAST) return size_t(B) * m->desc.odim;
+  return size_t(B) * T * m->desc.odim;
+}
+
+int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
+                      float* out_cache, int softmax, void* stream_) {
+  if (!m || !x || !y) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || T <= 0) return fail(WEKWS_HIP_EINVAL, "B=%d T=%d", B, T);
+  if (B == 0) return WEKWS_HIP_OK;
+  if (in_cache && in_cache == out_cache) return fail(WEKWS_HIP_EINVAL, "in_cache and out_cache must not alias");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const wekws_hip_desc& d = m->desc;
+  const bool per_frame = d.head == WEKWS_HIP_HEAD_LINEAR || d.head == WEKWS_HIP_HEAD_IDENTITY;
+
+  if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
+    const int rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
+    if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
+  } else {
+    const int TILE = WEKWS_HIP_TILE_FRAMES;
+    const int ntiles = (T + TILE - 1) / TILE;
+    const int C = d.hdim;
+    float* ws_cache[2] = {nullptr, nullptr};
+    float* gsum = nullptr;
+    std::unique_lock<std::mutex> lock(m->ws_mu, std::defer_lock);
+    if (ntiles > 1) {
+      // long input: tiles hand the causal context over through ping-pong caches in the workspace
+      lock.lock();
+      HIP_TRY(hipSetDevice(m->device));
+      const size_t ce = size_t(B) * C * m->cache_len;
+      if (m->ws.cache_elems < ce) {
+        for (float*& c : m->ws.cache) { if (c) (void)hipFree(c); c = nullptr; }
+        m->ws.cache_elems = 0;
+        HIP_TRY(hipMalloc(&m->ws.cache[0], ce * sizeof(float)));
+        HIP_TRY(hipMalloc(&m->ws.cache[1], ce * sizeof(float)));
+        m->ws.cache_elems = ce;
+      }
+      ws_cache[0] = m->ws.cache[0];
+      ws_cache[1] = m->ws.cache[1];
+      if (d.head == WEKWS_HIP_HEAD_GLOBAL) {
+        const size_t ge = size_t(B) * C;
+        if (m->ws.gsum_elems < ge) {
+          if (m->ws.gsum) (void)hipFree(m->ws.gsum);
+          m->ws.gsum = nullptr; m->ws.gsum_elems = 0;
+          HIP_TRY(hipMalloc(&m->ws.gsum, ge * sizeof(float)));
+          m->ws.gsum_elems = ge;
+        }
+        gsum = m->ws.gsum;
+      }
+    }
+    for (int i = 0; i < ntiles; ++i) {
+      const int t0 = i * TILE;
+      const int Tt = (T - t0 < TILE) ? (T - t0) : TILE;
+      const int nt16 = (Tt + 15) / 16;
+      const int nt = nt16 <= 1 ? 1 : nt16 <= 2 ? 2 : nt16 <= 4 ? 4 : 7;
+      wekws::CallArgs a{};
+      a.x = x + size_t(t0) * d.idim;
+      a.xs_b = int64_t(T) * d.idim;
+      a.in_cache = (i == 0) ? in_cache : ws_cache[(i - 1) & 1];
+      a.out_cache = (i == ntiles - 1) ? out_cache : ws_cache[i & 1];
+      a.y = per_frame ? y + size_t(t0) * d.odim : y;
+      a.ys_b = per_frame ? int64_t(T) * d.odim : d.odim;
+      a.gsum = gsum;
+      a.B = B;
+      a.T = Tt;
+      a.T_total = T;
+      a.first_tile = (i == 0);
+      a.last_tile = (i == ntiles - 1);
+      int rc;
+      switch (d.backbone) {
+        case WEKWS_HIP_BACKBONE_DS_TCN: rc = wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream); break;
+        case WEKWS_HIP_BACKBONE_TCN: rc = wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream); break;
+        default: rc = wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream); break;
+      }
+      if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
+    }
+  }
+  if (softmax) {
+    const int64_t rows = per_frame ? int64_t(B) * T : B;
+    const int K = d.odim;
+    hipLaunchKernelGGL(wekws::softmax_rows_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, stream, y, rows, K);
+    if (hipGetLastError() != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "softmax launch failed");
+  }
+  return WEKWS_HIP_OK;
+}
+
+// --------------------------------------------- fbank ---------------------------------------------
+int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip_fbank** out) {
+  if (!cfg || !out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (cfg->num_bins <= 0 || cfg->num_bins > wekws::kFbankMaxBins || cfg->sample_rate <= 0 || cfg->frame_length <= 0 ||
+      cfg->frame_shift <= 0 || cfg->frame_length > wekws::kFbankMaxFft)
+    return fail(WEKWS_HIP_EINVAL, "fbank cfg out of range");
+  if (cfg->window != WEKWS_HIP_WINDOW_HAMMING && cfg->window != WEKWS_HIP_WINDOW_POVEY)
+    return fail(WEKWS_HIP_EINVAL, "fbank window %d", cfg->window);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  wekws_hip_fbank* f = new (std::nothrow) wekws_hip_fbank();
+  if (!f) return fail(WEKWS_HIP_ENOMEM, "host allocation");
+  f->device = device;
+  std::vector<float> tables;
+  wekws::fbank_build_tables(cfg->num_bins, cfg->sample_rate, cfg->frame_length, cfg->frame_shift, cfg->window,
+                            &f->fp, &tables);
+  hipError_t e = hipMalloc(&f->d_tables, tables.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(f->d_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (f->d_tables) (void)hipFree(f->d_tables);
+    delete f;
+    return fail(WEKWS_HIP_EDEVICE, "fbank table upload: %s", hipGetErrorString(e));
+  }
+  f->fp.tables = f->d_tables;
+  *out = f;
+  return WEKWS_HIP_OK;
+}
+
+void wekws_hip_fbank_destroy(wekws_hip_fbank* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->d_tables) (void)hipFree(f->d_tables);
+  delete f;
+}
+
+int wekws_hip_fbank_num_frames(const wekws_hip_fbank* f, int nsamp) {
+  if (!f || nsamp < f->fp.frame_length) return 0;
+  return 1 + (nsamp - f->fp.frame_length) / f->fp.frame_shift;  // fbank.h:141-142
+}
+
+int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsamp, float* feats, void* stream_) {
+  if (!f || !pcm || !feats) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || nsamp < 0) return fail(WEKWS_HIP_EINVAL, "B=%d nsamp=%d", B, nsamp);
+  const int nf = wekws_hip_fbank_num_frames(f, nsamp);
+  if (B == 0 || nf == 0) return WEKWS_HIP_OK;
+  const int rc = wekws::launch_fbank(f->fp, pcm, B, nsamp, nf, feats, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "fbank launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+}  // extern "C"

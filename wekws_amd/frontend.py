@@ -1,0 +1,70 @@
+"""Batched on-device log-mel filterbank: MI355X replacement for ``wenet::Fbank::Compute``
+(runtime/core/frontend/fbank.h:138-198) behind ``FeaturePipeline::AcceptWaveform``'s framing rule
+(runtime/core/frontend/feature_pipeline.cc:30-47).  Thin host wrapper over the C ABI
+(wekws_hip_fbank_*); no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from wekws_amd import _capi
+
+WINDOWS = dict(hamming=0, povey=1)
+
+
+class Fbank:
+    """feats = Fbank(num_bins=40)(pcm)  with pcm (B, nsamp) float32 in int16 scale on a ROCm device
+    (the runtime never divides by 32768: runtime/core/frontend/wav.h:98-102) -> (B, frames, num_bins)."""
+
+    def __init__(self, num_bins: int = 40, sample_rate: int = 16000, frame_length: Optional[int] = None,
+                 frame_shift: Optional[int] = None, window: str = "hamming", device="cuda"):
+        # FeaturePipelineConfig: 25 ms window, 10 ms shift (feature_pipeline.h:34-39)
+        self.num_bins = num_bins
+        self.sample_rate = sample_rate
+        self.frame_length = frame_length if frame_length is not None else sample_rate // 1000 * 25
+        self.frame_shift = frame_shift if frame_shift is not None else sample_rate // 1000 * 10
+        if window not in WINDOWS:
+            raise ValueError(f"window must be one of {sorted(WINDOWS)}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("wekws_amd.frontend.Fbank runs on the MI355X HIP path only (no CPU fallback)")
+        lib = _capi.load()
+        cfg = _capi.FbankCfg()
+        cfg.num_bins, cfg.sample_rate = num_bins, sample_rate
+        cfg.frame_length, cfg.frame_shift, cfg.window = self.frame_length, self.frame_shift, WINDOWS[window]
+        self._lib = lib
+        self._ptr = ctypes.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _capi.check(lib.wekws_hip_fbank_create(ctypes.byref(cfg), idx, ctypes.byref(self._ptr)), "wekws_hip_fbank_create")
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.wekws_hip_fbank_destroy(self._ptr)
+                self._ptr = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def num_frames(self, nsamp: int) -> int:
+        return int(self._lib.wekws_hip_fbank_num_frames(self._ptr, int(nsamp)))
+
+    def __call__(self, pcm: torch.Tensor) -> torch.Tensor:
+        if pcm.dim() != 2 or not pcm.is_cuda or pcm.dtype != torch.float32:
+            raise ValueError("pcm must be a (B, nsamp) float32 tensor on a ROCm device")
+        pcm = pcm.contiguous()
+        B, n = int(pcm.size(0)), int(pcm.size(1))
+        nf = self.num_frames(n)
+        feats = torch.empty((B, nf, self.num_bins), dtype=torch.float32, device=pcm.device)
+        if B and nf:
+            stream = torch.cuda.current_stream(pcm.device).cuda_stream
+            _capi.check(self._lib.wekws_hip_fbank_compute(self._ptr, pcm.data_ptr(), B, n, feats.data_ptr(),
+                                                          ctypes.c_void_p(stream)), "wekws_hip_fbank_compute")
+        return feats
+
+    def leftover(self, nsamp: int) -> Tuple[int, int]:
+        """(frames, first sample to keep) for a streaming caller: the reference keeps
+        samples[frame_shift * frames:] for the next push (feature_pipeline.cc:41-44)."""
+        nf = self.num_frames(nsamp)
+        return nf, self.frame_shift * nf

@@ -1,0 +1,207 @@
+"""MI355X drop-in for ``wekws.model.kws_model`` (reference: wekws/model/kws_model.py:33-214).
+
+Same surface as the reference:
+    model = init_model(configs['model'])          # kws_model.py:97-214, same config dict
+    load_checkpoint(model, path)                  # wekws/utils/checkpoint.py:23-36 works unchanged: the
+                                                  # module exposes the reference's state_dict key names
+    model = model.to('cuda').eval()
+    y, out_cache = model(feats, in_cache)         # kws_model.py:65-76
+    y, out_cache = model.forward_softmax(...)     # kws_model.py:78-90
+but ``forward`` does not run torch ops: it folds + packs the weights once (wekws_amd/pack.py), hands them
+to libwekws_hip.so and launches the fused gfx950 kernels on the caller's current HIP stream.  PyTorch is
+used for tensor allocation / stream interop only.  There is deliberately NO CPU fallback: a CPU tensor, a
+missing library or an unsupported configuration raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import sys
+from typing import Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from wekws_amd import _capi, pack
+
+__all__ = ["KWSModel", "init_model"]
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked", "mean", "istd")
+
+
+def _default_init(name: str, shape: tuple) -> torch.Tensor:
+    """PyTorch-default-like initial values so a freshly built model is usable (training is out of scope)."""
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.long)
+    if leaf in ("running_mean", "mean"):
+        return torch.zeros(shape)
+    if leaf in ("running_var", "istd"):
+        return torch.ones(shape)
+    if leaf == "weight" and len(shape) == 1:  # BatchNorm gamma
+        return torch.ones(shape)
+    if leaf == "bias" and (".bn" in name or name.split(".")[-2] in ("1", "4") and "cnn" in name):
+        return torch.zeros(shape)
+    if leaf.startswith(("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
+        bound = 1.0 / math.sqrt(shape[0] / 3.0)
+    elif leaf == "weight":
+        bound = 1.0 / math.sqrt(float(np.prod(shape[1:])))
+    else:  # bias of a Linear / Conv: bound from the sibling weight is not known here; use a small range
+        bound = 0.05
+    return (torch.rand(shape) * 2.0 - 1.0) * bound
+
+
+class _Holder(nn.Module):
+    """Pure parameter container: gives nested names like ``backbone.network.0.cnn.3.weight``."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; the model runs through libwekws_hip.so")
+
+
+class _HipHandle:
+    """Owns one wekws_hip_model*; destroyed with the Python object."""
+
+    def __init__(self, desc_fields: dict, blob: np.ndarray, device_index: int):
+        lib = _capi.load()
+        self._lib = lib
+        self.ptr = ctypes.c_void_p()
+        desc = _capi.make_desc(desc_fields)
+        need = lib.wekws_hip_blob_elems(ctypes.byref(desc))
+        if need != blob.size:
+            raise _capi.HipLibraryError(f"packer produced {blob.size} floats, library expects {need}: "
+                                        f"{_capi.last_error()}")
+        _capi.check(lib.wekws_hip_create(ctypes.byref(desc), blob.ctypes.data, blob.size, device_index,
+                                         ctypes.byref(self.ptr)), "wekws_hip_create")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.wekws_hip_destroy(self.ptr)
+                self.ptr = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+class KWSModel(nn.Module):
+    """Reference: wekws/model/kws_model.py:33-95.  idim/odim/hdim attributes as there."""
+
+    def __init__(self, configs: Mapping):
+        super().__init__()
+        self._cfg = dict(configs)
+        self._d = pack.parse_config(configs)
+        self.idim, self.odim, self.hdim = self._d["idim"], self._d["odim"], self._d["hdim"]
+        for name, shape in pack.model_spec(configs):
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Holder())
+                mod = mod._modules[p]
+            t = _default_init(name, shape)
+            if parts[-1] in _BUFFER_LEAVES:
+                mod.register_buffer(parts[-1], t)
+            else:
+                mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+        self._handle: Optional[_HipHandle] = None
+        self._handle_key = None
+
+    # ------------------------------------------------------------------ weights -> device library
+    def _weights_key(self, device: torch.device):
+        return (device.index,) + tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
+
+    def load_packed(self, blob: np.ndarray) -> None:
+        """Install an already folded weight blob (e.g. received through the RCCL broadcast of
+        wekws_amd.parallel.broadcast_weights) instead of packing this module's own tensors."""
+        desc = {k: int(self._d[k]) for k in pack.DESC_FIELDS}
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        if blob.size != pack.blob_elems(desc):
+            raise ValueError(f"blob has {blob.size} floats, config needs {pack.blob_elems(desc)}")
+        self._packed_blob = blob
+        self._handle = None
+
+    def _get_handle(self, device: torch.device) -> _HipHandle:
+        if getattr(self, "_packed_blob", None) is not None:
+            if self._handle is None or self._handle_key != ("packed", device.index):
+                desc = {k: int(self._d[k]) for k in pack.DESC_FIELDS}
+                self._handle = _HipHandle(desc, self._packed_blob, device.index if device.index is not None else 0)
+                self._handle_key = ("packed", device.index)
+            return self._handle
+        key = self._weights_key(device)
+        if self._handle is None or key != self._handle_key:
+            sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+            desc, blob = pack.pack(self._cfg, sd)
+            self._handle = _HipHandle(desc, blob, device.index if device.index is not None else 0)
+            self._handle_key = key
+        return self._handle
+
+    def packed(self) -> Tuple[dict, np.ndarray]:
+        """(descriptor, folded float32 blob) -- what wekws_hip_create consumes; used by the multi-GPU
+        weight broadcast (wekws_amd/parallel.py) and the model-file writer."""
+        sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+        return pack.pack(self._cfg, sd)
+
+    # ------------------------------------------------------------------ forward
+    def _run(self, x: torch.Tensor, in_cache: Optional[torch.Tensor], softmax: bool):
+        if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.size(2) != self.idim:
+            raise ValueError(f"expected x of shape (B, T, {self.idim}), got {tuple(x.shape) if hasattr(x, 'shape') else x}")
+        if not x.is_cuda:
+            raise RuntimeError("wekws_amd.KWSModel runs on the MI355X HIP path only (no CPU fallback): "
+                               "move the model and its inputs to a ROCm device")
+        if x.dtype != torch.float32:
+            raise TypeError(f"x must be float32, got {x.dtype}")
+        dev = x.device
+        B, T = int(x.size(0)), int(x.size(1))
+        if T <= 0:
+            raise ValueError("empty time axis")
+        x = x.contiguous()
+        h = self._get_handle(dev)
+        lib = _capi.load()
+        cshape = pack.cache_shape(self._d, B)
+        cin = None
+        if in_cache is not None and in_cache.numel() > 0:
+            if tuple(in_cache.shape) != cshape:
+                raise ValueError(f"in_cache shape {tuple(in_cache.shape)} != {cshape}")
+            cin = in_cache.to(device=dev, dtype=torch.float32).contiguous()
+        per_frame = self._d["head"] in (pack.HEAD["linear"], pack.HEAD["identity"])
+        y = torch.empty((B, T, self.odim) if per_frame else (B, self.odim), dtype=torch.float32, device=dev)
+        out_cache = torch.empty(cshape, dtype=torch.float32, device=dev)
+        if B > 0:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _capi.check(lib.wekws_hip_forward(h.ptr, x.data_ptr(), B, T, cin.data_ptr() if cin is not None else None,
+                                              y.data_ptr(), out_cache.data_ptr() if out_cache.numel() else None,
+                                              1 if softmax else 0, ctypes.c_void_p(stream)), "wekws_hip_forward")
+        return y, out_cache
+
+    def forward(self, x: torch.Tensor,
+                in_cache: torch.Tensor = torch.zeros(0, 0, 0, dtype=torch.float)) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._run(x, in_cache, False)
+
+    def forward_softmax(self, x: torch.Tensor,
+                        in_cache: torch.Tensor = torch.zeros(0, 0, 0, dtype=torch.float)
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._d["head"] in (pack.HEAD["glob"], pack.HEAD["last"]):
+            raise IndexError("Dimension out of range (expected to be in range of [-2, 1], but got 2)")  # x.softmax(2) on (B, K)
+        return self._run(x, in_cache, True)
+
+    def fuse_modules(self):
+        """Reference: kws_model.py:92-94 (quantisation-time Conv+BN+ReLU fusion).  Here BN is always folded
+        at pack time, so this is a no-op kept for API compatibility."""
+        return None
+
+
+def init_model(configs: Mapping) -> KWSModel:
+    """Reference: wekws/model/kws_model.py:97-214.  Unknown types exit like the reference does."""
+    try:
+        model = KWSModel(configs)
+    except pack.ConfigError as e:
+        print(str(e))
+        sys.exit(1)
+    cmvn = configs.get("cmvn", {}) or {}
+    if cmvn.get("cmvn_file"):
+        from wekws_amd.utils.cmvn import load_cmvn, load_kaldi_cmvn
+        loader = load_kaldi_cmvn if "kaldi" in cmvn["cmvn_file"] else load_cmvn
+        mean, istd = loader(cmvn["cmvn_file"])
+        model.global_cmvn.mean.copy_(torch.from_numpy(mean).float())
+        model.global_cmvn.istd.copy_(torch.from_numpy(istd).float())
+    return model

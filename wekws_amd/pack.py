@@ -1,0 +1,229 @@
+"""Host-side weight packer: reference ``state_dict`` + ``configs['model']`` -> (descriptor, float32 blob)
+in the layout ``include/wekws_hip.h`` documents.
+
+Everything that is constant at inference time is folded here, in float64, and rounded to float32 once:
+  * GlobalCMVN ``(x - mean) * istd``  (wekws/model/cmvn.py:45-48) into the first Linear,
+  * every eval-mode ``BatchNorm1d``  ``(x - rm) / sqrt(rv + eps) * w + b``  (wekws/model/tcn.py:81,108,111;
+    wekws/model/mdtc.py:47,86,92) into the convolution in front of it,
+  * ``Dropout`` is the identity in eval mode and disappears.
+The state_dict key names are the reference's; ``model_spec`` reproduces them from
+the config alone so that ``wekws_amd.model.kws_model.init_model`` can build a ``load_state_dict``-compatible
+module without importing the reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Mapping, Tuple
+
+import numpy as np
+
+ABI_VERSION = 1
+BACKBONE = dict(ds_tcn=0, tcn=1, mdtc=2, gru=3)
+HEAD = dict(linear=0, glob=1, last=2, identity=3)
+BN_EPS = 1e-5
+HEAD_HIDDEN = 64  # nn.Linear(hidden_dim, 64) in wekws/model/kws_model.py:181-186
+
+DESC_FIELDS = ("abi_version", "backbone", "idim", "hdim", "odim", "num_layers", "num_stack", "stack_size",
+               "kernel_size", "preproc_relu", "head", "head_hidden", "activation")
+
+
+class ConfigError(ValueError):
+    pass
+
+
+def parse_config(configs: Mapping) -> dict:
+    """configs['model'] of the reference (wekws/model/kws_model.py:97-214) -> flat description."""
+    idim, odim, hdim = int(configs["input_dim"]), int(configs["output_dim"]), int(configs["hidden_dim"])
+    prep = configs["preprocessing"]["type"]
+    if prep not in ("linear", "none"):
+        # cnn1d_s1 exists in the reference but cannot run
+        raise ConfigError(f"Unknown preprocessing type {prep}")
+    bb = configs["backbone"]
+    bt = bb["type"]
+    d = dict(abi_version=ABI_VERSION, idim=idim, hdim=hdim, odim=odim, num_layers=0, num_stack=0, stack_size=0,
+             kernel_size=0, preproc_relu=1 if prep == "linear" else 0, prep=prep)
+    if bt == "gru":
+        d.update(backbone=BACKBONE["gru"], num_layers=int(bb["num_layers"]), kind="gru")
+    elif bt == "tcn":
+        ds = bool(bb.get("ds", False))
+        d.update(backbone=BACKBONE["ds_tcn" if ds else "tcn"], num_layers=int(bb["num_layers"]),
+                 kernel_size=int(bb.get("kernel_size", 8)), kind="ds_tcn" if ds else "tcn")
+    elif bt == "mdtc":
+        if not bb.get("causal", True):
+            raise ConfigError("mdtc: only causal=True is supported (all reference recipes use it)")
+        if int(bb["hidden_dim"]) != hdim:
+            raise ConfigError("mdtc: backbone.hidden_dim must equal hidden_dim")
+        d.update(backbone=BACKBONE["mdtc"], num_stack=int(bb["num_stack"]), stack_size=int(bb["stack_size"]),
+                 kernel_size=int(bb["kernel_size"]), kind="mdtc")
+    else:
+        raise ConfigError(f"Unknown body type {bt}")
+    if prep == "none" and idim != hdim:
+        raise ConfigError("preprocessing none needs input_dim == hidden_dim")
+    if "classifier" in configs:
+        ct = configs["classifier"]["type"]
+        if ct not in ("global", "last", "identity"):
+            raise ConfigError(f"Unknown classifier type {ct}")
+        d.update(head=HEAD["glob" if ct == "global" else ct], activation=0,
+                 head_hidden=HEAD_HIDDEN if ct in ("global", "last") else 0)
+        if ct == "identity" and odim != hdim:
+            raise ConfigError("identity classifier needs output_dim == hidden_dim")
+    else:
+        d.update(head=HEAD["linear"], activation=1, head_hidden=0)
+    if "activation" in configs:
+        if configs["activation"]["type"] != "identity":
+            raise ConfigError(f"Unknown activation type {configs['activation']['type']}")
+        d["activation"] = 0
+    cm = configs.get("cmvn", {}) or {}
+    d["cmvn"] = bool(configs.get("_cmvn")) or bool(cm.get("cmvn_file"))
+    d["norm_var"] = bool(cm.get("norm_var", True))
+    return d
+
+
+def mdtc_blocks(d: dict) -> List[Tuple[str, int]]:
+    """(state_dict prefix, dilation) of every TCNBlock in execution order (mdtc.py:247-275)."""
+    out = [("backbone.preprocessor.", 1)]
+    for s in range(d["num_stack"]):
+        for j in range(d["stack_size"]):
+            out.append((f"backbone.blocks.{s}.res_blocks.{j}.", 2 ** j))
+    return out
+
+
+def cache_shape(d: dict, B: int) -> Tuple[int, int, int]:
+    if d["kind"] == "gru":
+        return (d["num_layers"], B, d["hdim"])
+    k = d["kernel_size"]
+    if d["kind"] == "mdtc":
+        P = sum((k - 1) * dil for _, dil in mdtc_blocks(d))
+    else:
+        P = sum((k - 1) * 2 ** i for i in range(d["num_layers"]))
+    return (B, d["hdim"], P)
+
+
+def _bn(prefix: str, C: int) -> List[Tuple[str, tuple]]:
+    return [(prefix + ".weight", (C,)), (prefix + ".bias", (C,)), (prefix + ".running_mean", (C,)),
+            (prefix + ".running_var", (C,)), (prefix + ".num_batches_tracked", ())]
+
+
+def model_spec(configs: Mapping) -> List[Tuple[str, tuple]]:
+    """(name, shape) of every state_dict entry of the reference model for this config, in order."""
+    d = parse_config(configs)
+    C, I, K, ks = d["hdim"], d["idim"], d["odim"], d["kernel_size"]
+    spec: List[Tuple[str, tuple]] = []
+    if d["cmvn"]:
+        spec += [("global_cmvn.mean", (I,)), ("global_cmvn.istd", (I,))]
+    if d["prep"] == "linear":
+        spec += [("preprocessing.out.0.weight", (C, I)), ("preprocessing.out.0.bias", (C,))]
+    if d["kind"] == "gru":
+        for l in range(d["num_layers"]):
+            spec += [(f"backbone.weight_ih_l{l}", (3 * C, C)), (f"backbone.weight_hh_l{l}", (3 * C, C)),
+                     (f"backbone.bias_ih_l{l}", (3 * C,)), (f"backbone.bias_hh_l{l}", (3 * C,))]
+    elif d["kind"] == "ds_tcn":
+        for i in range(d["num_layers"]):
+            p = f"backbone.network.{i}.cnn."
+            spec += [(p + "0.weight", (C, 1, ks)), (p + "0.bias", (C,))] + _bn(p + "1", C)
+            spec += [(p + "3.weight", (C, C, 1)), (p + "3.bias", (C,))] + _bn(p + "4", C)
+    elif d["kind"] == "tcn":
+        for i in range(d["num_layers"]):
+            p = f"backbone.network.{i}.cnn."
+            spec += [(p + "0.weight", (C, C, ks)), (p + "0.bias", (C,))] + _bn(p + "1", C)
+    else:
+        for p, _ in mdtc_blocks(d):
+            spec += [(p + "conv1.conv.weight", (C, 1, ks)), (p + "conv1.conv.bias", (C,))] + _bn(p + "conv1.bn", C)
+            spec += [(p + "conv1.pointwise.weight", (C, C, 1)), (p + "conv1.pointwise.bias", (C,))]
+            spec += _bn(p + "bn1", C)
+            spec += [(p + "conv2.weight", (C, C, 1)), (p + "conv2.bias", (C,))] + _bn(p + "bn2", C)
+    if d["head"] == HEAD["linear"]:
+        spec += [("classifier.linear.weight", (K, C)), ("classifier.linear.bias", (K,))]
+    elif d["head"] in (HEAD["glob"], HEAD["last"]):
+        spec += [("classifier.classifier.0.weight", (HEAD_HIDDEN, C)), ("classifier.classifier.0.bias", (HEAD_HIDDEN,)),
+                 ("classifier.classifier.3.weight", (K, HEAD_HIDDEN)), ("classifier.classifier.3.bias", (K,))]
+    return spec
+
+
+def _f64(sd, name):
+    v = sd[name]
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, dtype=np.float64)
+
+
+def _bn_affine(sd, prefix):
+    """eval BatchNorm1d as y = s * x + t."""
+    s = _f64(sd, prefix + ".weight") / np.sqrt(_f64(sd, prefix + ".running_var") + BN_EPS)
+    t = _f64(sd, prefix + ".bias") - _f64(sd, prefix + ".running_mean") * s
+    return s, t
+
+
+def pack(configs: Mapping, sd: Mapping) -> Tuple[dict, np.ndarray]:
+    """-> (descriptor dict with DESC_FIELDS, float32 blob)."""
+    d = parse_config(configs)
+    C, I = d["hdim"], d["idim"]
+    parts: List[np.ndarray] = []
+
+    # ---- preprocessing (+ CMVN):  W (x - mean) * istd + b = (W * istd) x + (b - (W * istd) mean)
+    if d["prep"] == "linear":
+        W, b = _f64(sd, "preprocessing.out.0.weight"), _f64(sd, "preprocessing.out.0.bias")
+    else:
+        W, b = np.eye(C, I), np.zeros(C)
+    if d["cmvn"]:
+        mean = _f64(sd, "global_cmvn.mean")
+        istd = _f64(sd, "global_cmvn.istd") if d["norm_var"] else np.ones(I)
+        W = W * istd[None, :]
+        b = b - W @ mean
+    parts += [W, b]
+
+    if d["kind"] == "gru":
+        for l in range(d["num_layers"]):
+            parts += [_f64(sd, f"backbone.weight_ih_l{l}"), _f64(sd, f"backbone.weight_hh_l{l}"),
+                      _f64(sd, f"backbone.bias_ih_l{l}"), _f64(sd, f"backbone.bias_hh_l{l}")]
+    elif d["kind"] == "ds_tcn":
+        for i in range(d["num_layers"]):
+            p = f"backbone.network.{i}.cnn."
+            s1, t1 = _bn_affine(sd, p + "1")
+            s2, t2 = _bn_affine(sd, p + "4")
+            wd, bd = _f64(sd, p + "0.weight")[:, 0, :], _f64(sd, p + "0.bias")
+            wp, bp = _f64(sd, p + "3.weight")[:, :, 0], _f64(sd, p + "3.bias")
+            parts += [wd * s1[:, None], bd * s1 + t1, wp * s2[:, None], bp * s2 + t2]
+    elif d["kind"] == "tcn":
+        for i in range(d["num_layers"]):
+            p = f"backbone.network.{i}.cnn."
+            s1, t1 = _bn_affine(sd, p + "1")
+            parts += [_f64(sd, p + "0.weight") * s1[:, None, None], _f64(sd, p + "0.bias") * s1 + t1]
+    else:
+        for p, _ in mdtc_blocks(d):
+            sa, ta = _bn_affine(sd, p + "conv1.bn")
+            s1, t1 = _bn_affine(sd, p + "bn1")
+            s2, t2 = _bn_affine(sd, p + "bn2")
+            wd, bd = _f64(sd, p + "conv1.conv.weight")[:, 0, :], _f64(sd, p + "conv1.conv.bias")
+            w1, b1 = _f64(sd, p + "conv1.pointwise.weight")[:, :, 0], _f64(sd, p + "conv1.pointwise.bias")
+            w2, b2 = _f64(sd, p + "conv2.weight")[:, :, 0], _f64(sd, p + "conv2.bias")
+            parts += [wd * sa[:, None], bd * sa + ta, w1 * s1[:, None], b1 * s1 + t1, w2 * s2[:, None], b2 * s2 + t2]
+
+    if d["head"] == HEAD["linear"]:
+        parts += [_f64(sd, "classifier.linear.weight"), _f64(sd, "classifier.linear.bias")]
+    elif d["head"] in (HEAD["glob"], HEAD["last"]):
+        parts += [_f64(sd, "classifier.classifier.0.weight"), _f64(sd, "classifier.classifier.0.bias"),
+                  _f64(sd, "classifier.classifier.3.weight"), _f64(sd, "classifier.classifier.3.bias")]
+    blob = np.concatenate([np.ravel(p) for p in parts]).astype(np.float32)
+    desc = {k: int(d[k]) for k in DESC_FIELDS}
+    return desc, np.ascontiguousarray(blob)
+
+
+def blob_elems(desc: Mapping) -> int:
+    """Python twin of wekws_hip_blob_elems (checked against the library in tests/test_capi.py)."""
+    C, I, K, ks = desc["hdim"], desc["idim"], desc["odim"], desc["kernel_size"]
+    n = C * I + C
+    bb = desc["backbone"]
+    if bb == BACKBONE["ds_tcn"]:
+        n += desc["num_layers"] * (C * ks + C + C * C + C)
+    elif bb == BACKBONE["tcn"]:
+        n += desc["num_layers"] * (C * C * ks + C)
+    elif bb == BACKBONE["mdtc"]:
+        n += (1 + desc["num_stack"] * desc["stack_size"]) * (C * ks + C + 2 * (C * C + C))
+    else:
+        n += desc["num_layers"] * (6 * C * C + 6 * C)
+    if desc["head"] == HEAD["linear"]:
+        n += K * C + K
+    elif desc["head"] in (HEAD["glob"], HEAD["last"]):
+        hh = desc["head_hidden"]
+        n += hh * C + hh + K * hh + K
+    return n

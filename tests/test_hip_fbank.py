@@ -1,7 +1,9 @@
 """GPU: the HIP fbank kernel (wekws_hip_fbank_compute) against the reference-recorded goldens and the C oracle.
-Tolerance: 1e-4 abs on log-mel values would hold against an exact FFT (SURVEY.md appendix C measured 2.9e-5
-between the reference's recurrence-twiddle FFT and float64); the reference's own float32 table error is of
-the same order, so the test allows 2e-4 abs (values span [-16, 26])."""
+Tolerance (abs, on log-mel values spanning [-16, 26]): the reference's FFT uses a float32 sine table built by
+a recurrence (fft.cc:11-35) and is itself up to 2.4e-5 (40 bins) / 1.7e-4 (80 bins: narrow low-frequency filters
+on the pre-emphasised spectrum) away from a float64 evaluation of the same pipeline on these inputs (measured in
+the build container); the HIP kernel uses exactly-rounded twiddles, so it cannot be closer to the reference than
+that.  40 bins: 1e-4 (SURVEY.md appendix C target); 80 bins: 4e-4."""
 import os
 
 import numpy as np
@@ -15,7 +17,8 @@ from wekws_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL = 2e-4
+TOL = 1e-4
+TOL80 = 4e-4
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +33,7 @@ def test_golden(case, fgolden):
     got = fb(torch.from_numpy(pcm).cuda()).cpu().numpy()
     ref = fgolden[case["name"]]
     assert got.shape == ref.shape
-    assert float(np.abs(got - ref).max()) <= TOL
+    assert float(np.abs(got - ref).max()) <= (TOL if case["num_bins"] == 40 else TOL80)
 
 
 def test_batch_1024_vs_oracle_sample():

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (one JSON line each, not the bench.py contract):
+batch throughput of every backbone, streaming per-frame latency (B=1, 10-frame chunks, carried cache), fbank
+front-end throughput.  GPU only.   python tools/bench_configs.py > gpurun_out/configs.jsonl"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wekws_amd import pack  # noqa: E402
+from wekws_amd.frontend import Fbank  # noqa: E402
+from wekws_amd.model.kws_model import init_model  # noqa: E402
+from wekws_amd.utils import synth  # noqa: E402
+
+
+def build(name):
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    m = init_model(cfg)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return cfg, m.cuda().eval()
+
+
+def timeit(fn, warm=5, reps=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), float(np.percentile(ts, 10)), float(np.percentile(ts, 90))
+
+
+def main():
+    out = []
+    for name, B in (("ds_tcn_h256", 1024), ("ds_tcn_h256", 8192), ("mdtc_h64", 1024), ("mdtc_h64", 8192),
+                    ("mdtc_h64_global12", 1024), ("mdtc_small", 1024), ("ds_tcn_h64", 1024), ("tcn_h64", 1024),
+                    ("gru_2x128", 256), ("gru_2x128", 1024), ("gru_2x128", 16384)):
+        cfg, m = build(name)
+        x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=1)).cuda()
+        med, p10, p90 = timeit(lambda: m(x), reps=20 if B <= 1024 else 8)
+        out.append(dict(kind="batch", model=name, B=B, T=98, ms=round(med, 4), p10=round(p10, 4), p90=round(p90, 4),
+                        utts_per_s=round(B / med * 1e3, 1)))
+        print(json.dumps(out[-1]), flush=True)
+    # streaming latency: B streams, 10-frame chunks, cache carried, host-timed per chunk (includes launch overhead)
+    for name, B in (("gru_2x128", 1), ("gru_2x128", 256), ("ds_tcn_h256", 1), ("ds_tcn_h256", 256), ("mdtc_h64", 1),
+                    ("mdtc_h64", 256)):
+        cfg, m = build(name)
+        x = torch.from_numpy(synth.synth_feats(B, 10, cfg["input_dim"], seed=2)).cuda()
+        _, cache = m(x)
+        for _ in range(20):
+            _, cache = m(x, cache)
+        torch.cuda.synchronize()
+        n = 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            y, cache = m(x, cache)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n * 1e3
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            y, cache = m(x, cache)
+        b.record()
+        torch.cuda.synchronize()
+        dev = a.elapsed_time(b) / n
+        out.append(dict(kind="stream", model=name, B=B, chunk=10, ms_per_chunk_wall=round(wall, 4),
+                        ms_per_chunk_stream=round(dev, 4), us_per_frame=round(dev * 100, 2)))
+        print(json.dumps(out[-1]), flush=True)
+    fb = Fbank(40)
+    for B in (1024, 8192):
+        pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()
+        med, p10, p90 = timeit(lambda: fb(pcm))
+        out.append(dict(kind="fbank", B=B, nsamp=16000, ms=round(med, 4), utts_per_s=round(B / med * 1e3, 1),
+                        GBs=round((B * 16000 * 4 + B * 98 * 40 * 4) / med / 1e6, 1)))
+        print(json.dumps(out[-1]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace wekws {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -103,17 +105,22 @@ struct Geom {
 };
 
 // ---------------------------------------------------------------------------------------------
-// MFMA over `nk16` groups of 16 K-rows.  ap: this lane's float4 pointer to (otile 0 of the wave,
-// first 16-row group); consecutive groups are 64 float4 apart, consecutive o-tiles ot_stride apart.
-// bl: LDS pointer to (first K row + lane>>4, frame lane&15) of the wave's utterance.
+// MFMA building blocks.  A fragments are 16-byte loads of the host-packed image: for o-tile `ot`, 16-row
+// K group `g`, lane l holds W[ot*16 + (l&15)][g*16 + s*4 + (l>>4)], s = 0..3 (one float per k-step).
 // ---------------------------------------------------------------------------------------------
-template <int OW, int NT, int SS>
-__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[OW][NT], const float4* __restrict__ ap,
-                                          int ot_stride, const float* bl, int nk16) {
-  for (int g = 0; g < nk16; ++g) {
-    float4 a[OW];
+template <int OW, int NG>
+__device__ __forceinline__ void load_a(float4 (&a)[NG][OW], const float4* __restrict__ ap, int ot_stride) {
 #pragma unroll
-    for (int ow = 0; ow < OW; ++ow) a[ow] = ap[ow * ot_stride + g * 64];
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) a[g][ow] = ap[ow * ot_stride + g * 64];
+}
+
+// acc += A(groups) x B(rows of the LDS slab).  bl: LDS pointer to (first K row + lane>>4, frame lane&15).
+template <int OW, int NT, int SS, int NG>
+__device__ __forceinline__ void mfma_groups(f32x4 (&acc)[OW][NT], const float4 (&a)[NG][OW], const float* bl) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float b[NT];
@@ -121,12 +128,23 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[OW][NT], const float4* __
       for (int tt = 0; tt < NT; ++tt) b[tt] = bl[(g * 16 + s * 4) * SS + tt * 16];
 #pragma unroll
       for (int ow = 0; ow < OW; ++ow) {
-        const float av = s == 0 ? a[ow].x : s == 1 ? a[ow].y : s == 2 ? a[ow].z : a[ow].w;
+        const float av = s == 0 ? a[g][ow].x : s == 1 ? a[g][ow].y : s == 2 ? a[g][ow].z : a[g][ow].w;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
           acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[tt], acc[ow][tt], 0, 0, 0);
       }
     }
+  }
+}
+
+// runtime group count (preprocessing GEMM: K = idim rounded up to 16)
+template <int OW, int NT, int SS>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[OW][NT], const float4* __restrict__ ap, int ot_stride,
+                                          const float* bl, int nk16) {
+  for (int g = 0; g < nk16; ++g) {
+    float4 a[1][OW];
+    load_a<OW, 1>(a, ap + g * 64, ot_stride);
+    mfma_groups<OW, NT, SS, 1>(acc, a, bl + g * 16 * SS);
   }
 }
 
@@ -139,12 +157,16 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[OW][NT]) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w; }
 
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int C, int NT>
+template <int KIND, int C, int NT, int KS>
 __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackParams P, const CallArgs A) {
   using G = Geom<KIND, C, NT>;
   constexpr int U = G::U, OW = G::OW, SS = G::SS, KC = G::KC, R = G::R;
+  constexpr int NG = KC / 16;                       // 16-row K groups per produced chunk
+  constexpr int RP = (U * KC) / (kThreads / 16);    // slab rows each 16-lane group produces per chunk
+  static_assert(RP * (kThreads / 16) == U * KC && RP >= 1, "producer decomposition");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const hbuf = lds;                 // [U][C][SS]   resident activations h_i
   float* const slab = lds + G::H_FLOATS;   // [U][R][SS]   GEMM B-operand rows
@@ -159,16 +181,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
   const int b0 = blockIdx.x * U;           // first utterance of this workgroup
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
-  const int ks = P.ksize;
 
-  // producer mapping: 16 lanes share a row, each lane covers frames tl, tl+16, ...
+  // producer mapping: 16 lanes share a slab row, each lane covers frames tl, tl+16, ...
   const int pg = tid >> 4, tl = tid & 15;
 
   // this wave's accumulator geometry
   const int o_base = wo * OW * 16;         // first output channel of the wave
   float* const h_w = hbuf + wu * C * SS;   // the wave's utterance tile
   const float* const slab_w = slab + wu * R * SS + lq * SS + l15;
-  const bool utt_ok = (b0 + wu) < A.B;
 
   f32x4 acc[OW][NT];
   f32x4 zsum[KIND == KIND_MDTC ? OW : 1][KIND == KIND_MDTC ? NT : 1];
@@ -179,35 +199,35 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     zero_acc(acc);
     const int ot_stride = (P.kpre / 16) * 64;
     const float4* ap = reinterpret_cast<const float4*>(W + P.pre_a) + (wo * OW) * ot_stride + lane;
+    const float4 bias0 = *reinterpret_cast<const float4*>(W + P.pre_b + o_base + lq * 4);
+    const float4 bias1 = *reinterpret_cast<const float4*>(W + P.pre_b + o_base + (OW - 1) * 16 + lq * 4);
     for (int k0 = 0; k0 < P.kpre; k0 += R) {
       const int rows = min(R, P.kpre - k0);
       __syncthreads();
-      // slab[u][r][t] = x[b0+u][t][k0+r]  (zero beyond idim / T / B): coalesced global read over (t,k)
+      // slab[u][k][t] = x[b0+u][t][k0+k]  (zero beyond idim / T / B): one frame per wave per step, lanes along k
       for (int u = 0; u < U; ++u) {
         const bool ok = (b0 + u) < A.B;
-        const float* xu = A.x + int64_t(b0 + u) * A.xs_b;
-        for (int e = tid; e < 16 * NT * rows; e += kThreads) {
-          const int t = e / rows, r = e - t * rows;
-          const int k = k0 + r;
-          float v = 0.f;
-          if (ok && t < T && k < P.idim) v = xu[int64_t(t) * P.idim + k];
-          slab[(u * R + r) * SS + t] = v;
-        }
+        const float* xu = A.x + int64_t(b0 + u) * A.xs_b + k0;
+        for (int t = wave; t < 16 * NT; t += kWaves)
+          for (int k = lane; k < rows; k += 64) {
+            float v = 0.f;
+            if (ok && t < T && k0 + k < P.idim) v = xu[t * P.idim + k];
+            slab[(u * R + k) * SS + t] = v;
+          }
       }
       __syncthreads();
       mfma_rows<OW, NT, SS>(acc, ap + (k0 / 16) * 64, ot_stride, slab_w, rows / 16);
     }
-    // epilogue -> h
 #pragma unroll
     for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
-      const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o);
+      const float4 bias = ow == 0 ? bias0 : bias1;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const int t = tt * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+          float v = acc[ow][tt][r] + f4c(bias, r);
           if (P.pre_relu) v = fmaxf(v, 0.f);
           h_w[(o + r) * SS + t] = (t < T) ? v : 0.f;
         }
@@ -220,93 +240,141 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = P.blocks[bi];
     const int d = bd.dil, pad = bd.pad;
+    const int K1 = (KIND == KIND_TCN) ? C * KS : C;
+    const int nch = K1 / KC;
+    const int ot_stride1 = (K1 / 16) * 64;
+    const float4* ap1 = reinterpret_cast<const float4*>(W + bd.a1) + (wo * OW) * ot_stride1 + lane;
+
+    // ---- register-resident weights of the rows this thread produces, fetched one chunk ahead
+    float dww[KIND == KIND_TCN ? 1 : RP][KIND == KIND_TCN ? 1 : KS + 1];
+    auto load_dw = [&](int n) {
+      if constexpr (KIND != KIND_TCN) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+          const int item = pg + i * (kThreads / 16);
+          const int c = n * KC + (item % KC);
+#pragma unroll
+          for (int j = 0; j < KS; ++j) dww[i][j] = W[bd.dw_w + c * KS + j];
+          dww[i][KS] = W[bd.dw_b + c];
+        }
+      }
+    };
+    float4 a_cur[NG][OW], a_nxt[NG][OW];
+    load_dw(0);
+    load_a<OW, NG>(a_cur, ap1, ot_stride1);
 
     // ---- streaming cache hand-over: new_cache = last `pad` frames of [cache | h]  (tcn.py:54, mdtc.py:112)
     if (A.out_cache) {
-      for (int e = tid; e < U * C * pad; e += kThreads) {
-        const int p = e % pad;
-        const int uc = e / pad;
-        const int u = uc / C, c = uc - u * C;
+      for (int row = pg; row < U * C; row += kThreads / 16) {
+        const int u = row / C, c = row % C;
         if (b0 + u < A.B) {
-          const int src = T + p - pad;  // index into h (negative: still inside the old cache)
-          float v;
-          if (src >= 0) v = hbuf[(u * C + c) * SS + src];
-          else v = A.in_cache ? A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + T + p] : 0.f;
-          A.out_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p] = v;
+          const int64_t gbase = (int64_t(b0 + u) * C + c) * Pc + bd.cache_off;
+          for (int p = tl; p < pad; p += 16) {
+            const int src = T + p - pad;  // index into h (negative: still inside the old cache)
+            float v;
+            if (src >= 0) v = hbuf[row * SS + src];
+            else v = A.in_cache ? A.in_cache[gbase + T + p] : 0.f;
+            A.out_cache[gbase + p] = v;
+          }
         }
       }
     }
 
-    // left-context fetch for frame index idx < 0 (relative to the tile start)
-    auto halo = [&](int u, int c, int idx) -> float {
-      if (!A.in_cache || (b0 + u) >= A.B) return 0.f;
-      return A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + pad + idx];
-    };
-
-    // ---- producer of K-chunk n into slab buffer `buf` (rows buf*KC .. buf*KC+KC-1 of every utterance)
-    auto produce = [&](int n, int buf) {
-      for (int item = pg; item < U * KC; item += kThreads / 16) {
-        const int u = item / KC, r = item - u * KC;
+    // ---- producer of K-chunk n into slab buffer `buf` (rows buf*KC .. buf*KC+KC-1 of every utterance).
+    // Left context (frame index idx < 0 relative to the tile start) comes from the streaming cache in global
+    // memory when there is one, else it is zero (tcn.py:49-52).  Both variants are branch-free per tap: the
+    // LDS read is issued unconditionally at a clamped index and the result selected, so the KS reads of a
+    // frame are in flight together.
+    auto produce_impl = [&](int n, int buf, auto has_cache_tag) {
+      constexpr bool HAS_CACHE = decltype(has_cache_tag)::value;
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        const int item = pg + i * (kThreads / 16);
+        const int u = item / KC, r = item % KC;
         float* dst = slab + (u * R + buf * KC + r) * SS;
+        const bool uok = (b0 + u) < A.B;
         if constexpr (KIND == KIND_TCN) {
-          // dense conv as GEMM over K' = (c, j):  row = h[c][t - (ks-1-j)*d]      (tcn.py:76-80)
+          // dense conv as GEMM over K' = (c, j):  row = h[c][t - (KS-1-j)*d]      (tcn.py:76-80)
           const int kk = n * KC + r;
-          const int c = kk / ks, j = kk - c * ks;
-          const int sh = (ks - 1 - j) * d;
+          const int c = kk / KS, j = kk % KS;
+          const int sh = (KS - 1 - j) * d;
           const float* hc = hbuf + (u * C + c) * SS;
+          const float* cg = HAS_CACHE ? A.in_cache + (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off + pad : nullptr;
 #pragma unroll
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
             const int idx = t - sh;
-            float v = (idx >= 0) ? hc[idx] : halo(u, c, idx);
+            float v = hc[max(idx, 0)];
+            if constexpr (HAS_CACHE) {
+              const float g = cg[min(idx, -1)];
+              v = idx >= 0 ? v : (uok ? g : 0.f);
+            } else {
+              v = idx >= 0 ? v : 0.f;
+            }
             dst[t] = (t < T) ? v : 0.f;
           }
         } else {
           // depthwise dilated conv + folded BN (+ReLU for DS-TCN)        (tcn.py:102-109, mdtc.py:55-58)
           const int c = n * KC + r;
           const float* hc = hbuf + (u * C + c) * SS;
-          const float* wd = W + bd.dw_w + c * ks;
-          const float bias = W[bd.dw_b + c];
-          float o[NT];
-#pragma unroll
-          for (int m = 0; m < NT; ++m) o[m] = bias;
-          for (int j = 0; j < ks; ++j) {
-            const float wj = wd[j];
-            const int sh = (ks - 1 - j) * d;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) {
-              const int idx = tl + 16 * m - sh;
-              const float v = (idx >= 0) ? hc[idx] : halo(u, c, idx);
-              o[m] = fmaf(wj, v, o[m]);
-            }
-          }
-#pragma unroll
+          const float* cg = HAS_CACHE ? A.in_cache + (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off + pad : nullptr;
+          // frame loop kept rolled (taps unrolled): bounds the live LDS values to KS per step so that the
+          // accumulators + prefetched weights stay in registers (no scratch)
+#pragma unroll 1
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
-            float v = o[m];
-            if (KIND == KIND_DS) v = fmaxf(v, 0.f);
-            dst[t] = (t < T) ? v : 0.f;
+            float v[KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+              const int idx = t - (KS - 1 - j) * d;
+              v[j] = hc[max(idx, 0)];
+              if constexpr (HAS_CACHE) {
+                const float g = cg[min(idx, -1)];
+                v[j] = idx >= 0 ? v[j] : (uok ? g : 0.f);
+              } else {
+                v[j] = idx >= 0 ? v[j] : 0.f;
+              }
+            }
+            float o = dww[i][KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], v[j], o);
+            if (KIND == KIND_DS) o = fmaxf(o, 0.f);
+            dst[t] = (t < T) ? o : 0.f;
           }
         }
       }
     };
+    const bool has_cache = A.in_cache != nullptr;
+    auto produce = [&](int n, int buf) {
+      if (has_cache) produce_impl(n, buf, std::true_type{});
+      else produce_impl(n, buf, std::false_type{});
+    };
 
-    // ---- GEMM 1 over K (= C, or C*ksize for the dense conv), double-buffered chunks
-    const int K1 = (KIND == KIND_TCN) ? C * ks : C;
-    const int nch = K1 / KC;
-    const int ot_stride1 = (K1 / 16) * 64;
-    const float4* ap1 = reinterpret_cast<const float4*>(W + bd.a1) + (wo * OW) * ot_stride1 + lane;
+    // ---- GEMM 1 over K (= C, or C*KS for the dense conv): double-buffered chunks, one barrier per chunk;
+    //      weights of chunk n+1 (A fragments) and n+2 (depthwise taps) are in flight while chunk n is multiplied
     zero_acc(acc);
     produce(0, 0);
+    if (nch > 1) load_dw(1);
     __syncthreads();
     for (int n = 0; n < nch; ++n) {
-      if (n + 1 < nch) produce(n + 1, (n + 1) & 1);
-      mfma_rows<OW, NT, SS>(acc, ap1 + n * (KC / 16) * 64, ot_stride1, slab_w + (n & 1) * KC * SS, KC / 16);
+      if (n + 1 < nch) {
+        produce(n + 1, (n + 1) & 1);
+        load_a<OW, NG>(a_nxt, ap1 + (n + 1) * NG * 64, ot_stride1);
+        if (n + 2 < nch) load_dw(n + 2);
+      }
+      mfma_groups<OW, NT, SS, NG>(acc, a_cur, slab_w + (n & 1) * KC * SS);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int ow = 0; ow < OW; ++ow) a_cur[g][ow] = a_nxt[g][ow];
       __syncthreads();
     }
 
     if constexpr (KIND == KIND_MDTC) {
       // ---- mid = ReLU(BN1(pointwise))  -> slab rows [0, C) ; then conv2 (1x1) + BN2      (mdtc.py:113-116)
+      constexpr int NG2 = C / 16;
+      float4 a2[NG2][OW];
+      load_a<OW, NG2>(a2, reinterpret_cast<const float4*>(W + bd.a2) + (wo * OW) * (NG2 * 64) + lane, NG2 * 64);
       float* mid_w = slab + wu * R * SS;
 #pragma unroll
       for (int ow = 0; ow < OW; ++ow) {
@@ -317,16 +385,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
           const int t = tt * 16 + l15;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+            const float v = acc[ow][tt][r] + f4c(bias, r);
             mid_w[(o + r) * SS + t] = (t < T) ? fmaxf(v, 0.f) : 0.f;
           }
         }
       }
       __syncthreads();
-      const int ot_stride2 = (C / 16) * 64;
-      const float4* ap2 = reinterpret_cast<const float4*>(W + bd.a2) + (wo * OW) * ot_stride2 + lane;
       zero_acc(acc);
-      mfma_rows<OW, NT, SS>(acc, ap2, ot_stride2, slab_w, C / 16);
+      mfma_groups<OW, NT, SS, NG2>(acc, a2, slab_w);
     }
 
     // ---- epilogue: bias (+ReLU) + residual, in place into h
@@ -339,7 +405,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
         const int t = tt * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[ow][tt][r] + (r == 0 ? bias.x : r == 1 ? bias.y : r == 2 ? bias.z : bias.w);
+          float v = acc[ow][tt][r] + f4c(bias, r);
           float* hp = h_w + (o + r) * SS + t;
           if constexpr (KIND == KIND_MDTC) {
             v = fmaxf(v + *hp, 0.f);        // ReLU(out + inputs)            (mdtc.py:117-118)
@@ -369,20 +435,29 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     }
     __syncthreads();
   }
-  (void)utt_ok;
 
   // ============================================ head ============================================
   const int K = P.odim;
   if (P.head == HEAD_LINEAR) {
     // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
+    // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
+    const bool staged = K * (C + 1) <= G::S_FLOATS;
+    if (staged) {
+      for (int e = tid; e < K * C; e += kThreads) slab[e] = W[P.head_w + e];
+      for (int e = tid; e < K; e += kThreads) slab[K * C + e] = W[P.head_b + e];
+      __syncthreads();
+    }
+    const float* wsrc = staged ? slab : W + P.head_w;
+    const float* bsrc = staged ? slab + K * C : W + P.head_b;
     for (int e = tid; e < U * K * T; e += kThreads) {
       const int t = e % T;
       const int uk = e / T;
       const int u = uk / K, k = uk - u * K;
       if (b0 + u >= A.B) continue;
       const float* hc = hbuf + u * C * SS + t;
-      const float* wk = W + P.head_w + k * C;
+      const float* wk = wsrc + k * C;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
       for (int c = 0; c < C; c += 4) {
         const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
         s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
@@ -390,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
         s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
         s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
       }
-      float v = (s0 + s1) + (s2 + s3) + W[P.head_b + k];
+      float v = (s0 + s1) + (s2 + s3) + bsrc[k];
       if (P.sigmoid) v = sigmoidf_(v);
       A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
     }
@@ -476,8 +551,10 @@ template <> int launch_conv_stack<KIND_MDTC>(int, int, const StackParams&, const
 template <int KIND, int C, int NT>
 inline int launch_one(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   using G = Geom<KIND, C, NT>;
+  constexpr int KS = (KIND == KIND_MDTC) ? 5 : 8;  // the kernel sizes of the reference recipes (tcn.yaml / mdtc.yaml)
+  if (P.ksize != KS) return -4;
   static bool attr_set = false;
-  auto kern = conv_stack_kernel<KIND, C, NT>;
+  auto kern = conv_stack_kernel<KIND, C, NT, KS>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(G::LDS_BYTES)) != hipSuccess)

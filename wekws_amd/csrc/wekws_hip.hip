@@ -179,8 +179,11 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for 32/64/128/256", C);
     if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256)
       return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim 256 does not fit the LDS tile");
-    if (d.backbone == WEKWS_HIP_BACKBONE_TCN && (C * ks) % 32)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "tcn: hidden_dim*kernel_size must be a multiple of 32");
+    // the conv kernels are specialised for the kernel sizes of the reference recipes
+    // (examples/*/s0/conf/{ds_tcn,tcn}.yaml: 8; mdtc*.yaml: 5)
+    const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
+    if (ks != ks_built)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "kernel_size %d: this backbone's kernel is built for %d", ks, ks_built);
   } else {
     if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128", C);
     if (d.num_layers > wekws::kGruMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "gru num_layers %d > %d", d.num_layers, wekws::kGruMaxLayers);

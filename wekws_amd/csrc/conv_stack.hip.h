@@ -354,19 +354,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     //      weights of chunk n+1 (A fragments) and n+2 (depthwise taps) are in flight while chunk n is multiplied
     zero_acc(acc);
     produce(0, 0);
-    if (nch > 1) load_dw(1);
+    load_dw(1);
     __syncthreads();
-    for (int n = 0; n < nch; ++n) {
-      if (n + 1 < nch) {
-        produce(n + 1, (n + 1) & 1);
-        load_a<OW, NG>(a_nxt, ap1 + (n + 1) * NG * 64, ot_stride1);
-        if (n + 2 < nch) load_dw(n + 2);
-      }
-      mfma_groups<OW, NT, SS, NG>(acc, a_cur, slab_w + (n & 1) * KC * SS);
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int ow = 0; ow < OW; ++ow) a_cur[g][ow] = a_nxt[g][ow];
+    // two chunks per trip with ping-pong fragment registers (a_cur / a_nxt): no register copies, so the
+    // fragments consumed by chunk n were requested a whole chunk earlier.  nch is even for every built shape.
+    // The prefetches are UNCONDITIONAL (chunk index clamped; the last trip re-reads a valid chunk it will not
+    // use): a branch around a load makes the compiler's s_waitcnt placement fall back to the conservative
+    // count at the join, which drains the whole prefetch queue in front of the MFMAs.
+    for (int n = 0; n < nch; n += 2) {
+      produce(n + 1, 1);
+      load_a<OW, NG>(a_nxt, ap1 + (n + 1) * NG * 64, ot_stride1);
+      load_dw(min(n + 2, nch - 1));
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMA block
+      mfma_groups<OW, NT, SS, NG>(acc, a_cur, slab_w);
+      __syncthreads();
+      if (n + 2 < nch) produce(n + 2, 0);
+      load_a<OW, NG>(a_cur, ap1 + min(n + 2, nch - 1) * NG * 64, ot_stride1);
+      load_dw(min(n + 3, nch - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_groups<OW, NT, SS, NG>(acc, a_nxt, slab_w + KC * SS);
       __syncthreads();
     }
 

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 from typing import Optional
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libwekws_hip.so")
+_LIB_PATH = os.environ.get("WEKWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                      "libwekws_hip.so")  # override: kernel experiments only
 ABI_VERSION = 1
 
 

@@ -39,6 +39,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum : int { KIND_DS = 0, KIND_TCN = 1, KIND_MDTC = 2 };
 enum : int { HEAD_LINEAR = 0, HEAD_GLOBAL = 1, HEAD_LAST = 2, HEAD_IDENTITY = 3 };
 
+// Development-only ablation switch (tools/ablate.sh): 0 = product.  1: no producer in the chunk loop,
+// 2: no MFMAs, 3: neither, 4: no per-chunk barrier; 5-9 = 3 plus: 5 no x staging, 6 no cache write, 7 no head,
+// 8 no block epilogue, 9 all of 5-8.  Results are WRONG for any value but 0.
+#ifndef WEKWS_ABLATE
+#define WEKWS_ABLATE 0
+#endif
+#ifndef WEKWS_SETPRIO
+#define WEKWS_SETPRIO 0
+#endif
+
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;
 
@@ -117,24 +127,35 @@ __device__ __forceinline__ void load_a(float4 (&a)[NG][OW], const float4* __rest
 }
 
 // acc += A(groups) x B(rows of the LDS slab).  bl: LDS pointer to (first K row + lane>>4, frame lane&15).
+// The B fragments of k-step i+1 are requested before the MFMAs of k-step i are issued (one step = OW*NT MFMAs,
+// >= 224 cycles of matrix pipe), so a wave that owns the pipe alone never waits on LDS latency.
 template <int OW, int NT, int SS, int NG>
 __device__ __forceinline__ void mfma_groups(f32x4 (&acc)[OW][NT], const float4 (&a)[NG][OW], const float* bl) {
+  constexpr int STEPS = NG * 4;
+  float b[2][NT];
+  if (WEKWS_SETPRIO) __builtin_amdgcn_s_setprio(WEKWS_SETPRIO);
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
+  for (int tt = 0; tt < NT; ++tt) b[0][tt] = bl[tt * 16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float b[NT];
+  for (int i = 0; i < STEPS; ++i) {
+    const int g = i / 4, sidx = i % 4;
+    if (i + 1 < STEPS) {
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) b[tt] = bl[(g * 16 + s * 4) * SS + tt * 16];
-#pragma unroll
-      for (int ow = 0; ow < OW; ++ow) {
-        const float av = s == 0 ? a[g][ow].x : s == 1 ? a[g][ow].y : s == 2 ? a[g][ow].z : a[g][ow].w;
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[tt], acc[ow][tt], 0, 0, 0);
-      }
+      for (int tt = 0; tt < NT; ++tt) b[(i + 1) & 1][tt] = bl[((i + 1) * 4) * SS + tt * 16];
     }
+    // pin: [reads of step i+1] then [MFMAs of step i]; without it the scheduler re-merges the two buffers and
+    // re-issues each read two MFMAs before its use (an lgkmcnt stall per step when the wave runs alone)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const float av = sidx == 0 ? a[g][ow].x : sidx == 1 ? a[g][ow].y : sidx == 2 ? a[g][ow].z : a[g][ow].w;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+        acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[i & 1][tt], acc[ow][tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (WEKWS_SETPRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // runtime group count (preprocessing GEMM: K = idim rounded up to 16)
@@ -205,15 +226,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
       const int rows = min(R, P.kpre - k0);
       __syncthreads();
       // slab[u][k][t] = x[b0+u][t][k0+k]  (zero beyond idim / T / B): one frame per wave per step, lanes along k
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U && !(WEKWS_ABLATE == 5 || WEKWS_ABLATE == 9); ++u) {
         const bool ok = (b0 + u) < A.B;
         const float* xu = A.x + int64_t(b0 + u) * A.xs_b + k0;
-        for (int t = wave; t < 16 * NT; t += kWaves)
-          for (int k = lane; k < rows; k += 64) {
-            float v = 0.f;
-            if (ok && t < T && k0 + k < P.idim) v = xu[t * P.idim + k];
-            slab[(u * R + k) * SS + t] = v;
+        constexpr int FPW = (16 * NT + kWaves - 1) / kWaves;  // frames per wave
+        for (int k = lane; k < rows; k += 64) {
+          float xv[FPW];
+#pragma unroll
+          for (int i = 0; i < FPW; ++i) {   // all loads of the pass in flight together
+            const int t = wave + i * kWaves;
+            xv[i] = (ok && t < T && k0 + k < P.idim) ? xu[t * P.idim + k] : 0.f;
           }
+#pragma unroll
+          for (int i = 0; i < FPW; ++i) {
+            const int t = wave + i * kWaves;
+            if (t < 16 * NT) slab[(u * R + k) * SS + t] = xv[i];
+          }
+        }
       }
       __syncthreads();
       mfma_rows<OW, NT, SS>(acc, ap + (k0 / 16) * 64, ot_stride, slab_w, rows / 16);
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
         for (int r = 0; r < 4; ++r) {
           float v = acc[ow][tt][r] + f4c(bias, r);
           if (P.pre_relu) v = fmaxf(v, 0.f);
-          h_w[(o + r) * SS + t] = (t < T) ? v : 0.f;
+          h_w[(o + r) * SS + t] = v;  // frames >= T hold finite don't-care values from here on
         }
       }
     }
@@ -245,9 +274,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     const int ot_stride1 = (K1 / 16) * 64;
     const float4* ap1 = reinterpret_cast<const float4*>(W + bd.a1) + (wo * OW) * ot_stride1 + lane;
 
-    // ---- register-resident weights of the rows this thread produces, fetched one chunk ahead
+    // register-resident depthwise taps (+bias) of the rows this thread produces next, fetched ahead of use
     float dww[KIND == KIND_TCN ? 1 : RP][KIND == KIND_TCN ? 1 : KS + 1];
-    auto load_dw = [&](int n) {
+    auto load_dw = [&](int n) __attribute__((always_inline)) {
       if constexpr (KIND != KIND_TCN) {
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
@@ -259,33 +288,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
         }
       }
     };
-    float4 a_cur[NG][OW], a_nxt[NG][OW];
+    float4 a0[NG][OW], a1[NG][OW];
     load_dw(0);
-    load_a<OW, NG>(a_cur, ap1, ot_stride1);
-
-    // ---- streaming cache hand-over: new_cache = last `pad` frames of [cache | h]  (tcn.py:54, mdtc.py:112)
-    if (A.out_cache) {
-      for (int row = pg; row < U * C; row += kThreads / 16) {
-        const int u = row / C, c = row % C;
-        if (b0 + u < A.B) {
-          const int64_t gbase = (int64_t(b0 + u) * C + c) * Pc + bd.cache_off;
-          for (int p = tl; p < pad; p += 16) {
-            const int src = T + p - pad;  // index into h (negative: still inside the old cache)
-            float v;
-            if (src >= 0) v = hbuf[row * SS + src];
-            else v = A.in_cache ? A.in_cache[gbase + T + p] : 0.f;
-            A.out_cache[gbase + p] = v;
-          }
-        }
-      }
-    }
+    load_a<OW, NG>(a0, ap1, ot_stride1);
+    // epilogue bias, requested now so its latency is long gone when the layer's MFMAs finish
+    float4 ebias[OW];
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow)
+      ebias[ow] = *reinterpret_cast<const float4*>(W + (KIND == KIND_MDTC ? bd.b2 : bd.b1) + o_base + ow * 16 + lq * 4);
 
     // ---- producer of K-chunk n into slab buffer `buf` (rows buf*KC .. buf*KC+KC-1 of every utterance).
-    // Left context (frame index idx < 0 relative to the tile start) comes from the streaming cache in global
-    // memory when there is one, else it is zero (tcn.py:49-52).  Both variants are branch-free per tap: the
-    // LDS read is issued unconditionally at a clamped index and the result selected, so the KS reads of a
-    // frame are in flight together.
-    auto produce_impl = [&](int n, int buf, auto has_cache_tag) {
+    // 16 lanes share a slab row.  Lane l owns the NT output frames  f_i = base + i*d  (a run at stride = the
+    // dilation; base = (l/d)*NT*d + l%d tiles [0, 16*NT) for every d that divides 16), so the KS taps of
+    // consecutive outputs slide over the same inputs: NT+KS-1 LDS reads per row instead of NT*KS, all in
+    // flight together, one latency exposure.  Left context (index < 0 relative to the tile start) comes from
+    // the streaming cache in global memory when there is one, else it is zero (tcn.py:49-52); the read is
+    // issued unconditionally at a clamped index and the result selected (branch-free).
+    // The same lanes also hand the row's streaming cache over: new_cache = last `pad` frames of [cache | h]
+    // (tcn.py:54, mdtc.py:112) -- spread over the layer instead of one write burst per layer.
+    const bool slide = d <= 16 && (16 % d) == 0;
+    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;   // first output frame of this lane
+    const int fstep = slide ? d : 16;                             // distance between its output frames
+    auto produce_impl = [&](int n, int buf, auto has_cache_tag) __attribute__((always_inline)) {
       constexpr bool HAS_CACHE = decltype(has_cache_tag)::value;
 #pragma unroll
       for (int i = 0; i < RP; ++i) {
@@ -293,87 +317,112 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
         const int u = item / KC, r = item % KC;
         float* dst = slab + (u * R + buf * KC + r) * SS;
         const bool uok = (b0 + u) < A.B;
+        const int kk = n * KC + r;
+        const int c = (KIND == KIND_TCN) ? kk / KS : kk;
+        const int j0 = (KIND == KIND_TCN) ? kk % KS : 0;
+        const int hoff = (u * C + c) * SS;
+        const int64_t gbase = (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
+        // [cache | h] at frame idx (idx < 0: left context); both reads unconditional at clamped indices
+#define fetch(idx_)                                                                      \
+  ({                                                                                     \
+    const int ix_ = (idx_);                                                              \
+    float fv_ = hbuf[hoff + max(ix_, 0)];                                                \
+    if constexpr (HAS_CACHE) {                                                           \
+      const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
+      fv_ = ix_ >= 0 ? fv_ : (uok ? fg_ : 0.f);                                          \
+    } else {                                                                             \
+      fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
+    }                                                                                    \
+    fv_;                                                                                 \
+  })
+        if (A.out_cache && uok && j0 == 0 && !(WEKWS_ABLATE == 6 || WEKWS_ABLATE == 9)) {
+          for (int p = tl; p < pad; p += 16) {
+            const int src = T + p - pad;  // index into h (negative: still inside the old cache)
+            float cv = hbuf[hoff + max(src, 0)];
+            if constexpr (HAS_CACHE) {
+              const float g = A.in_cache[gbase + pad + min(src, -1)];
+              cv = src >= 0 ? cv : g;
+            } else {
+              cv = src >= 0 ? cv : 0.f;
+            }
+            A.out_cache[gbase + p] = cv;
+          }
+        }
         if constexpr (KIND == KIND_TCN) {
           // dense conv as GEMM over K' = (c, j):  row = h[c][t - (KS-1-j)*d]      (tcn.py:76-80)
-          const int kk = n * KC + r;
-          const int c = kk / KS, j = kk % KS;
-          const int sh = (KS - 1 - j) * d;
-          const float* hc = hbuf + (u * C + c) * SS;
-          const float* cg = HAS_CACHE ? A.in_cache + (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off + pad : nullptr;
+          const int sh = (KS - 1 - j0) * d;
 #pragma unroll
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
-            const int idx = t - sh;
-            float v = hc[max(idx, 0)];
-            if constexpr (HAS_CACHE) {
-              const float g = cg[min(idx, -1)];
-              v = idx >= 0 ? v : (uok ? g : 0.f);
-            } else {
-              v = idx >= 0 ? v : 0.f;
-            }
+            const float v = fetch(t - sh);
             dst[t] = (t < T) ? v : 0.f;
           }
         } else {
           // depthwise dilated conv + folded BN (+ReLU for DS-TCN)        (tcn.py:102-109, mdtc.py:55-58)
-          const int c = n * KC + r;
-          const float* hc = hbuf + (u * C + c) * SS;
-          const float* cg = HAS_CACHE ? A.in_cache + (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off + pad : nullptr;
-          // frame loop kept rolled (taps unrolled): bounds the live LDS values to KS per step so that the
-          // accumulators + prefetched weights stay in registers (no scratch)
-#pragma unroll 1
-          for (int m = 0; m < NT; ++m) {
-            const int t = tl + 16 * m;
-            float v[KS];
+          if (slide) {
+            float v[NT + KS - 1];
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-              const int idx = t - (KS - 1 - j) * d;
-              v[j] = hc[max(idx, 0)];
-              if constexpr (HAS_CACHE) {
-                const float g = cg[min(idx, -1)];
-                v[j] = idx >= 0 ? v[j] : (uok ? g : 0.f);
-              } else {
-                v[j] = idx >= 0 ? v[j] : 0.f;
-              }
+            for (int q = 0; q < NT + KS - 1; ++q) v[q] = fetch(fbase + (q - (KS - 1)) * d);
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+              float o = dww[i][KS];
+#pragma unroll
+              for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], v[m + j], o);
+              if (KIND == KIND_DS) o = fmaxf(o, 0.f);
+              const int t = fbase + m * d;
+              dst[t] = (t < T) ? o : 0.f;
             }
-            float o = dww[i][KS];
+          } else {
+            // generic dilation (does not divide 16): one frame at a time
+#pragma unroll 1
+            for (int m = 0; m < NT; ++m) {
+              const int t = tl + 16 * m;
+              float o = dww[i][KS];
 #pragma unroll
-            for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], v[j], o);
-            if (KIND == KIND_DS) o = fmaxf(o, 0.f);
-            dst[t] = (t < T) ? o : 0.f;
+              for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], fetch(t - (KS - 1 - j) * d), o);
+              if (KIND == KIND_DS) o = fmaxf(o, 0.f);
+              dst[t] = (t < T) ? o : 0.f;
+            }
           }
         }
       }
     };
+#undef fetch
     const bool has_cache = A.in_cache != nullptr;
-    auto produce = [&](int n, int buf) {
+    auto produce = [&](int n, int buf) __attribute__((always_inline)) {
       if (has_cache) produce_impl(n, buf, std::true_type{});
       else produce_impl(n, buf, std::false_type{});
     };
+    (void)fstep;
 
-    // ---- GEMM 1 over K (= C, or C*KS for the dense conv): double-buffered chunks, one barrier per chunk;
-    //      weights of chunk n+1 (A fragments) and n+2 (depthwise taps) are in flight while chunk n is multiplied
+    // ---- GEMM 1 over K (= C, or C*KS for the dense conv): double-buffered chunks, one barrier per chunk.
+    // Measured on MI355X (tools/ablate.sh): the f32 MFMA stream and the VALU/LDS producer do NOT overlap on a
+    // SIMD even when they come from different waves (time = MFMA + producer, also with the two waves of a SIMD
+    // staggered into different phases), so the producer is kept short instead of hidden.
+    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
+    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
+    constexpr bool kBarrier = WEKWS_ABLATE != 4;
     zero_acc(acc);
     produce(0, 0);
     load_dw(1);
     __syncthreads();
-    // two chunks per trip with ping-pong fragment registers (a_cur / a_nxt): no register copies, so the
-    // fragments consumed by chunk n were requested a whole chunk earlier.  nch is even for every built shape.
-    // The prefetches are UNCONDITIONAL (chunk index clamped; the last trip re-reads a valid chunk it will not
-    // use): a branch around a load makes the compiler's s_waitcnt placement fall back to the conservative
-    // count at the join, which drains the whole prefetch queue in front of the MFMAs.
+    // Two chunks per trip with ping-pong fragment registers (a0 / a1), no register copies, so the fragments
+    // consumed by chunk n were requested a whole chunk earlier.  nch is even for every built shape.  Prefetches
+    // are UNCONDITIONAL (chunk index clamped): a branch around a load makes the compiler's s_waitcnt placement
+    // fall back to the conservative count at the join and drain the prefetch queue in front of the MFMAs.
     for (int n = 0; n < nch; n += 2) {
-      produce(n + 1, 1);
-      load_a<OW, NG>(a_nxt, ap1 + (n + 1) * NG * 64, ot_stride1);
+      if (kProduce) produce(n + 1, 1);
+      load_a<OW, NG>(a1, ap1 + (n + 1) * NG * 64, ot_stride1);
       load_dw(min(n + 2, nch - 1));
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMA block
-      mfma_groups<OW, NT, SS, NG>(acc, a_cur, slab_w);
-      __syncthreads();
-      if (n + 2 < nch) produce(n + 2, 0);
-      load_a<OW, NG>(a_cur, ap1 + min(n + 2, nch - 1) * NG * 64, ot_stride1);
+      if (kMfma) mfma_groups<OW, NT, SS, NG>(acc, a0, slab_w);
+      if (kBarrier) __syncthreads();
+      if (kProduce && n + 2 < nch) produce(n + 2, 0);
+      load_a<OW, NG>(a0, ap1 + min(n + 2, nch - 1) * NG * 64, ot_stride1);
       load_dw(min(n + 3, nch - 1));
       __builtin_amdgcn_sched_barrier(0);
-      mfma_groups<OW, NT, SS, NG>(acc, a_nxt, slab_w + KC * SS);
-      __syncthreads();
+      if (kMfma) mfma_groups<OW, NT, SS, NG>(acc, a1, slab_w + KC * SS);
+      if (kBarrier) __syncthreads();
     }
 
     if constexpr (KIND == KIND_MDTC) {
@@ -392,7 +441,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[ow][tt][r] + f4c(bias, r);
-            mid_w[(o + r) * SS + t] = (t < T) ? fmaxf(v, 0.f) : 0.f;
+            mid_w[(o + r) * SS + t] = fmaxf(v, 0.f);
           }
         }
       }
@@ -403,9 +452,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 
     // ---- epilogue: bias (+ReLU) + residual, in place into h
 #pragma unroll
-    for (int ow = 0; ow < OW; ++ow) {
+    for (int ow = 0; ow < ((WEKWS_ABLATE == 8 || WEKWS_ABLATE == 9) ? 0 : OW); ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
-      const float4 bias = *reinterpret_cast<const float4*>(W + (KIND == KIND_MDTC ? bd.b2 : bd.b1) + o);
+      const float4 bias = ebias[ow];
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const int t = tt * 16 + l15;
@@ -419,7 +468,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
           } else {
             v = fmaxf(v, 0.f) + *hp;        // y + x, nothing after the add   (tcn.py:60)
           }
-          if (t < T) *hp = v;
+          *hp = v;
         }
       }
     }
@@ -444,7 +493,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 
   // ============================================ head ============================================
   const int K = P.odim;
-  if (P.head == HEAD_LINEAR) {
+  if (WEKWS_ABLATE == 7 || WEKWS_ABLATE == 9) {
+  } else if (P.head == HEAD_LINEAR) {
     // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
     // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
     const bool staged = K * (C + 1) <= G::S_FLOATS;

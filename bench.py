@@ -129,6 +129,14 @@ def main():
         launch_flop = flop * B if flop else None
         ach_tf = launch_flop / (kern_ms * 1e-3) / 1e12 if flop else None
         hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
+            # the timed process); ignored unless it was taken on the kernel this run dispatches
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.model == "ds_tcn_h256" and B == 1024 and "conv_stack_kernel<0, 256, 7" in pm["kernel"]:
+                traffic, traffic_src = pm["traffic_bytes_per_launch"], pm["profile"]
+        except Exception:
+            pass
         out = {
             "metric": "1-sec utterances/sec (40-d fbank -> DS-TCN posteriors), whole job",
             "value": round(value, 1), "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -138,9 +146,11 @@ def main():
                                    f"per GPU, T=98 frames x 40-d fbank in HBM -> (B,98,2) sigmoid posteriors + "
                                    f"(B,256,105) streaming cache",
                        "batch_per_gpu": B, "frames": T, "feat_dim": idim, "parallelism": f"utterance-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_stack_kernel<DS,256,NT=7>",
+            "roofline": {"bound": "mfma", "kernel": "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>",
                          "achieved": round(ach_tf, 3) if ach_tf else None, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / PEAK_F32_TFLOPS, 4) if ach_tf else None, "traffic": None,
+                         "frac": round(ach_tf / PEAK_F32_TFLOPS, 4) if ach_tf else None, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch_with_cache_out": (BYTES_PER_UTT + 256 * 105 * 4) * B,
                          "kernel_ms": round(kern_ms, 4), "flop_per_launch": launch_flop,
                          "hbm_achieved_GBs": round(hbm_gbs, 2), "hbm_peak_GBs": PEAK_HBM_GBS,
                          "hbm_frac": round(hbm_gbs / PEAK_HBM_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_UTT * B},

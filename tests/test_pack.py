@@ -74,3 +74,16 @@ def test_cmvn_file_loaders(tmp_path):
     cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"], cmvn=dict(cmvn_file=str(p), norm_var=True))
     m = init_model(cfg)
     assert np.allclose(m.global_cmvn.mean.numpy(), feats.mean(0), atol=1e-5)
+
+
+def test_packed_model_file_roundtrip(tmp_path):
+    cfg = synth.MODEL_CONFIGS["mdtc_small_global12"]
+    desc, blob = pack.pack(cfg, synth.synth_state_dict(pack.model_spec(cfg), 9))
+    p = str(tmp_path / "model.wekwship")
+    pack.save_packed(p, desc, blob)
+    d2, b2 = pack.load_packed(p)
+    assert d2 == desc and np.array_equal(b2, blob)
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        pack.load_packed(p)

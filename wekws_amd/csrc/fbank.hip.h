@@ -105,6 +105,15 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
   fp->table_floats = int(t.size());
 }
 
+// The LDS strip of a frame is private to one wave and a wave's LDS operations execute in program order, so
+// hand-offs between lanes of the wave need no workgroup barrier: a wave-scope fence (orders the compiler and
+// drains the wave's outstanding LDS traffic) is enough, and the four waves of a workgroup run unsynchronised.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -131,13 +140,11 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
 
   const int64_t total = int64_t(B) * nframes;
   const int64_t stride = int64_t(gridDim.x) * kFbankWaves;
-  const int64_t iters = (total + stride - 1) / stride;  // uniform trip count: barriers inside
   const int FL = P.frame_length;
-  for (int64_t it = 0; it < iters; ++it) {
-    const int64_t f = (it * gridDim.x + blockIdx.x) * kFbankWaves + wave;
-    const bool live = f < total;
-    const int64_t b = live ? f / nframes : 0;
-    const int fr = live ? int(f - b * nframes) : 0;
+  for (int64_t f = int64_t(blockIdx.x) * kFbankWaves + wave; f < total; f += stride) {
+    const bool live = true;
+    const int64_t b = f / nframes;
+    const int fr = int(f - b * nframes);
     const float* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
 
     // ---- load, DC removal (fbank.h:155-160)
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       const int i = lane + 64 * m;
       strip[i] = (i < FL) ? v[m] - mean : 0.f;
     }
-    __syncthreads();
+    wave_sync();
     // ---- pre-emphasis 0.97 (fbank.h:122-127), window (fbank.h:130-135), pack as complex
     float y[8];
 #pragma unroll
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
         y[2 * m + h] = (i < FL) ? (cur - 0.97f * prev) * win[i] : 0.f;
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- 256-point complex FFT, radix-4 DIF, 4 stages
     float2 a0 = make_float2(y[0], y[1]), a1 = make_float2(y[2], y[3]), a2 = make_float2(y[4], y[5]),
            a3 = make_float2(y[6], y[7]);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
         o3 = cmul(o3, tw256[(3 * j * tstep) & 255]);
       }
       z[base] = o0; z[base + q] = o1; z[base + 2 * q] = o2; z[base + 3 * q] = o3;
-      __syncthreads();
+      wave_sync();
     }
     // ---- real-FFT untangle + power (fbank.h:173-175): X[k] = (Zk + conj(Zn))/2 - i w^k (Zk - conj(Zn))/2
     float pw[4];
@@ -215,10 +222,10 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       const float xr = e.x + wo.y, xi = e.y - wo.x;  // e - i*wo
       pw[m] = xr * xr + xi * xi;
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int m = 0; m < 4; ++m) strip[lane + 64 * m] = pw[m];
-    __syncthreads();
+    wave_sync();
     // ---- mel + log (fbank.h:179-190)
     for (int bin = lane; bin < P.num_bins; bin += 64) {
       const int first = int(tab[P.mel_first_off + bin]);
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       e = logf(fmaxf(e, FLT_EPSILON));
       if (live) feats[(b * nframes + fr) * P.num_bins + bin] = e;
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 

@@ -227,3 +227,39 @@ def blob_elems(desc: Mapping) -> int:
         hh = desc["head_hidden"]
         n += hh * C + hh + K * hh + K
     return n
+
+
+# ------------------------------------------------------------------------------------------------
+# Packed-model file: what a C / C++ host reads instead of a torch checkpoint.
+#   bytes 0..7    magic b"WEKWSHIP"
+#   then          16 x int32 little-endian = struct wekws_hip_desc (13 fields + 3 reserved zeros)
+#   then          uint64 n_elems, n_elems x float32 little-endian = the folded blob
+# ------------------------------------------------------------------------------------------------
+MAGIC = b"WEKWSHIP"
+
+
+def save_packed(path: str, desc: Mapping, blob: np.ndarray) -> None:
+    fields = [int(desc[k]) for k in DESC_FIELDS] + [0, 0, 0]
+    blob = np.ascontiguousarray(blob, dtype="<f4")
+    if blob.size != blob_elems(desc):
+        raise ValueError(f"blob has {blob.size} floats, descriptor needs {blob_elems(desc)}")
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(np.asarray(fields, dtype="<i4").tobytes())
+        f.write(np.asarray([blob.size], dtype="<u8").tobytes())
+        f.write(blob.tobytes())
+
+
+def load_packed(path: str) -> Tuple[dict, np.ndarray]:
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not a packed wekws_hip model")
+        fields = np.frombuffer(f.read(64), dtype="<i4")
+        n = int(np.frombuffer(f.read(8), dtype="<u8")[0])
+        blob = np.frombuffer(f.read(4 * n), dtype="<f4").astype(np.float32)
+    if blob.size != n or fields.size != 16:
+        raise ValueError(f"{path}: truncated")
+    desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields[:13])}
+    if desc["abi_version"] != ABI_VERSION or blob.size != blob_elems(desc):
+        raise ValueError(f"{path}: ABI version / size mismatch")
+    return desc, blob

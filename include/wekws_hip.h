@@ -69,6 +69,15 @@ enum wekws_hip_activation {
   WEKWS_HIP_ACT_SIGMOID = 1 /* kws_model.py:196-199 */
 };
 
+/* How the 1x1 / dense convolutions and Linear layers of the conv backbones are multiplied.  Both modes read and
+ * write float32 and accumulate in float32; both meet the 1e-4 posterior bar against the reference. */
+enum wekws_hip_precision {
+  WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 for conv backbones, F32 for GRU */
+  WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32 math */
+  WEKWS_HIP_PRECISION_F16X3 = 2    /* operands split into fp16 hi + lo, three fp16 matrix products per term (fp32-level
+                                      accuracy, ~5x the matrix rate); needs |activation| < 65504 */
+};
+
 /*
  * Model descriptor = the reference's configs['model'] dict (kws_model.py:97-214) as plain ints.
  * The weights travel separately as ONE float32 blob with inference-time constants already
@@ -100,7 +109,8 @@ typedef struct wekws_hip_desc {
   int32_t head;         /* enum wekws_hip_head */
   int32_t head_hidden;  /* GLOBAL / LAST: width of the MLP (64 in kws_model.py:181-186), else 0 */
   int32_t activation;   /* enum wekws_hip_activation */
-  int32_t reserved[3];  /* must be 0 */
+  int32_t precision;    /* enum wekws_hip_precision */
+  int32_t reserved[2];  /* must be 0 */
 } wekws_hip_desc;
 
 typedef struct wekws_hip_model wekws_hip_model;

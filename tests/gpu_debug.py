@@ -17,7 +17,7 @@ bad = 0
 for case in CASES:
     try:
         cfg, sd = case_weights(case)
-        model = build(cfg, sd)
+        model = build(cfg, sd).set_precision(os.environ.get('WEKWS_PRECISION', 'default'))
         y, cache = run(model, case_input(case), case_in_cache(case, cfg), softmax=case.get("softmax", False),
                        chunks=case.get("chunks"))
         gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]

@@ -51,19 +51,21 @@ def run(model, x, cache=None, softmax=False, chunks=None):
 def models():
     cache = {}
 
-    def get(case):
-        key = (case["model"], case.get("odim"), case["cmvn"], case.get("norm_var", True), case["wseed"])
+    def get(case, precision="default"):
+        key = (case["model"], case.get("odim"), case["cmvn"], case.get("norm_var", True), case["wseed"], precision)
         if key not in cache:
             cfg, sd = case_weights(case)
-            cache[key] = (cfg, sd, build(cfg, sd))
+            cache[key] = (cfg, sd, build(cfg, sd).set_precision(precision))
         return cache[key]
     return get
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_golden(case, golden, models):
-    """HIP vs the live-reference golden vectors (41 cases: every backbone/head, ragged T, caches, streaming)."""
-    cfg, sd, model = models(case)
+def test_golden(case, precision, golden, models):
+    """HIP vs the live-reference golden vectors (41 cases: every backbone/head, ragged T, caches, streaming), in
+    both matrix precisions (wekws_hip_precision): exact-f32 MFMA and the fp16 hi/lo split."""
+    cfg, sd, model = models(case, precision)
     x = case_input(case)
     y, cache = run(model, x, case_in_cache(case, cfg), softmax=case.get("softmax", False), chunks=case.get("chunks"))
     gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]

@@ -18,7 +18,7 @@ class HipLibraryError(RuntimeError):
 class Desc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "backbone", "idim", "hdim", "odim", "num_layers", "num_stack", "stack_size", "kernel_size",
-        "preproc_relu", "head", "head_hidden", "activation")] + [("reserved", C.c_int32 * 3)]
+        "preproc_relu", "head", "head_hidden", "activation", "precision")] + [("reserved", C.c_int32 * 2)]
 
 
 class FbankCfg(C.Structure):

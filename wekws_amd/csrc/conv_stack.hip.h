@@ -64,6 +64,8 @@ struct BlockDesc {
   uint32_t b1;        // its folded bias [C]
   uint32_t a2;        // MDTC: packed A of conv2
   uint32_t b2;        // MDTC: folded bias of conv2 [C]
+  uint32_t a1_16;     // same matrices split into fp16 hi/lo and packed for v_mfma_f32_16x16x32_f16
+  uint32_t a2_16;     //   ([o-tile][k32][hi|lo][lane][8 halves], conv_stack_f16.hip.h)
 };
 
 struct StackParams {
@@ -76,6 +78,8 @@ struct StackParams {
   int32_t odim;
   int32_t pre_relu;
   uint32_t pre_a, pre_b;    // packed A [C/16][kpre/16][64][4], bias [C]
+  int32_t kpre16;           // idim rounded up to 32 (fp16 K step)
+  uint32_t pre_a16;         // fp16 hi/lo packed A of the preprocessing Linear
   int32_t head;             // HEAD_*
   int32_t head_hidden;
   int32_t sigmoid;
@@ -179,6 +183,105 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[OW][NT]) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w; }
+
+// ---------------------------------------------------------------------------------------------
+// Classifier head on the resident tile (shared by the f32 and the split-fp16 kernels).  `slab` is free scratch.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int C, int NT>
+__device__ __forceinline__ void conv_stack_head(const StackParams& P, const CallArgs& A, float* hbuf, float* slab, int b0) {
+  using G = Geom<KIND, C, NT>;
+  constexpr int U = G::U, SS = G::SS;
+  const int tid = threadIdx.x;
+  const int T = A.T;
+  const float* __restrict__ W = P.w;
+  const int K = P.odim;
+  if (WEKWS_ABLATE == 7 || WEKWS_ABLATE == 9) {
+  } else if (P.head == HEAD_LINEAR) {
+    // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
+    // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
+    const bool staged = K * (C + 1) <= G::S_FLOATS;
+    if (staged) {
+      for (int e = tid; e < K * C; e += kThreads) slab[e] = W[P.head_w + e];
+      for (int e = tid; e < K; e += kThreads) slab[K * C + e] = W[P.head_b + e];
+      __syncthreads();
+    }
+    const float* wsrc = staged ? slab : W + P.head_w;
+    const float* bsrc = staged ? slab + K * C : W + P.head_b;
+    for (int e = tid; e < U * K * T; e += kThreads) {
+      const int t = e % T;
+      const int uk = e / T;
+      const int u = uk / K, k = uk - u * K;
+      if (b0 + u >= A.B) continue;
+      const float* hc = hbuf + u * C * SS + t;
+      const float* wk = wsrc + k * C;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+      for (int c = 0; c < C; c += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
+        s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
+        s1 = fmaf(w4.y, hc[(c + 1) * SS], s1);
+        s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
+        s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
+      }
+      float v = (s0 + s1) + (s2 + s3) + bsrc[k];
+      if (P.sigmoid) v = sigmoidf_(v);
+      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
+    }
+  } else if (P.head == HEAD_IDENTITY) {
+    for (int e = tid; e < U * T * C; e += kThreads) {
+      const int c = e % C;
+      const int ut = e / C;
+      const int u = ut / T, t = ut - u * T;
+      if (b0 + u >= A.B) continue;
+      float v = hbuf[(u * C + c) * SS + t];
+      if (P.sigmoid) v = sigmoidf_(v);
+      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * C + c] = v;
+    }
+  } else {
+    // GLOBAL: m = mean_t h ; LAST: m = h[:, -1]  ->  W2 ReLU(W1 m + b1) + b2   (classifier.py:26-28, :38-40)
+    float* mvec = slab;                 // [U][C]
+    float* hid = slab + U * C;          // [U][head_hidden]
+    const int HH = P.head_hidden;
+    for (int e = tid; e < U * C; e += kThreads) {
+      const int u = e / C, c = e - u * C;
+      const float* hc = hbuf + (u * C + c) * SS;
+      float s;
+      if (P.head == HEAD_GLOBAL) {
+        s = 0.f;
+        for (int t = 0; t < T; ++t) s += hc[t];
+        if (A.gsum && (b0 + u) < A.B) {
+          float* gp = A.gsum + int64_t(b0 + u) * C + c;
+          if (!A.first_tile) s += *gp;
+          if (!A.last_tile) *gp = s;
+        }
+        s = s / float(A.T_total);
+      } else {
+        s = hc[T - 1];
+      }
+      mvec[e] = s;
+    }
+    __syncthreads();
+    if (A.last_tile) {
+      for (int e = tid; e < U * HH; e += kThreads) {
+        const int u = e / HH, j = e - u * HH;
+        const float* w1 = W + P.head_w + j * C;
+        float s = W[P.head_b + j];
+        for (int c = 0; c < C; ++c) s = fmaf(w1[c], mvec[u * C + c], s);
+        hid[e] = fmaxf(s, 0.f);
+      }
+      __syncthreads();
+      for (int e = tid; e < U * K; e += kThreads) {
+        const int u = e / K, k = e - u * K;
+        if (b0 + u >= A.B) continue;
+        const float* w2 = W + P.head_w2 + k * HH;
+        float s = W[P.head_b2 + k];
+        for (int j = 0; j < HH; ++j) s = fmaf(w2[j], hid[u * HH + j], s);
+        if (P.sigmoid) s = sigmoidf_(s);
+        A.y[int64_t(b0 + u) * A.ys_b + k] = s;
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 template <int KIND, int C, int NT, int KS>
@@ -491,94 +594,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     __syncthreads();
   }
 
-  // ============================================ head ============================================
-  const int K = P.odim;
-  if (WEKWS_ABLATE == 7 || WEKWS_ABLATE == 9) {
-  } else if (P.head == HEAD_LINEAR) {
-    // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
-    // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
-    const bool staged = K * (C + 1) <= G::S_FLOATS;
-    if (staged) {
-      for (int e = tid; e < K * C; e += kThreads) slab[e] = W[P.head_w + e];
-      for (int e = tid; e < K; e += kThreads) slab[K * C + e] = W[P.head_b + e];
-      __syncthreads();
-    }
-    const float* wsrc = staged ? slab : W + P.head_w;
-    const float* bsrc = staged ? slab + K * C : W + P.head_b;
-    for (int e = tid; e < U * K * T; e += kThreads) {
-      const int t = e % T;
-      const int uk = e / T;
-      const int u = uk / K, k = uk - u * K;
-      if (b0 + u >= A.B) continue;
-      const float* hc = hbuf + u * C * SS + t;
-      const float* wk = wsrc + k * C;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-      for (int c = 0; c < C; c += 4) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
-        s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
-        s1 = fmaf(w4.y, hc[(c + 1) * SS], s1);
-        s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
-        s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
-      }
-      float v = (s0 + s1) + (s2 + s3) + bsrc[k];
-      if (P.sigmoid) v = sigmoidf_(v);
-      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
-    }
-  } else if (P.head == HEAD_IDENTITY) {
-    for (int e = tid; e < U * T * C; e += kThreads) {
-      const int c = e % C;
-      const int ut = e / C;
-      const int u = ut / T, t = ut - u * T;
-      if (b0 + u >= A.B) continue;
-      float v = hbuf[(u * C + c) * SS + t];
-      if (P.sigmoid) v = sigmoidf_(v);
-      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * C + c] = v;
-    }
-  } else {
-    // GLOBAL: m = mean_t h ; LAST: m = h[:, -1]  ->  W2 ReLU(W1 m + b1) + b2   (classifier.py:26-28, :38-40)
-    float* mvec = slab;                 // [U][C]
-    float* hid = slab + U * C;          // [U][head_hidden]
-    const int HH = P.head_hidden;
-    for (int e = tid; e < U * C; e += kThreads) {
-      const int u = e / C, c = e - u * C;
-      const float* hc = hbuf + (u * C + c) * SS;
-      float s;
-      if (P.head == HEAD_GLOBAL) {
-        s = 0.f;
-        for (int t = 0; t < T; ++t) s += hc[t];
-        if (A.gsum && (b0 + u) < A.B) {
-          float* gp = A.gsum + int64_t(b0 + u) * C + c;
-          if (!A.first_tile) s += *gp;
-          if (!A.last_tile) *gp = s;
-        }
-        s = s / float(A.T_total);
-      } else {
-        s = hc[T - 1];
-      }
-      mvec[e] = s;
-    }
-    __syncthreads();
-    if (A.last_tile) {
-      for (int e = tid; e < U * HH; e += kThreads) {
-        const int u = e / HH, j = e - u * HH;
-        const float* w1 = W + P.head_w + j * C;
-        float s = W[P.head_b + j];
-        for (int c = 0; c < C; ++c) s = fmaf(w1[c], mvec[u * C + c], s);
-        hid[e] = fmaxf(s, 0.f);
-      }
-      __syncthreads();
-      for (int e = tid; e < U * K; e += kThreads) {
-        const int u = e / K, k = e - u * K;
-        if (b0 + u >= A.B) continue;
-        const float* w2 = W + P.head_w2 + k * HH;
-        float s = W[P.head_b2 + k];
-        for (int j = 0; j < HH; ++j) s = fmaf(w2[j], hid[u * HH + j], s);
-        if (P.sigmoid) s = sigmoidf_(s);
-        A.y[int64_t(b0 + u) * A.ys_b + k] = s;
-      }
-    }
-  }
+  conv_stack_head<KIND, C, NT>(P, A, hbuf, slab, b0);
 }
 
 // Row softmax over the last axis (KWSModel.forward_softmax, kws_model.py:89): one wave per row.

@@ -1,0 +1,471 @@
+// Split-precision variant of the fused conv-backbone forward (see conv_stack.hip.h for the structure, the
+// reference citations and the LDS geometry, which are shared).
+//
+// The f32-input matrix instruction of gfx950 issues at the vector-FP32 rate (32 cycles per 16x16x4), 1/16 of the
+// fp16 rate, and -- measured, build/probe/mfma_probe.hip -- a saturated MFMA stream lets only ONE VALU instruction
+// of the co-resident wave through per MFMA, so matrix time and vector time add up.  Here every 1x1 / dense
+// convolution runs on v_mfma_f32_16x16x32_f16 instead, with fp32-level accuracy recovered by the classic
+// two-term split of both operands:
+//        w = wh + wl,  a = ah + al      (wh = fp16(w), wl = fp16(w - wh); same for a; |w - wh - wl| <~ 2^-22 |w|)
+//        w*a ~= wh*ah + wh*al + wl*ah   (the dropped wl*al term is <= 2^-22 relative)
+// Products of fp16 values are exact in the fp32 accumulator and the instruction honours fp16 subnormals
+// (build/probe/denorm.hip), so the lo parts need no scaling and all three terms share ONE accumulator set.
+// Cost per 32-deep K step: 3 x 17 cycles instead of 8 x 32.  Assumption: |activation| < 65504 (fp16 range);
+// the exact-f32 kernel remains selectable (wekws_hip_desc.precision) for models outside it.
+//
+// Differences from the f32 kernel:
+//   - slab (MFMA B operand) holds fp16 hi and lo planes in [k-octet][frame][8] order: one lane's fragment
+//     (8 consecutive k of one frame) is a single ds_read_b128 and a 16-lane group covers 16 distinct 16-byte
+//     slots -> conflict free; same byte footprint as the f32 slab;
+//   - weights are split and packed on the host into [o-tile][k32][hi|lo][lane][8 halves] (two 16-byte loads per
+//     lane, o-tile and K step);
+//   - producers convert on the fly (cvt, subtract, cvt) and store halves; the MDTC mid tile is written by the
+//     first epilogue directly in operand order.
+#pragma once
+#include "conv_stack.hip.h"
+
+namespace wekws {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct F16Frag {
+  f16x8 h, l;
+};
+
+__device__ __forceinline__ void split16(float v, _Float16& h, _Float16& l) {
+  h = static_cast<_Float16>(v);
+  l = static_cast<_Float16>(v - static_cast<float>(h));
+}
+
+// Byte size of one (utterance, buffer) hi or lo plane holding KCH channels x TT frames
+template <int KCH, int TT>
+struct Plane {
+  static constexpr int BYTES = (KCH / 8) * TT * 16;
+};
+
+// acc += A x B for ONE 32-deep K step.  bh / bl: this lane's 16-byte item of t-tile 0 in the hi / lo plane
+// ((k-octet = lane>>4, frame = lane&15)); consecutive t-tiles are 16 items (256 B) apart.
+template <int OW, int NT>
+__device__ __forceinline__ void mfma16_step(f32x4 (&acc)[OW][NT], const F16Frag (&a)[OW], const char* bh, const char* bl) {
+  f16x8 vh[2], vl[2];
+  vh[0] = *reinterpret_cast<const f16x8*>(bh);
+  vl[0] = *reinterpret_cast<const f16x8*>(bl);
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    if (tt + 1 < NT) {
+      vh[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bh + (tt + 1) * 256);
+      vl[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bl + (tt + 1) * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // reads of tile tt+1 stay ahead of the MFMAs of tile tt
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ow].h, vh[tt & 1], acc[ow][tt], 0, 0, 0);
+      acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ow].h, vl[tt & 1], acc[ow][tt], 0, 0, 0);
+      acc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ow].l, vh[tt & 1], acc[ow][tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// A fragments of one K step: image order [o-tile][k32][hi|lo][lane][8 halves] = 128 uint4 per (o-tile, k32)
+template <int OW>
+__device__ __forceinline__ void load_a16(F16Frag (&a)[OW], const uint4* __restrict__ ap, int ot_stride) {
+#pragma unroll
+  for (int ow = 0; ow < OW; ++ow) {
+    const uint4 h = ap[ow * ot_stride], l = ap[ow * ot_stride + 64];
+    a[ow].h = __builtin_bit_cast(f16x8, h);
+    a[ow].l = __builtin_bit_cast(f16x8, l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int C, int NT, int KS>
+__global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const StackParams P, const CallArgs A) {
+  using G = Geom<KIND, C, NT>;
+  constexpr int U = G::U, OW = G::OW, SS = G::SS;
+  constexpr int TT = 16 * NT;
+  constexpr int KC = 32;                                   // one MFMA K step per produced chunk
+  constexpr int NBUF = (C >= 64) ? 2 : 1;                  // C = 32: the whole K is one chunk
+  constexpr int PB = Plane<KC, TT>::BYTES;                 // one hi (or lo) plane of a chunk
+  constexpr int UB = (KIND == KIND_MDTC && C > 2 * KC) ? 2 * Plane<C, TT>::BYTES : NBUF * 2 * PB;  // bytes per utterance
+  static_assert(U * UB <= G::S_FLOATS * 4, "fp16 slab must fit the shared geometry");
+  constexpr int RP = (U * KC) / (kThreads / 16);           // slab rows per 16-lane group per chunk
+  static_assert(RP * (kThreads / 16) == U * KC && RP >= 1, "producer decomposition");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const hbuf = lds;                                 // [U][C][SS] f32 resident activations
+  char* const slab = reinterpret_cast<char*>(lds + G::H_FLOATS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wo = wave % G::WO, wu = wave / G::WO;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b0 = blockIdx.x * U;
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int pg = tid >> 4, tl = tid & 15;
+  const int o_base = wo * OW * 16;
+  float* const h_w = hbuf + wu * C * SS;
+  char* const slab_u = slab + wu * UB;                     // this wave's utterance
+  const int frag_off = (lq * TT + l15) * 16;               // this lane's item of t-tile 0 inside a plane
+
+  f32x4 acc[OW][NT];
+  f32x4 zsum[KIND == KIND_MDTC ? OW : 1][KIND == KIND_MDTC ? NT : 1];
+  if constexpr (KIND == KIND_MDTC) zero_acc(zsum);
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+    zero_acc(acc);
+    const int nk = P.kpre16 / 32;                          // K steps (idim rounded up to 32)
+    const int ot_stride = nk * 128;
+    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + (wo * OW) * ot_stride + lane;
+    float4 bias[OW];
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) bias[ow] = *reinterpret_cast<const float4*>(W + P.pre_b + o_base + ow * 16 + lq * 4);
+    for (int k0 = 0; k0 < nk; k0 += NBUF) {                // NBUF K steps staged per pass
+      const int steps = min(NBUF, nk - k0);
+      __syncthreads();
+      // item = (utterance, step, k-octet, frame): 8 consecutive features of one frame -> one 16-byte hi + lo store
+      for (int e = tid; e < U * steps * 4 * TT; e += kThreads) {
+        const int t = e % TT;
+        int q = e / TT;
+        const int oct = q & 3; q >>= 2;
+        const int st = q % steps, u = q / steps;
+        const int kf = (k0 + st) * 32 + oct * 8;
+        const bool ok = (b0 + u) < A.B && t < T;
+        const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          _Float16 h, l;
+          split16(v, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        char* dst = slab + u * UB + st * 2 * PB + (oct * TT + t) * 16;
+        *reinterpret_cast<f16x8*>(dst) = vh;
+        *reinterpret_cast<f16x8*>(dst + PB) = vl;
+      }
+      __syncthreads();
+      for (int st = 0; st < steps; ++st) {
+        F16Frag a[OW];
+        load_a16<OW>(a, ap + (k0 + st) * 128, ot_stride);
+        mfma16_step<OW, NT>(acc, a, slab_u + st * 2 * PB + frag_off, slab_u + st * 2 * PB + PB + frag_off);
+      }
+    }
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ow][tt][r] + f4c(bias[ow], r);
+          if (P.pre_relu) v = fmaxf(v, 0.f);
+          h_w[(o + r) * SS + t] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ======================================= residual blocks =======================================
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    const BlockDesc bd = P.blocks[bi];
+    const int d = bd.dil, pad = bd.pad;
+    const int K1 = (KIND == KIND_TCN) ? C * KS : C;
+    const int nch = K1 / KC;
+    const int ot_stride1 = nch * 128;
+    const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + (wo * OW) * ot_stride1 + lane;
+
+    float dww[KIND == KIND_TCN ? 1 : RP][KIND == KIND_TCN ? 1 : KS + 1];
+    auto load_dw = [&](int n) __attribute__((always_inline)) {
+      if constexpr (KIND != KIND_TCN) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+          const int item = pg + i * (kThreads / 16);
+          const int c = n * KC + (item % KC);
+#pragma unroll
+          for (int j = 0; j < KS; ++j) dww[i][j] = W[bd.dw_w + c * KS + j];
+          dww[i][KS] = W[bd.dw_b + c];
+        }
+      }
+    };
+    F16Frag a0[OW], a1[OW];
+    load_dw(0);
+    load_a16<OW>(a0, ap1, ot_stride1);
+    float4 ebias[OW];
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow)
+      ebias[ow] = *reinterpret_cast<const float4*>(W + (KIND == KIND_MDTC ? bd.b2 : bd.b1) + o_base + ow * 16 + lq * 4);
+
+    const bool slide = d <= 16 && (16 % d) == 0;
+    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+
+    // ---- producer of K-chunk n into slab buffer `buf` (fp16 hi / lo planes, [k-octet][frame][8])
+    auto produce_impl = [&](int n, int buf, auto has_cache_tag) __attribute__((always_inline)) {
+      constexpr bool HAS_CACHE = decltype(has_cache_tag)::value;
+#define fetch(idx_)                                                                      \
+  ({                                                                                     \
+    const int ix_ = (idx_);                                                              \
+    float fv_ = hbuf[hoff + max(ix_, 0)];                                                \
+    if constexpr (HAS_CACHE) {                                                           \
+      const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
+      fv_ = ix_ >= 0 ? fv_ : (uok ? fg_ : 0.f);                                          \
+    } else {                                                                             \
+      fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
+    }                                                                                    \
+    fv_;                                                                                 \
+  })
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        const int item = pg + i * (kThreads / 16);
+        const int u = item / KC, r = item % KC;
+        const bool uok = (b0 + u) < A.B;
+        char* const plane = slab + u * UB + buf * 2 * PB;       // hi plane; lo plane at + PB
+        if constexpr (KIND == KIND_TCN) {
+          // dense conv as GEMM over K' = (c, j): the 8 taps of channel c are one k-octet   (tcn.py:76-80)
+          // 16 lanes cover the 8 taps x 2 frame halves; one lane stores one half (2 bytes) per frame.
+          const int kk = n * KC + r;
+          const int c = kk / KS, j0 = kk % KS;
+          const int hoff = (u * C + c) * SS;
+          const int64_t gbase = (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
+          if (A.out_cache && uok && j0 == 0) {
+            for (int p = tl; p < pad; p += 16) {
+              const int src = T + p - pad;
+              float cv = hbuf[hoff + max(src, 0)];
+              if constexpr (HAS_CACHE) {
+                const float g = A.in_cache[gbase + pad + min(src, -1)];
+                cv = src >= 0 ? cv : g;
+              } else {
+                cv = src >= 0 ? cv : 0.f;
+              }
+              A.out_cache[gbase + p] = cv;
+            }
+          }
+          const int sh = (KS - 1 - j0) * d;
+          _Float16* ph = reinterpret_cast<_Float16*>(plane) + ((r >> 3) * TT) * 8 + (r & 7);
+          _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + ((r >> 3) * TT) * 8 + (r & 7);
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+            const int t = tl + 16 * m;
+            const float v = (t < T) ? fetch(t - sh) : 0.f;
+            _Float16 h, l;
+            split16(v, h, l);
+            ph[t * 8] = h;
+            pl[t * 8] = l;
+          }
+        } else {
+          // depthwise dilated conv + folded BN (+ReLU for DS-TCN)        (tcn.py:102-109, mdtc.py:55-58)
+          const int c = n * KC + r;
+          const int hoff = (u * C + c) * SS;
+          const int64_t gbase = (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
+          if (A.out_cache && uok) {
+            for (int p = tl; p < pad; p += 16) {
+              const int src = T + p - pad;
+              float cv = hbuf[hoff + max(src, 0)];
+              if constexpr (HAS_CACHE) {
+                const float g = A.in_cache[gbase + pad + min(src, -1)];
+                cv = src >= 0 ? cv : g;
+              } else {
+                cv = src >= 0 ? cv : 0.f;
+              }
+              A.out_cache[gbase + p] = cv;
+            }
+          }
+          _Float16* ph = reinterpret_cast<_Float16*>(plane) + ((r >> 3) * TT) * 8 + (r & 7);
+          _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + ((r >> 3) * TT) * 8 + (r & 7);
+          if (slide) {
+            float v[NT + KS - 1];
+#pragma unroll
+            for (int q = 0; q < NT + KS - 1; ++q) v[q] = fetch(fbase + (q - (KS - 1)) * d);
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+              float o = dww[i][KS];
+#pragma unroll
+              for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], v[m + j], o);
+              if (KIND == KIND_DS) o = fmaxf(o, 0.f);
+              const int t = fbase + m * d;
+              o = (t < T) ? o : 0.f;
+              _Float16 h, l;
+              split16(o, h, l);
+              ph[t * 8] = h;
+              pl[t * 8] = l;
+            }
+          } else {
+#pragma unroll 1
+            for (int m = 0; m < NT; ++m) {
+              const int t = tl + 16 * m;
+              float o = dww[i][KS];
+#pragma unroll
+              for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], fetch(t - (KS - 1 - j) * d), o);
+              if (KIND == KIND_DS) o = fmaxf(o, 0.f);
+              o = (t < T) ? o : 0.f;
+              _Float16 h, l;
+              split16(o, h, l);
+              ph[t * 8] = h;
+              pl[t * 8] = l;
+            }
+          }
+        }
+      }
+#undef fetch
+    };
+    const bool has_cache = A.in_cache != nullptr;
+    auto produce = [&](int n, int buf) __attribute__((always_inline)) {
+      if (has_cache) produce_impl(n, buf, std::true_type{});
+      else produce_impl(n, buf, std::false_type{});
+    };
+
+    // ---- GEMM 1 over K: one MFMA K step per chunk, double-buffered planes, one barrier per chunk
+    zero_acc(acc);
+    produce(0, 0);
+    load_dw(min(1, nch - 1));
+    __syncthreads();
+    if constexpr (NBUF == 2) {
+      for (int n = 0; n < nch; n += 2) {
+        produce(n + 1, 1);
+        load_a16<OW>(a1, ap1 + (n + 1) * 128, ot_stride1);
+        load_dw(min(n + 2, nch - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
+        __syncthreads();
+        if (n + 2 < nch) produce(n + 2, 0);
+        load_a16<OW>(a0, ap1 + min(n + 2, nch - 1) * 128, ot_stride1);
+        load_dw(min(n + 3, nch - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16_step<OW, NT>(acc, a1, slab_u + 2 * PB + frag_off, slab_u + 3 * PB + frag_off);
+        __syncthreads();
+      }
+    } else {
+      mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
+      __syncthreads();
+      (void)a1;
+    }
+
+    if constexpr (KIND == KIND_MDTC) {
+      // ---- mid = ReLU(BN1(pointwise)) written straight in operand order, then conv2 (1x1) + BN2   (mdtc.py:113-116)
+      constexpr int NK2 = C / 32;
+      constexpr int MPB = Plane<C, TT>::BYTES;                 // hi plane of the full-width mid tile
+      static_assert(2 * MPB <= UB, "mid tile must fit the per-utterance slab");
+      F16Frag a2[NK2][OW];
+      const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + (wo * OW) * (NK2 * 128) + lane;
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks) load_a16<OW>(a2[ks], ap2 + ks * 128, NK2 * 128);
+#pragma unroll
+      for (int ow = 0; ow < OW; ++ow) {
+        const int o = o_base + ow * 16 + lq * 4;
+        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const int t = tt * 16 + l15;
+          f16x4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(acc[ow][tt][r] + f4c(bias, r), 0.f);
+            _Float16 h, l;
+            split16(v, h, l);
+            vh[r] = h; vl[r] = l;
+          }
+          char* dst = slab_u + (((o >> 3) * TT + t) * 8 + (o & 7)) * 2;   // 4 consecutive channels = 8 bytes
+          *reinterpret_cast<f16x4*>(dst) = vh;
+          *reinterpret_cast<f16x4*>(dst + MPB) = vl;
+        }
+      }
+      __syncthreads();
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < NK2; ++ks)
+        mfma16_step<OW, NT>(acc, a2[ks], slab_u + ks * 4 * TT * 16 + frag_off, slab_u + MPB + ks * 4 * TT * 16 + frag_off);
+    }
+
+    // ---- epilogue: bias (+ReLU) + residual, in place into h
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+      const float4 bias = ebias[ow];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ow][tt][r] + f4c(bias, r);
+          float* hp = h_w + (o + r) * SS + t;
+          if constexpr (KIND == KIND_MDTC) {
+            v = fmaxf(v + *hp, 0.f);
+            if (bd.zadd) zsum[ow][tt][r] += v;
+          } else {
+            v = fmaxf(v, 0.f) + *hp;
+          }
+          *hp = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (KIND == KIND_MDTC) {
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tt * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h_w[(o + r) * SS + t] = zsum[ow][tt][r];
+      }
+    }
+    __syncthreads();
+  }
+
+  conv_stack_head<KIND, C, NT>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
+}
+
+template <int KIND>
+int launch_conv_stack_f16(int C, int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+template <> int launch_conv_stack_f16<KIND_DS>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+template <> int launch_conv_stack_f16<KIND_TCN>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+template <> int launch_conv_stack_f16<KIND_MDTC>(int, int, const StackParams&, const CallArgs&, hipStream_t);
+
+template <int KIND, int C, int NT>
+inline int launch_one_f16(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  using G = Geom<KIND, C, NT>;
+  constexpr int KS = (KIND == KIND_MDTC) ? 5 : 8;
+  if (P.ksize != KS) return -4;
+  static bool attr_set = false;
+  auto kern = conv_stack_f16_kernel<KIND, C, NT, KS>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(G::LDS_BYTES)) != hipSuccess)
+      return -3;
+    attr_set = true;
+  }
+  const int grid = (A.B + G::U - 1) / G::U;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+#define WEKWS_DISPATCH_NT_F16(KIND, CC)                                        \
+  switch (nt) {                                                                \
+    case 1: return launch_one_f16<KIND, CC, 1>(P, A, stream);                  \
+    case 2: return launch_one_f16<KIND, CC, 2>(P, A, stream);                  \
+    case 4: return launch_one_f16<KIND, CC, 4>(P, A, stream);                  \
+    case 7: return launch_one_f16<KIND, CC, 7>(P, A, stream);                  \
+    default: return -1;                                                        \
+  }
+
+#define WEKWS_DEFINE_LAUNCHER_F16(KIND, WITH256)                               \
+  template <>                                                                  \
+  int launch_conv_stack_f16<KIND>(int C, int nt, const StackParams& P, const CallArgs& A, hipStream_t stream) { \
+    switch (C) {                                                               \
+      case 32: WEKWS_DISPATCH_NT_F16(KIND, 32)                                 \
+      case 64: WEKWS_DISPATCH_NT_F16(KIND, 64)                                 \
+      case 128: WEKWS_DISPATCH_NT_F16(KIND, 128)                               \
+      case 256: if constexpr (WITH256) { WEKWS_DISPATCH_NT_F16(KIND, 256) } else return -4; \
+      default: return -4;                                                      \
+    }                                                                          \
+  }
+
+}  // namespace wekws

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "conv_stack.hip.h"
+#include "conv_stack_f16.hip.h"
 #include "fbank.hip.h"
 #include "gru.hip.h"
 
@@ -70,6 +71,27 @@ struct Image {
           }
     return off;
   }
+  // A operand of v_mfma_f32_16x16x32_f16, operands split into fp16 hi + lo (conv_stack_f16.hip.h):
+  // [o-tile][k32][hi|lo][lane][8 halves], lane l holds W[otile*16 + (l&15)][k32*32 + 8*(l>>4) + e], e = 0..7.
+  uint32_t put_packed_a16(const float* Wsrc, int O, int Ksrc, int ld) {
+    const int Op = round_up(O, 16), Kp = round_up(Ksrc, 32);
+    const size_t halves = size_t(Op) * Kp * 2;
+    uint32_t off = reserve(halves / 2);
+    _Float16* dst = reinterpret_cast<_Float16*>(data.data() + off);
+    for (int ot = 0; ot < Op / 16; ++ot)
+      for (int ks = 0; ks < Kp / 32; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int o = ot * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + e;
+            const float v = (o < O && k < Ksrc) ? Wsrc[size_t(o) * ld + k] : 0.f;
+            const _Float16 h = static_cast<_Float16>(v);
+            const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+            const size_t base = ((size_t(ot) * (Kp / 32) + ks) * 2) * 512;  // halves per (o-tile, k32, plane) = 64*8
+            dst[base + lane * 8 + e] = h;
+            dst[base + 512 + lane * 8 + e] = l;
+          }
+    return off;
+  }
 };
 
 struct Workspace {
@@ -94,7 +116,8 @@ int n_blocks(const wekws_hip_desc& d) {
 size_t blob_elems(const wekws_hip_desc& d) {
   if (d.abi_version != WEKWS_HIP_ABI_VERSION) { fail(WEKWS_HIP_EINVAL, "desc.abi_version %d != %d", d.abi_version, WEKWS_HIP_ABI_VERSION); return 0; }
   if (d.idim <= 0 || d.hdim <= 0 || d.odim <= 0) { fail(WEKWS_HIP_EINVAL, "idim/hdim/odim must be positive"); return 0; }
-  if (d.reserved[0] || d.reserved[1] || d.reserved[2]) { fail(WEKWS_HIP_EINVAL, "desc.reserved must be 0"); return 0; }
+  if (d.reserved[0] || d.reserved[1]) { fail(WEKWS_HIP_EINVAL, "desc.reserved must be 0"); return 0; }
+  if (d.precision < 0 || d.precision > WEKWS_HIP_PRECISION_F16X3) { fail(WEKWS_HIP_EINVAL, "desc.precision %d", d.precision); return 0; }
   const size_t C = d.hdim, K = d.odim, ks = d.kernel_size;
   size_t n = C * d.idim + C;  // preprocessing
   switch (d.backbone) {
@@ -207,6 +230,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
 
   // ---- preprocessing
   const uint32_t pre_a = img.put_packed_a(p, C, d.idim, d.idim);
+  const uint32_t pre_a16 = desc_conv(d) ? img.put_packed_a16(p, C, d.idim, d.idim) : 0;
   p += size_t(C) * d.idim;
   const uint32_t pre_b = img.put(p, C);
   p += C;
@@ -219,6 +243,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     sp.pre_relu = d.preproc_relu;
     sp.pre_a = pre_a;
     sp.pre_b = pre_b;
+    sp.kpre16 = round_up(d.idim, 32);
+    sp.pre_a16 = pre_a16;
     const int nb = n_blocks(d);
     int off = 0;
     for (int i = 0; i < nb; ++i) {
@@ -234,6 +260,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       off += b.pad;
       if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
         b.a1 = img.put_packed_a(p, C, C * ks, C * ks);
+        b.a1_16 = img.put_packed_a16(p, C, C * ks, C * ks);
         p += size_t(C) * C * ks;
         b.b1 = img.put(p, C);
         p += C;
@@ -243,11 +270,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
         b.dw_b = img.put(p, C);
         p += C;
         b.a1 = img.put_packed_a(p, C, C, C);
+        b.a1_16 = img.put_packed_a16(p, C, C, C);
         p += size_t(C) * C;
         b.b1 = img.put(p, C);
         p += C;
         if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
           b.a2 = img.put_packed_a(p, C, C, C);
+          b.a2_16 = img.put_packed_a16(p, C, C, C);
           p += size_t(C) * C;
           b.b2 = img.put(p, C);
           p += C;
@@ -412,10 +441,20 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       a.first_tile = (i == 0);
       a.last_tile = (i == ntiles - 1);
       int rc;
+      const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
       switch (d.backbone) {
-        case WEKWS_HIP_BACKBONE_DS_TCN: rc = wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream); break;
-        case WEKWS_HIP_BACKBONE_TCN: rc = wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream); break;
-        default: rc = wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream); break;
+        case WEKWS_HIP_BACKBONE_DS_TCN:
+          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+                   : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream);
+          break;
+        case WEKWS_HIP_BACKBONE_TCN:
+          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
+                   : wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
+          break;
+        default:
+          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
+                   : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
+          break;
       }
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
     }

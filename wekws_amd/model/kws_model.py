@@ -135,6 +135,16 @@ class KWSModel(nn.Module):
             self._handle_key = key
         return self._handle
 
+    def set_precision(self, mode: str) -> "KWSModel":
+        """'default' | 'f32' (exact-f32 matrix instructions) | 'f16x3' (fp16 hi/lo split, fp32-level accuracy,
+        ~5x the matrix rate) -- enum wekws_hip_precision.  Can also be given as configs['_precision']."""
+        if mode not in pack.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(pack.PRECISION)}")
+        self._cfg["_precision"] = mode
+        self._d["precision"] = pack.PRECISION[mode]
+        self._handle = None
+        return self
+
     def packed(self) -> Tuple[dict, np.ndarray]:
         """(descriptor, folded float32 blob) -- what wekws_hip_create consumes; used by the multi-GPU
         weight broadcast (wekws_amd/parallel.py) and the model-file writer."""

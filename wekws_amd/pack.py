@@ -23,7 +23,8 @@ BN_EPS = 1e-5
 HEAD_HIDDEN = 64  # nn.Linear(hidden_dim, 64) in wekws/model/kws_model.py:181-186
 
 DESC_FIELDS = ("abi_version", "backbone", "idim", "hdim", "odim", "num_layers", "num_stack", "stack_size",
-               "kernel_size", "preproc_relu", "head", "head_hidden", "activation")
+               "kernel_size", "preproc_relu", "head", "head_hidden", "activation", "precision")
+PRECISION = dict(default=0, f32=1, f16x3=2)  # enum wekws_hip_precision
 
 
 class ConfigError(ValueError):
@@ -40,7 +41,8 @@ def parse_config(configs: Mapping) -> dict:
     bb = configs["backbone"]
     bt = bb["type"]
     d = dict(abi_version=ABI_VERSION, idim=idim, hdim=hdim, odim=odim, num_layers=0, num_stack=0, stack_size=0,
-             kernel_size=0, preproc_relu=1 if prep == "linear" else 0, prep=prep)
+             kernel_size=0, preproc_relu=1 if prep == "linear" else 0, prep=prep,
+             precision=PRECISION[str(configs.get("_precision", "default"))])
     if bt == "gru":
         d.update(backbone=BACKBONE["gru"], num_layers=int(bb["num_layers"]), kind="gru")
     elif bt == "tcn":
@@ -232,14 +234,14 @@ def blob_elems(desc: Mapping) -> int:
 # ------------------------------------------------------------------------------------------------
 # Packed-model file: what a C / C++ host reads instead of a torch checkpoint.
 #   bytes 0..7    magic b"WEKWSHIP"
-#   then          16 x int32 little-endian = struct wekws_hip_desc (13 fields + 3 reserved zeros)
+#   then          16 x int32 little-endian = struct wekws_hip_desc (14 fields + 2 reserved zeros)
 #   then          uint64 n_elems, n_elems x float32 little-endian = the folded blob
 # ------------------------------------------------------------------------------------------------
 MAGIC = b"WEKWSHIP"
 
 
 def save_packed(path: str, desc: Mapping, blob: np.ndarray) -> None:
-    fields = [int(desc[k]) for k in DESC_FIELDS] + [0, 0, 0]
+    fields = [int(desc[k]) for k in DESC_FIELDS] + [0, 0]
     blob = np.ascontiguousarray(blob, dtype="<f4")
     if blob.size != blob_elems(desc):
         raise ValueError(f"blob has {blob.size} floats, descriptor needs {blob_elems(desc)}")
@@ -259,7 +261,7 @@ def load_packed(path: str) -> Tuple[dict, np.ndarray]:
         blob = np.frombuffer(f.read(4 * n), dtype="<f4").astype(np.float32)
     if blob.size != n or fields.size != 16:
         raise ValueError(f"{path}: truncated")
-    desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields[:13])}
+    desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields[:14])}
     if desc["abi_version"] != ABI_VERSION or blob.size != blob_elems(desc):
         raise ValueError(f"{path}: ABI version / size mismatch")
     return desc, blob

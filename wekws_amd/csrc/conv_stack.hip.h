@@ -64,6 +64,7 @@ struct BlockDesc {
   uint32_t b1;        // its folded bias [C]
   uint32_t a2;        // MDTC: packed A of conv2
   uint32_t b2;        // MDTC: folded bias of conv2 [C]
+  uint32_t dw_pk;     // DS/MDTC: taps + bias per channel padded to a multiple of 4 floats: [C][round_up(ksize+1,4)]
   uint32_t a1_16;     // same matrices split into fp16 hi/lo and packed for v_mfma_f32_16x16x32_f16
   uint32_t a2_16;     //   ([o-tile][k32][hi|lo][lane][8 halves], conv_stack_f16.hip.h)
 };
@@ -207,25 +208,50 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     }
     const float* wsrc = staged ? slab : W + P.head_w;
     const float* bsrc = staged ? slab + K * C : W + P.head_b;
-    for (int e = tid; e < U * K * T; e += kThreads) {
+    const int nout = U * K * T;
+    // few outputs (K = 1..2 keywords): split the channel sum over PARTS threads per output and combine through the
+    // slab tail, so that all eight waves work instead of the first three
+    const int PARTS = (staged && nout * 4 <= kThreads && K * (C + 1) + 4 * nout <= G::S_FLOATS) ? 4
+                    : (staged && nout * 2 <= kThreads && K * (C + 1) + 2 * nout <= G::S_FLOATS) ? 2 : 1;
+    float* part = slab + K * (C + 1);
+    for (int e0 = tid; e0 < nout * PARTS; e0 += kThreads) {
+      const int e = e0 % nout, ps = e0 / nout;
       const int t = e % T;
       const int uk = e / T;
       const int u = uk / K, k = uk - u * K;
-      if (b0 + u >= A.B) continue;
+      const int c0 = ps * (C / PARTS), c1 = c0 + C / PARTS;
       const float* hc = hbuf + u * C * SS + t;
       const float* wk = wsrc + k * C;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 4
-      for (int c = 0; c < C; c += 4) {
+      for (int c = c0; c < c1; c += 4) {
         const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
         s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
         s1 = fmaf(w4.y, hc[(c + 1) * SS], s1);
         s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
         s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
       }
-      float v = (s0 + s1) + (s2 + s3) + bsrc[k];
-      if (P.sigmoid) v = sigmoidf_(v);
-      A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
+      const float sum = (s0 + s1) + (s2 + s3);
+      if (PARTS > 1) {
+        part[ps * nout + e] = sum;
+      } else if (b0 + u < A.B) {
+        float v = sum + bsrc[k];
+        if (P.sigmoid) v = sigmoidf_(v);
+        A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
+      }
+    }
+    if (PARTS > 1) {
+      __syncthreads();
+      for (int e = tid; e < nout; e += kThreads) {
+        const int t = e % T;
+        const int uk = e / T;
+        const int u = uk / K, k = uk - u * K;
+        if (b0 + u >= A.B) continue;
+        float v = bsrc[k];
+        for (int ps = 0; ps < PARTS; ++ps) v += part[ps * nout + e];
+        if (P.sigmoid) v = sigmoidf_(v);
+        A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
+      }
     }
   } else if (P.head == HEAD_IDENTITY) {
     for (int e = tid; e < U * T * C; e += kThreads) {

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   constexpr int RP = (U * KC) / (kThreads / 16);           // slab rows per 16-lane group per chunk
   static_assert(RP * (kThreads / 16) == U * KC && RP >= 1, "producer decomposition");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const hbuf = lds;                                 // [U][C][SS] f32 resident activations
-  char* const slab = reinterpret_cast<char*>(lds + G::H_FLOATS);
+  // the operand slab sits BELOW the activation tile so that a (slightly) negative frame index on channel row 0
+  // still addresses valid LDS: left-context reads need no index clamp, only the select
+  char* const slab = reinterpret_cast<char*>(lds);
+  float* const hbuf = lds + G::S_FLOATS;                   // [U][C][SS] f32 resident activations
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
       const int steps = min(NBUF, nk - k0);
       __syncthreads();
       // item = (utterance, step, k-octet, frame): 8 consecutive features of one frame -> one 16-byte hi + lo store
-      for (int e = tid; e < U * steps * 4 * TT; e += kThreads) {
+      for (int e = tid; e < ((WEKWS_ABLATE == 5 || WEKWS_ABLATE == 9) ? 0 : U * steps * 4 * TT); e += kThreads) {
         const int t = e % TT;
         int q = e / TT;
         const int oct = q & 3; q >>= 2;
@@ -187,9 +189,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         for (int i = 0; i < RP; ++i) {
           const int item = pg + i * (kThreads / 16);
           const int c = n * KC + (item % KC);
+          constexpr int DWP = (KS + 1 + 3) / 4 * 4;
+          const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + c * DWP);
 #pragma unroll
-          for (int j = 0; j < KS; ++j) dww[i][j] = W[bd.dw_w + c * KS + j];
-          dww[i][KS] = W[bd.dw_b + c];
+          for (int q = 0; q < DWP / 4; ++q) {
+            const float4 w4 = src[q];
+            if (q * 4 + 0 <= KS) dww[i][q * 4 + 0] = w4.x;
+            if (q * 4 + 1 <= KS) dww[i][q * 4 + 1] = w4.y;
+            if (q * 4 + 2 <= KS) dww[i][q * 4 + 2] = w4.z;
+            if (q * 4 + 3 <= KS) dww[i][q * 4 + 3] = w4.w;
+          }
         }
       }
     };
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #define fetch(idx_)                                                                      \
   ({                                                                                     \
     const int ix_ = (idx_);                                                              \
-    float fv_ = hbuf[hoff + max(ix_, 0)];                                                \
+    float fv_ = hbuf[hoff + ix_];                                                        \
     if constexpr (HAS_CACHE) {                                                           \
       const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
       fv_ = ix_ >= 0 ? fv_ : (uok ? fg_ : 0.f);                                          \
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #pragma unroll
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
-            const float v = (t < T) ? fetch(t - sh) : 0.f;
+            const float v = fetch(t - sh);
             _Float16 h, l;
             split16(v, h, l);
             ph[t * 8] = h;
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
           const int c = n * KC + r;
           const int hoff = (u * C + c) * SS;
           const int64_t gbase = (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
-          if (A.out_cache && uok) {
+          if (A.out_cache && uok && !(WEKWS_ABLATE == 6 || WEKWS_ABLATE == 9)) {
             for (int p = tl; p < pad; p += 16) {
               const int src = T + p - pad;
               float cv = hbuf[hoff + max(src, 0)];
@@ -288,7 +297,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
               for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], v[m + j], o);
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
               const int t = fbase + m * d;
-              o = (t < T) ? o : 0.f;
               _Float16 h, l;
               split16(o, h, l);
               ph[t * 8] = h;
@@ -302,7 +310,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #pragma unroll
               for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], fetch(t - (KS - 1 - j) * d), o);
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
-              o = (t < T) ? o : 0.f;
               _Float16 h, l;
               split16(o, h, l);
               ph[t * 8] = h;
@@ -320,23 +327,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     };
 
     // ---- GEMM 1 over K: one MFMA K step per chunk, double-buffered planes, one barrier per chunk
+    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
+    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
     zero_acc(acc);
     produce(0, 0);
     load_dw(min(1, nch - 1));
     __syncthreads();
     if constexpr (NBUF == 2) {
       for (int n = 0; n < nch; n += 2) {
-        produce(n + 1, 1);
+        if (kProduce) produce(n + 1, 1);
         load_a16<OW>(a1, ap1 + (n + 1) * 128, ot_stride1);
         load_dw(min(n + 2, nch - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
+        if (kMfma) mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
         __syncthreads();
-        if (n + 2 < nch) produce(n + 2, 0);
+        if (kProduce && n + 2 < nch) produce(n + 2, 0);
         load_a16<OW>(a0, ap1 + min(n + 2, nch - 1) * 128, ot_stride1);
         load_dw(min(n + 3, nch - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mfma16_step<OW, NT>(acc, a1, slab_u + 2 * PB + frag_off, slab_u + 3 * PB + frag_off);
+        if (kMfma) mfma16_step<OW, NT>(acc, a1, slab_u + 2 * PB + frag_off, slab_u + 3 * PB + frag_off);
         __syncthreads();
       }
     } else {
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 
     // ---- epilogue: bias (+ReLU) + residual, in place into h
 #pragma unroll
-    for (int ow = 0; ow < OW; ++ow) {
+    for (int ow = 0; ow < ((WEKWS_ABLATE == 8 || WEKWS_ABLATE == 9) ? 0 : OW); ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
       const float4 bias = ebias[ow];
 #pragma unroll

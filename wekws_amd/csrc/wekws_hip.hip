@@ -266,8 +266,17 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
         p += C;
       } else {
         b.dw_w = img.put(p, size_t(C) * ks);
+        b.dw_b = img.put(p + size_t(C) * ks, C);
+        {  // taps + bias of a channel side by side, padded to whole float4s (one or three 16-byte loads per row)
+          const int dwp = round_up(ks + 1, 4);
+          std::vector<float> pk(size_t(C) * dwp, 0.f);
+          for (int c = 0; c < C; ++c) {
+            for (int j = 0; j < ks; ++j) pk[size_t(c) * dwp + j] = p[size_t(c) * ks + j];
+            pk[size_t(c) * dwp + ks] = p[size_t(C) * ks + c];
+          }
+          b.dw_pk = img.put(pk.data(), pk.size());
+        }
         p += size_t(C) * ks;
-        b.dw_b = img.put(p, C);
         p += C;
         b.a1 = img.put_packed_a(p, C, C, C);
         b.a1_16 = img.put_packed_a16(p, C, C, C);

@@ -1,0 +1,83 @@
+#include "kws/keyword_spotting.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "utils/check.h"
+
+namespace wekws {
+
+namespace {
+void ReadPackedModel(const std::string& path, wekws_hip_desc* desc, std::vector<float>* blob) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  WEKWS_CHECK(f != nullptr) << "cannot open " << path;
+  char magic[8];
+  uint64_t n = 0;
+  static_assert(sizeof(wekws_hip_desc) == 64, "descriptor is 16 x int32");
+  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "WEKWSHIP", 8) == 0 &&
+            std::fread(desc, sizeof(*desc), 1, f) == 1 && std::fread(&n, sizeof(n), 1, f) == 1;
+  WEKWS_CHECK(ok) << path << " is not a packed wekws_hip model";
+  blob->resize(n);
+  WEKWS_CHECK(std::fread(blob->data(), sizeof(float), n, f) == n) << path << " is truncated";
+  std::fclose(f);
+}
+}  // namespace
+
+KeywordSpotting::KeywordSpotting(const std::string& model_path) {
+  wekws_hip_desc desc;
+  std::vector<float> blob;
+  ReadPackedModel(model_path, &desc, &blob);
+  WEKWS_CHECK(wekws_hip_create(&desc, blob.data(), blob.size(), /*device=*/0, &model_) == WEKWS_HIP_OK)
+      << wekws_hip_last_error();
+  WEKWS_CHECK(desc.head == WEKWS_HIP_HEAD_LINEAR || desc.head == WEKWS_HIP_HEAD_IDENTITY)
+      << "the streaming runtime needs a per-frame head";
+  idim_ = desc.idim;
+  odim_ = desc.odim;
+  const size_t ce = wekws_hip_cache_elems(model_, 1);  // cache_dim * cache_len (keyword_spotting.cc:33-40)
+  for (float*& c : d_cache_) WEKWS_CHECK(hipMalloc(reinterpret_cast<void**>(&c), ce * sizeof(float)) == hipSuccess);
+}
+
+KeywordSpotting::~KeywordSpotting() {
+  if (d_x_) (void)hipFree(d_x_);
+  if (d_y_) (void)hipFree(d_y_);
+  for (float* c : d_cache_) if (c) (void)hipFree(c);
+  wekws_hip_destroy(model_);
+}
+
+void KeywordSpotting::Reset() { have_cache_ = false; }
+
+void KeywordSpotting::EnsureCapacity(int frames) {
+  if (frames <= cap_frames_) return;
+  if (d_x_) (void)hipFree(d_x_);
+  if (d_y_) (void)hipFree(d_y_);
+  WEKWS_CHECK(hipMalloc(reinterpret_cast<void**>(&d_x_), size_t(frames) * idim_ * sizeof(float)) == hipSuccess);
+  WEKWS_CHECK(hipMalloc(reinterpret_cast<void**>(&d_y_), size_t(frames) * odim_ * sizeof(float)) == hipSuccess);
+  cap_frames_ = frames;
+}
+
+void KeywordSpotting::Forward(const std::vector<std::vector<float>>& feats, std::vector<std::vector<float>>* prob) {
+  prob->clear();
+  if (feats.empty()) return;  // keyword_spotting.cc:59
+  const int T = static_cast<int>(feats.size());
+  EnsureCapacity(T);
+  h_x_.resize(size_t(T) * idim_);
+  for (int t = 0; t < T; ++t) {  // keyword_spotting.cc:63-68: (1, T, dim) row-major
+    WEKWS_CHECK(static_cast<int>(feats[t].size()) == idim_) << "frame " << t << " has " << feats[t].size() << " dims";
+    std::memcpy(h_x_.data() + size_t(t) * idim_, feats[t].data(), idim_ * sizeof(float));
+  }
+  WEKWS_CHECK(hipMemcpyAsync(d_x_, h_x_.data(), h_x_.size() * sizeof(float), hipMemcpyHostToDevice, nullptr) == hipSuccess);
+  WEKWS_CHECK(wekws_hip_forward(model_, d_x_, /*B=*/1, T, have_cache_ ? d_cache_[cur_] : nullptr, d_y_,
+                                d_cache_[cur_ ^ 1], /*softmax=*/0, /*stream=*/nullptr) == WEKWS_HIP_OK)
+      << wekws_hip_last_error();
+  cur_ ^= 1;  // keyword_spotting.cc:82: r_cache becomes the next call's cache
+  have_cache_ = true;
+  h_y_.resize(size_t(T) * odim_);
+  WEKWS_CHECK(hipMemcpy(h_y_.data(), d_y_, h_y_.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+  prob->resize(T);  // keyword_spotting.cc:89-94
+  for (int t = 0; t < T; ++t) (*prob)[t].assign(h_y_.begin() + size_t(t) * odim_, h_y_.begin() + size_t(t + 1) * odim_);
+}
+
+}  // namespace wekws

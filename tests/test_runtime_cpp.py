@@ -1,0 +1,66 @@
+"""C++ runtime over the C ABI (runtime/: wekws::KeywordSpotting, wenet::FeaturePipeline, kws_main).
+CPU: it builds and rejects a wrong command line like the reference's kws_main.  GPU: wav file -> kws_main ->
+per-frame probabilities must match  oracle fbank (C port of the reference front-end) -> oracle streaming forward
+with the same chunking, i.e. the same numbers the reference runtime would print for this model and audio."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import fbank_oracle, kws_oracle
+from wekws_amd import pack
+from wekws_amd.utils import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KWS_MAIN = os.path.join(ROOT, "runtime", "build", "kws_main")
+
+
+def build_runtime():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "runtime")], check=True, capture_output=True)
+    assert os.path.exists(KWS_MAIN)
+
+
+def write_wav(path, pcm_int16, rate=16000):
+    data = np.asarray(pcm_int16, dtype="<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+def test_builds_and_rejects_bad_usage():
+    build_runtime()
+    r = subprocess.run([KWS_MAIN, "40"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage: kws_main fbank_dim(int) batch_size(int)" in r.stderr
+    r = subprocess.run([KWS_MAIN, "40", "80", "/nonexistent/model", "/nonexistent.wav"], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot read" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,chunk", [("ds_tcn_h64", 80), ("mdtc_small", 33), ("ds_tcn_h256", 10), ("gru_2x128", 25)])
+def test_kws_main_matches_oracle(tmp_path, name, chunk):
+    build_runtime()
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    desc, blob = pack.pack(cfg, sd)
+    model = str(tmp_path / "model.wekwship")
+    pack.save_packed(model, desc, blob)
+    pcm = (synth.synth_pcm(1, 40000, seed=11, kind="noise")[0] * 0.5 + synth.synth_pcm(1, 40000, kind="sine")[0])
+    pcm = np.clip(np.round(pcm), -32768, 32767).astype(np.int16)
+    wav = str(tmp_path / "t.wav")
+    write_wav(wav, pcm)
+    r = subprocess.run([KWS_MAIN, "40", str(chunk), model, wav], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert all(w[0] == "frame" and w[2] == "prob" for w in rows)
+    assert [int(w[1]) for w in rows] == list(range(len(rows)))  # reference numbering: offset + i
+    got = np.array([[float(v) for v in w[3:]] for w in rows], np.float32)
+
+    feats = fbank_oracle.fbank(pcm.astype(np.float32), 40)
+    T = feats.shape[0]
+    chunks = [chunk] * (T // chunk) + ([T % chunk] if T % chunk else [])
+    ref, _ = kws_oracle.forward_streaming(cfg, sd, feats[None], chunks, None)
+    assert got.shape == ref[0].shape == (T, cfg["output_dim"])
+    assert float(np.abs(got - ref[0]).max()) <= 1e-4

@@ -72,7 +72,7 @@ enum wekws_hip_activation {
 /* How the 1x1 / dense convolutions and Linear layers of the conv backbones are multiplied.  Both modes read and
  * write float32 and accumulate in float32; both meet the 1e-4 posterior bar against the reference. */
 enum wekws_hip_precision {
-  WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 for conv backbones, F32 for GRU */
+  WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 */
   WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32 math */
   WEKWS_HIP_PRECISION_F16X3 = 2    /* operands split into fp16 hi + lo, three fp16 matrix products per term (fp32-level
                                       accuracy, ~5x the matrix rate); needs |activation| < 65504 */

@@ -17,6 +17,7 @@
 #include "conv_stack_f16.hip.h"
 #include "fbank.hip.h"
 #include "gru.hip.h"
+#include "gru_f16.hip.h"
 
 namespace {
 
@@ -167,6 +168,7 @@ struct wekws_hip_model {
   wekws::BlockDesc* d_blocks = nullptr;
   wekws::StackParams sp{};
   wekws::GruParams gp{};
+  wekws::GruF16Params gq{};
   int cache_len = 0;
   Workspace ws;
   std::mutex ws_mu;
@@ -326,11 +328,16 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       const float* bhh = p; p += 3 * C;
       gp.layer[l].a_ih = img.put_packed_a(wih, 3 * C, C, C);
       gp.layer[l].a_hh = img.put_packed_a(whh, 3 * C, C, C);
+      m->gq.a_ih16[l] = img.put_packed_a16(wih, 3 * C, C, C);
+      m->gq.a_hh16[l] = img.put_packed_a16(whh, 3 * C, C, C);
       gp.layer[l].b_ih = img.put(bih, 3 * C);
       gp.layer[l].b_hh = img.put(bhh, 3 * C);
     }
+    m->gq.head_a16 = img.put_packed_a16(p, K, C, C);
     gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
     gp.head_b = img.put(p, K); p += K;
+    m->gq.kpre16 = round_up(d.idim, 32);
+    m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim);
     m->cache_len = 0;
   }
   if (size_t(p - blob) != n_elems) {
@@ -357,6 +364,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   sp.w = m->d_w;
   sp.blocks = m->d_blocks;
   m->gp.w = m->d_w;
+  m->gq.base = m->gp;
   *out = m;
   return WEKWS_HIP_OK;
 }
@@ -397,7 +405,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   const bool per_frame = d.head == WEKWS_HIP_HEAD_LINEAR || d.head == WEKWS_HIP_HEAD_IDENTITY;
 
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    const int rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
+    const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && d.odim <= 128;
+    const int rc = f16 ? wekws::launch_gru_f16(m->gq, x, B, T, in_cache, y, out_cache, stream)
+                       : wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
   } else {
     const int TILE = WEKWS_HIP_TILE_FRAMES;

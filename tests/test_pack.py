@@ -87,3 +87,25 @@ def test_packed_model_file_roundtrip(tmp_path):
         f.write(b"XXXX")
     with pytest.raises(ValueError):
         pack.load_packed(p)
+
+
+def test_export_packed_cli_from_reference_style_artifacts(tmp_path):
+    """config.yaml (train.py:150-153 layout) + state_dict .pt (checkpoint.py:39-57) -> packed file == direct pack."""
+    import yaml
+    from wekws_amd.bin import export_packed
+    from wekws_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"], cmvn=dict(cmvn_file=str(tmp_path / "not_here_global_cmvn"), norm_var=True))
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 21)
+    assert "global_cmvn.mean" in sd
+    m = init_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    save_checkpoint(m, str(tmp_path / "avg.pt"), dict(epoch=3, lr=1e-3, cv_loss=0.5))
+    (tmp_path / "config.yaml").write_text(yaml.dump(dict(model=cfg, dataset_conf={})))
+    m2 = init_model(cfg)
+    assert load_checkpoint(m2, str(tmp_path / "avg.pt")) == dict(epoch=3, lr=1e-3, cv_loss=0.5)
+    out = str(tmp_path / "m.wekwship")
+    export_packed.main(["--config", str(tmp_path / "config.yaml"), "--checkpoint", str(tmp_path / "avg.pt"),
+                        "--output", out, "--precision", "f32"])
+    desc, blob = pack.load_packed(out)
+    want_desc, want_blob = pack.pack(dict(cfg, _precision="f32"), sd)
+    assert desc == want_desc and desc["precision"] == 1 and np.array_equal(blob, want_blob)

@@ -210,8 +210,12 @@ def init_model(configs: Mapping) -> KWSModel:
     cmvn = configs.get("cmvn", {}) or {}
     if cmvn.get("cmvn_file"):
         from wekws_amd.utils.cmvn import load_cmvn, load_kaldi_cmvn
-        loader = load_kaldi_cmvn if "kaldi" in cmvn["cmvn_file"] else load_cmvn
-        mean, istd = loader(cmvn["cmvn_file"])
-        model.global_cmvn.mean.copy_(torch.from_numpy(mean).float())
-        model.global_cmvn.istd.copy_(torch.from_numpy(istd).float())
+        import os
+        if os.path.exists(cmvn["cmvn_file"]):
+            loader = load_kaldi_cmvn if "kaldi" in cmvn["cmvn_file"] else load_cmvn
+            mean, istd = loader(cmvn["cmvn_file"])
+            model.global_cmvn.mean.copy_(torch.from_numpy(mean).float())
+            model.global_cmvn.istd.copy_(torch.from_numpy(istd).float())
+        # else: the statistics file recorded in config.yaml is not on this machine (the reference would raise here);
+        # the global_cmvn.mean / .istd buffers are still created and a checkpoint's state_dict fills them
     return model

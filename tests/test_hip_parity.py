@@ -174,3 +174,43 @@ def test_weight_update_repacks():
     y2, _ = run(model, x)
     r2, _ = kws_oracle.forward(cfg, sd2, x, None)
     assert max_abs(y2, r2) <= POSTERIOR_TOL and max_abs(y1, y2) > 1e-3
+
+
+def test_large_vocabulary_head_matches_oracle():
+    """CTC-style heads (reference ds_tcn_ctc.yaml: thousands of tokens) do not fit the LDS-staged classifier path;
+    the fallback that streams the classifier rows from global memory must give the same numbers."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64_ctc20"], output_dim=700)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 3)
+    model = build(cfg, sd)
+    x = synth.synth_feats(3, 45, 40, seed=2)
+    y, _ = run(model, x)
+    ry, _ = kws_oracle.forward(cfg, sd, x, None)
+    assert y.shape == (3, 45, 700) and max_abs(y, ry) <= tol_for(ry)
+    ys, _ = run(model, x, softmax=True)
+    rs, _ = kws_oracle.forward(cfg, sd, x, None, softmax=True)
+    assert max_abs(ys, rs) <= POSTERIOR_TOL
+
+
+def test_concurrent_streams_and_models():
+    """Two models on two HIP streams at once (the library keeps no hidden global state besides the per-model
+    workspace): results equal the serial ones bit for bit."""
+    from wekws_amd import pack
+    ms, xs, serial = [], [], []
+    for name, seed in (("ds_tcn_h256", 1), ("mdtc_h64", 2)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), seed))
+        x = torch.from_numpy(synth.synth_feats(64, 98, 40, seed=seed)).cuda()
+        ms.append(m); xs.append(x)
+        serial.append(m(x)[0].clone())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(4):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(ms[i](xs[i])[0])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for y in outs[i]:
+            assert torch.equal(y, serial[i])

@@ -13,6 +13,6 @@ for v in ${ABLATE_SET:-0 1 2 3 4}; do
     wait
     # tcn / mdtc launchers are not needed for the DS-TCN bench but the library must link: reuse the product objects
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ablate/lib$v.so $d/wekws_hip.o $d/conv_stack_ds.o $d/conv_stack_f16_ds.o \
-        wekws_amd/lib/obj/conv_stack_tcn.o wekws_amd/lib/obj/conv_stack_mdtc.o wekws_amd/lib/obj/conv_stack_f16_tcn.o wekws_amd/lib/obj/conv_stack_f16_mdtc.o
+        wekws_amd/lib/obj/conv_stack_tcn.o wekws_amd/lib/obj/conv_stack_mdtc.o wekws_amd/lib/obj/conv_stack_f16_tcn.o wekws_amd/lib/obj/conv_stack_f16_mdtc.o wekws_amd/lib/obj/dense_stack_f16_tcn.o
   fi
 done

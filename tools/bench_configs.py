@@ -26,7 +26,9 @@ def build(name):
     return cfg, m.cuda().eval()
 
 
-def timeit(fn, warm=5, reps=30):
+def timeit(fn, warm=5, reps=30, group=10):
+    """Throughput timing: `group` back-to-back launches between two events (the stream never drains, so host launch
+    overhead is hidden as in bench.py), repeated `reps` times; returns median / p10 / p90 of the per-launch time."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -34,10 +36,11 @@ def timeit(fn, warm=5, reps=30):
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(group):
+            fn()
         b.record()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
+        ts.append(a.elapsed_time(b) / group)
     return float(np.median(ts)), float(np.percentile(ts, 10)), float(np.percentile(ts, 90))
 
 
@@ -48,7 +51,7 @@ def main():
                     ("gru_2x128", 256), ("gru_2x128", 1024), ("gru_2x128", 16384)):
         cfg, m = build(name)
         x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=1)).cuda()
-        med, p10, p90 = timeit(lambda: m(x), reps=20 if B <= 1024 else 8)
+        med, p10, p90 = timeit(lambda: m(x), reps=10 if B <= 1024 else 4, group=10 if B <= 1024 else 4)
         out.append(dict(kind="batch", model=name, B=B, T=98, ms=round(med, 4), p10=round(p10, 4), p90=round(p90, 4),
                         utts_per_s=round(B / med * 1e3, 1)))
         print(json.dumps(out[-1]), flush=True)

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -15,6 +16,7 @@
 
 #include "conv_stack.hip.h"
 #include "conv_stack_f16.hip.h"
+#include "dense_stack_f16.hip.h"
 #include "fbank.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
@@ -166,7 +168,10 @@ struct wekws_hip_model {
   int device = 0;
   float* d_w = nullptr;
   wekws::BlockDesc* d_blocks = nullptr;
+  wekws::DenseBlock* d_dblocks = nullptr;
   wekws::StackParams sp{};
+  wekws::DenseParams dp{};
+  bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
   wekws::GruF16Params gq{};
   int cache_len = 0;
@@ -229,6 +234,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   const float* p = blob;
   wekws::StackParams& sp = m->sp;
   std::vector<wekws::BlockDesc> blocks;
+  std::vector<wekws::DenseBlock> dblocks;
 
   // ---- preprocessing
   const uint32_t pre_a = img.put_packed_a(p, C, d.idim, d.idim);
@@ -260,11 +266,21 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       b.pad = (ks - 1) * b.dil;
       b.cache_off = off;
       off += b.pad;
+      wekws::DenseBlock db{};
+      db.dil = b.dil; db.pad = b.pad; db.cache_off = b.cache_off; db.zadd = b.zadd;
       if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
         b.a1 = img.put_packed_a(p, C, C * ks, C * ks);
         b.a1_16 = img.put_packed_a16(p, C, C * ks, C * ks);
+        {  // dense-stack kernel: K reordered to (tap, channel)
+          std::vector<float> mw(size_t(C) * C * ks);
+          for (int o = 0; o < C; ++o)
+            for (int c = 0; c < C; ++c)
+              for (int j = 0; j < ks; ++j) mw[(size_t(o) * ks + j) * C + c] = p[(size_t(o) * C + c) * ks + j];
+          db.a1 = img.put_packed_a16(mw.data(), C, C * ks, C * ks);
+        }
         p += size_t(C) * C * ks;
         b.b1 = img.put(p, C);
+        db.b1 = b.b1;
         p += C;
       } else {
         b.dw_w = img.put(p, size_t(C) * ks);
@@ -294,6 +310,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
         }
       }
       blocks.push_back(b);
+      dblocks.push_back(db);
     }
     m->cache_len = off;
     sp.cache_len = off;
@@ -301,7 +318,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     sp.head = d.head;
     sp.head_hidden = d.head_hidden;
     sp.sigmoid = d.activation == WEKWS_HIP_ACT_SIGMOID;
+    wekws::DenseParams& dp = m->dp;
     if (d.head == WEKWS_HIP_HEAD_LINEAR) {
+      dp.head_a16 = img.put_packed_a16(p, K, C, C);
       sp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
       sp.head_b = img.put(p, K); p += K;
     } else if (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST) {
@@ -311,6 +330,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       sp.head_w2 = img.put(p, size_t(K) * HH); p += size_t(K) * HH;
       sp.head_b2 = img.put(p, K); p += K;
     }
+    // dense-stack kernel parameters (plain TCN): same scalars, its own block table
+    dp.nblocks = nb; dp.idim = d.idim; dp.kpre16 = sp.kpre16; dp.ksize = ks; dp.odim = K; dp.pre_relu = d.preproc_relu;
+    dp.pre_a16 = sp.pre_a16; dp.pre_b = sp.pre_b; dp.head = d.head; dp.head_hidden = d.head_hidden; dp.sigmoid = sp.sigmoid;
+    dp.head_w = sp.head_w; dp.head_b = sp.head_b; dp.head_w2 = sp.head_w2; dp.head_b2 = sp.head_b2; dp.cache_len = off;
+    int max_pad = 0;
+    for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
+    m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
   } else {
     wekws::GruParams& gp = m->gp;
     gp.idim = d.idim;
@@ -348,6 +374,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   auto cleanup = [&]() {
     if (m->d_w) (void)hipFree(m->d_w);
     if (m->d_blocks) (void)hipFree(m->d_blocks);
+    if (m->d_dblocks) (void)hipFree(m->d_dblocks);
     delete m;
   };
   hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
@@ -356,6 +383,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     e = hipMalloc(&m->d_blocks, blocks.size() * sizeof(wekws::BlockDesc));
     if (e == hipSuccess)
       e = hipMemcpy(m->d_blocks, blocks.data(), blocks.size() * sizeof(wekws::BlockDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&m->d_dblocks, dblocks.size() * sizeof(wekws::DenseBlock));
+    if (e == hipSuccess)
+      e = hipMemcpy(m->d_dblocks, dblocks.data(), dblocks.size() * sizeof(wekws::DenseBlock), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     cleanup();
@@ -363,6 +393,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   }
   sp.w = m->d_w;
   sp.blocks = m->d_blocks;
+  m->dp.w = m->d_w;
+  m->dp.blocks = m->d_dblocks;
   m->gp.w = m->d_w;
   m->gq.base = m->gp;
   *out = m;
@@ -374,6 +406,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   (void)hipSetDevice(m->device);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
+  if (m->d_dblocks) (void)hipFree(m->d_dblocks);
   for (float* c : m->ws.cache) if (c) (void)hipFree(c);
   if (m->ws.gsum) (void)hipFree(m->ws.gsum);
   delete m;
@@ -467,8 +500,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                    : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;
         case WEKWS_HIP_BACKBONE_TCN:
-          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
-                   : wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
+          rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
+               : m->dense_ok ? wekws::launch_dense_stack_f16<wekws::KIND_TCN>(C, nt, m->dp, a, stream)
+                             : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
           rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

@@ -188,7 +188,7 @@ __device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q
 // ---------------------------------------------------------------------------------------------
 // Classifier head on the resident tile (shared by the f32 and the split-fp16 kernels).  `slab` is free scratch.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int C, int NT>
+template <int KIND, int C, int NT, int NTHR = kThreads>
 __device__ __forceinline__ void conv_stack_head(const StackParams& P, const CallArgs& A, float* hbuf, float* slab, int b0) {
   using G = Geom<KIND, C, NT>;
   constexpr int U = G::U, SS = G::SS;
@@ -202,8 +202,8 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
     const bool staged = K * (C + 1) <= G::S_FLOATS;
     if (staged) {
-      for (int e = tid; e < K * C; e += kThreads) slab[e] = W[P.head_w + e];
-      for (int e = tid; e < K; e += kThreads) slab[K * C + e] = W[P.head_b + e];
+      for (int e = tid; e < K * C; e += NTHR) slab[e] = W[P.head_w + e];
+      for (int e = tid; e < K; e += NTHR) slab[K * C + e] = W[P.head_b + e];
       __syncthreads();
     }
     const float* wsrc = staged ? slab : W + P.head_w;
@@ -211,10 +211,10 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     const int nout = U * K * T;
     // few outputs (K = 1..2 keywords): split the channel sum over PARTS threads per output and combine through the
     // slab tail, so that all eight waves work instead of the first three
-    const int PARTS = (staged && nout * 4 <= kThreads && K * (C + 1) + 4 * nout <= G::S_FLOATS) ? 4
-                    : (staged && nout * 2 <= kThreads && K * (C + 1) + 2 * nout <= G::S_FLOATS) ? 2 : 1;
+    const int PARTS = (staged && nout * 4 <= NTHR && K * (C + 1) + 4 * nout <= G::S_FLOATS) ? 4
+                    : (staged && nout * 2 <= NTHR && K * (C + 1) + 2 * nout <= G::S_FLOATS) ? 2 : 1;
     float* part = slab + K * (C + 1);
-    for (int e0 = tid; e0 < nout * PARTS; e0 += kThreads) {
+    for (int e0 = tid; e0 < nout * PARTS; e0 += NTHR) {
       const int e = e0 % nout, ps = e0 / nout;
       const int t = e % T;
       const int uk = e / T;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     }
     if (PARTS > 1) {
       __syncthreads();
-      for (int e = tid; e < nout; e += kThreads) {
+      for (int e = tid; e < nout; e += NTHR) {
         const int t = e % T;
         const int uk = e / T;
         const int u = uk / K, k = uk - u * K;
@@ -254,7 +254,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
       }
     }
   } else if (P.head == HEAD_IDENTITY) {
-    for (int e = tid; e < U * T * C; e += kThreads) {
+    for (int e = tid; e < U * T * C; e += NTHR) {
       const int c = e % C;
       const int ut = e / C;
       const int u = ut / T, t = ut - u * T;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     float* mvec = slab;                 // [U][C]
     float* hid = slab + U * C;          // [U][head_hidden]
     const int HH = P.head_hidden;
-    for (int e = tid; e < U * C; e += kThreads) {
+    for (int e = tid; e < U * C; e += NTHR) {
       const int u = e / C, c = e - u * C;
       const float* hc = hbuf + (u * C + c) * SS;
       float s;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     }
     __syncthreads();
     if (A.last_tile) {
-      for (int e = tid; e < U * HH; e += kThreads) {
+      for (int e = tid; e < U * HH; e += NTHR) {
         const int u = e / HH, j = e - u * HH;
         const float* w1 = W + P.head_w + j * C;
         float s = W[P.head_b + j];
@@ -296,7 +296,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
         hid[e] = fmaxf(s, 0.f);
       }
       __syncthreads();
-      for (int e = tid; e < U * K; e += kThreads) {
+      for (int e = tid; e < U * K; e += NTHR) {
         const int u = e / K, k = e - u * K;
         if (b0 + u >= A.B) continue;
         const float* w2 = W + P.head_w2 + k * HH;

@@ -177,8 +177,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = P.blocks[bi];
     const int d = bd.dil, pad = bd.pad;
-    const int K1 = (KIND == KIND_TCN) ? C * KS : C;
-    const int nch = K1 / KC;
+    constexpr int K1 = (KIND == KIND_TCN) ? C * KS : C;
+    constexpr int nch = K1 / KC;
+    static_assert(NBUF == 1 ? nch == 1 : nch % 2 == 0, "chunk pipeline shape");
     const int ot_stride1 = nch * 128;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + (wo * OW) * ot_stride1 + lane;
 
@@ -443,6 +444,9 @@ inline int launch_one_f16(const StackParams& P, const CallArgs& A, hipStream_t s
   using G = Geom<KIND, C, NT>;
   constexpr int KS = (KIND == KIND_MDTC) ? 5 : 8;
   if (P.ksize != KS) return -4;
+  if constexpr (KIND == KIND_TCN && C < 64) {
+    return -4;  // K = 8*C needs a double-buffered slab that does not fit Geom<> at C = 32; served by dense_stack_f16
+  } else {
   static bool attr_set = false;
   auto kern = conv_stack_f16_kernel<KIND, C, NT, KS>;
   if (!attr_set) {
@@ -454,6 +458,7 @@ inline int launch_one_f16(const StackParams& P, const CallArgs& A, hipStream_t s
   const int grid = (A.B + G::U - 1) / G::U;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
 }
 
 #define WEKWS_DISPATCH_NT_F16(KIND, CC)                                        \

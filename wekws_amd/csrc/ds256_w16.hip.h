@@ -1,0 +1,267 @@
+// DS-TCN, hidden_dim 256 (the reference's hi_xiaowen ds_tcn.yaml, the headline model): 16-wave variant of
+// conv_stack_f16_kernel<KIND_DS, 256, NT, 8>.  Same arithmetic (3 x fp16 MFMA on hi/lo-split operands, fp32
+// accumulate), same LDS footprint (f32 tile 256 x SS + 28,672 B of operand planes = 143,360 B at NT = 7, one
+// workgroup per CU), same results -- different occupancy: 1024 threads = 4 waves per SIMD instead of 2.
+//
+// Why: after the move to fp16 matrix products the kernel is bound by vector-instruction ISSUE, not by the matrix pipe
+// (profiles/r01c: MFMA pipe ~25 % busy), and build/probe/valu_rate.hip measures what a SIMD issues per VALU
+// instruction: 5.5 cycles with one wave, 3.0 with two, 1.9 with four.  The LDS tile allows only one workgroup per CU,
+// so the only way to four waves per SIMD is a 16-wave workgroup: each wave owns ONE 16-channel o-tile for all NT
+// frame tiles (28 accumulator registers at NT = 7, the whole kernel fits the 128-VGPR budget of 4 waves/SIMD).
+//
+// K is consumed in intervals of 64 channels = the whole operand slab (two 32-deep K steps), single-buffered:
+//   [all 64 lane-groups produce one row each] barrier [every wave: 2 K steps x 3 products x NT tiles] barrier
+// A double buffer would buy nothing here: a saturated MFMA stream lets one VALU instruction of the co-resident waves
+// through per MFMA (build/probe/mfma_probe.hip), so producer and matrix phases do not overlap on a SIMD anyway.
+#pragma once
+#include "conv_stack_f16.hip.h"
+
+namespace wekws {
+
+// One 32-deep K step for one o-tile, B fragments loaded tile by tile (no double buffer: with four waves per SIMD the
+// LDS latency of a tile is covered by the other waves, and the registers are needed elsewhere).
+template <int NT>
+__device__ __forceinline__ void mfma16_step_nb(f32x4 (&acc)[NT], const F16Frag& a, const char* bh, const char* bl) {
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const f16x8 vh = *reinterpret_cast<const f16x8*>(bh + tt * 256);
+    const f16x8 vl = *reinterpret_cast<const f16x8*>(bl + tt * 256);
+    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
+    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
+    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+  }
+}
+
+constexpr int kW16Threads = 1024;
+constexpr int kW16Waves = 16;
+
+template <int NT>
+struct W16Geom {
+  static constexpr int C = 256;
+  static constexpr int TT = 16 * NT;
+  static constexpr int SS = (NT % 2) ? 16 * NT : 16 * NT + 16;
+  static constexpr int PB = Plane<32, TT>::BYTES;            // one hi (or lo) plane of one 32-channel K step
+  static constexpr int SLAB = 4 * PB;                        // [kstep 0 hi | kstep 0 lo | kstep 1 hi | kstep 1 lo]
+  static constexpr int H_FLOATS = C * SS;
+  static constexpr size_t LDS_BYTES = size_t(SLAB) + size_t(H_FLOATS) * 4;
+};
+
+// HAS_CACHE: left context from the streaming cache in global memory (true) or zeros (false).  A template parameter,
+// not a run-time branch: with both producer variants in one kernel the register allocation exceeds the 128-VGPR
+// budget of four waves per SIMD and spills.
+template <int NT, bool HAS_CACHE>
+__global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParams P, const CallArgs A) {
+  using G = W16Geom<NT>;
+  constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB, KS = 8;
+  extern __shared__ __attribute__((aligned(16))) float w16_lds[];
+  char* const slab = reinterpret_cast<char*>(w16_lds);       // operand planes, below the tile (no index clamp needed)
+  float* const hbuf = w16_lds + G::SLAB / 4;                 // [256][SS] f32 resident activations
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b = blockIdx.x;                                  // one utterance per workgroup
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int pg = tid >> 4, tl = tid & 15;                    // producer: 64 lane-groups x 16 lanes
+  const int o0 = wave * 16 + lq * 4;                         // this lane's 4 output channels (o-tile = wave)
+  const int frag_off = (lq * TT + l15) * 16;
+
+  f32x4 acc[1][NT];
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+    zero_acc(acc);
+    const int nk = P.kpre16 / 32;
+    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
+    const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the slab)
+      const int steps = min(2, nk - k0);
+      __syncthreads();
+      for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, frame)
+        const int t = e % TT;
+        const int q = e / TT;
+        const int oct = q & 3, st = q >> 2;
+        const int kf = (k0 + st) * 32 + oct * 8;
+        const bool ok = t < T;
+        const float* xr = A.x + int64_t(b) * A.xs_b + int64_t(t) * P.idim + kf;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          _Float16 h, l;
+          split16(v, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        char* dst = slab + st * 2 * PB + (oct * TT + t) * 16;
+        *reinterpret_cast<f16x8*>(dst) = vh;
+        *reinterpret_cast<f16x8*>(dst + PB) = vl;
+      }
+      __syncthreads();
+      for (int st = 0; st < steps; ++st) {
+        F16Frag a[1];
+        load_a16<1>(a, ap + (k0 + st) * 128, 0);
+        mfma16_step_nb<NT>(acc[0], a[0], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int t = tt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[0][tt][r] + f4c(bias, r);
+        if (P.pre_relu) v = fmaxf(v, 0.f);
+        hbuf[(o0 + r) * SS + t] = v;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ======================================= residual blocks =======================================
+  constexpr int NIV = C / 64;                                // K intervals per layer
+  constexpr int OTS = (C / 32) * 128;                        // uint4 per o-tile (8 K steps)
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    const BlockDesc bd = P.blocks[bi];
+    const int d = bd.dil, pad = bd.pad;
+    const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
+    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
+    // taps + bias of the row this lane-group produces in the coming interval (padded 12-float record)
+    float dww[KS + 1];
+    auto load_dw = [&](int iv) __attribute__((always_inline)) {
+      const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + (iv * 64 + pg) * 12);
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+      dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w;
+      dww[4] = q1.x; dww[5] = q1.y; dww[6] = q1.z; dww[7] = q1.w;
+      dww[8] = q2.x;
+    };
+    // weight fragments of the two K steps of an interval; each is reloaded with the next interval's right after its
+    // MFMAs have been issued, i.e. a whole producer phase ahead of its next use
+    F16Frag a0[1], a1[1];
+    load_dw(0);
+    load_a16<1>(a0, ap1, 0);
+    load_a16<1>(a1, ap1 + 128, 0);
+
+    const bool slide = d <= 16 && (16 % d) == 0;
+    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+
+    // ---- producer: lane-group pg makes slab row pg of interval iv: depthwise dilated conv + folded BN + ReLU of
+    //      channel iv*64 + pg (tcn.py:102-109), split to fp16 hi/lo, and hands the channel's streaming cache over.
+    auto produce_iv = [&](int iv) __attribute__((always_inline)) {
+      const int r = pg, c = iv * 64 + pg;
+      const int hoff = c * SS;
+      const int64_t gbase = (int64_t(b) * C + c) * Pc + bd.cache_off;
+#define fetch(idx_)                                                                      \
+  ({                                                                                     \
+    const int ix_ = (idx_);                                                              \
+    float fv_ = hbuf[hoff + ix_];                                                        \
+    if constexpr (HAS_CACHE) {                                                           \
+      const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
+      fv_ = ix_ >= 0 ? fv_ : fg_;                                                        \
+    } else {                                                                             \
+      fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
+    }                                                                                    \
+    fv_;                                                                                 \
+  })
+      if (A.out_cache) {
+        for (int p = tl; p < pad; p += 16) {
+          const int src = T + p - pad;   // index into h (negative: still inside the old cache)
+          float cv = hbuf[hoff + max(src, 0)];
+          if constexpr (HAS_CACHE) {
+            const float g = A.in_cache[gbase + pad + min(src, -1)];
+            cv = src >= 0 ? cv : g;
+          } else {
+            cv = src >= 0 ? cv : 0.f;
+          }
+          A.out_cache[gbase + p] = cv;
+        }
+      }
+      // row r -> K step r>>5, k-octet (r&31)>>3, half (r&7) of the [k-octet][frame][8] planes
+      char* const plane = slab + (r >> 5) * 2 * PB;
+      _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((r & 31) >> 3) * TT) * 8 + (r & 7);
+      _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + (((r & 31) >> 3) * TT) * 8 + (r & 7);
+      if (slide) {
+        float v[NT + KS - 1];
+#pragma unroll
+        for (int q = 0; q < NT + KS - 1; ++q) v[q] = fetch(fbase + (q - (KS - 1)) * d);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          float o = dww[KS];
+#pragma unroll
+          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
+          o = fmaxf(o, 0.f);
+          const int t = fbase + m * d;
+          _Float16 h, l;
+          split16(o, h, l);
+          ph[t * 8] = h;
+          pl[t * 8] = l;
+        }
+      } else {
+#pragma unroll 1
+        for (int m = 0; m < NT; ++m) {
+          const int t = tl + 16 * m;
+          float o = dww[KS];
+#pragma unroll
+          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
+          o = fmaxf(o, 0.f);
+          _Float16 h, l;
+          split16(o, h, l);
+          ph[t * 8] = h;
+          pl[t * 8] = l;
+        }
+      }
+#undef fetch
+    };
+    zero_acc(acc);
+#pragma unroll 1
+    for (int iv = 0; iv < NIV; ++iv) {
+      const int nx = min(iv + 1, NIV - 1);                   // clamped: the last interval re-reads itself
+      produce_iv(iv);
+      load_dw(nx);
+      __syncthreads();
+      mfma16_step_nb<NT>(acc[0], a0[0], slab + frag_off, slab + PB + frag_off);
+      load_a16<1>(a0, ap1 + (2 * nx) * 128, 0);
+      mfma16_step_nb<NT>(acc[0], a1[0], slab + 2 * PB + frag_off, slab + 3 * PB + frag_off);
+      load_a16<1>(a1, ap1 + (2 * nx + 1) * 128, 0);
+      __syncthreads();
+    }
+
+    // ---- epilogue: folded bias + ReLU + residual, in place (tcn.py:60: add after the ReLU)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const int t = tt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* hp = hbuf + (o0 + r) * SS + t;
+        *hp = fmaxf(acc[0][tt][r] + f4c(ebias, r), 0.f) + *hp;
+      }
+    }
+    __syncthreads();
+  }
+
+  conv_stack_head<KIND_DS, 256, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
+}
+
+template <int NT, bool HAS_CACHE>
+inline int launch_ds256_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  using G = W16Geom<NT>;
+  static bool attr_set = false;
+  auto kern = ds256_w16_kernel<NT, HAS_CACHE>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(G::LDS_BYTES)) != hipSuccess)
+      return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int NT>
+inline int launch_ds256_w16_nt(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  return A.in_cache ? launch_ds256_w16_ntc<NT, true>(P, A, stream) : launch_ds256_w16_ntc<NT, false>(P, A, stream);
+}
+
+int launch_ds256_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+
+}  // namespace wekws

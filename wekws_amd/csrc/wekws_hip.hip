@@ -17,6 +17,7 @@
 #include "conv_stack.hip.h"
 #include "conv_stack_f16.hip.h"
 #include "dense_stack_f16.hip.h"
+#include "ds256_w16.hip.h"
 #include "fbank.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
@@ -171,6 +172,7 @@ struct wekws_hip_model {
   wekws::DenseBlock* d_dblocks = nullptr;
   wekws::StackParams sp{};
   wekws::DenseParams dp{};
+  bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
   wekws::GruF16Params gq{};
@@ -337,6 +339,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     int max_pad = 0;
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
+    if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
   } else {
     wekws::GruParams& gp = m->gp;
     gp.idim = d.idim;
@@ -496,8 +499,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
-          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream)
-                   : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream);
+          rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+               : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, m->sp, a, stream)   // 16-wave variant
+                                         : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;
         case WEKWS_HIP_BACKBONE_TCN:
           rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream)

@@ -133,12 +133,12 @@ def main():
         ach_tf = launch_flop / (kern_ms * 1e-3) / 1e12 if flop else None
         hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
         f16x3 = args.precision != "f32"
-        kname = ("conv_stack_f16_kernel" if f16x3 else "conv_stack_kernel") + "<KIND_DS, C=256, NT=7, KS=8>"
+        kname = "ds256_w16_kernel<NT=7, HAS_CACHE=false>" if f16x3 else "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>"
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
             # the timed process); ignored unless it was taken on the kernel this run dispatches
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            want = "conv_stack_f16_kernel<0, 256, 7" if f16x3 else "conv_stack_kernel<0, 256, 7"
+            want = "ds256_w16_kernel<7" if f16x3 else "conv_stack_kernel<0, 256, 7"
             if args.model == "ds_tcn_h256" and B == 1024 and want in pm["kernel"]:
                 traffic, traffic_src = pm["traffic_bytes_per_launch"], pm["profile"]
         except Exception:

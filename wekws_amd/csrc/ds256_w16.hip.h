@@ -183,7 +183,11 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
       if (slide) {
         float v[NT + KS - 1];
 #pragma unroll
-        for (int q = 0; q < NT + KS - 1; ++q) v[q] = fetch(fbase + (q - (KS - 1)) * d);
+        for (int q = 0; q < NT + KS - 1; ++q) {
+          // slots q >= KS-1 sit at frame fbase + (q-KS+1)*d >= 0: never left context, plain read, no select
+          if (q >= KS - 1) v[q] = hbuf[hoff + fbase + (q - (KS - 1)) * d];
+          else v[q] = fetch(fbase + (q - (KS - 1)) * d);
+        }
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           float o = dww[KS];

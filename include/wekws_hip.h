@@ -53,7 +53,8 @@ enum wekws_hip_backbone {
   WEKWS_HIP_BACKBONE_DS_TCN = 0, /* type: tcn, ds: true   (wekws/model/tcn.py:91-119)  */
   WEKWS_HIP_BACKBONE_TCN = 1,    /* type: tcn, ds: false  (wekws/model/tcn.py:67-88)   */
   WEKWS_HIP_BACKBONE_MDTC = 2,   /* type: mdtc            (wekws/model/mdtc.py:201-276) */
-  WEKWS_HIP_BACKBONE_GRU = 3     /* type: gru             (wekws/model/kws_model.py:128-133) */
+  WEKWS_HIP_BACKBONE_GRU = 3,    /* type: gru             (wekws/model/kws_model.py:128-133) */
+  WEKWS_HIP_BACKBONE_FSMN = 4    /* type: fsmn            (wekws/model/fsmn.py:394-495) */
 };
 
 /* classifier of the reference config (wekws/model/kws_model.py:175-199) */
@@ -94,6 +95,17 @@ enum wekws_hip_precision {
  *   head LINEAR         Wc[odim][hdim], bc[odim]
  *   head GLOBAL / LAST  W1[head_hidden][hdim], b1[head_hidden], W2[odim][head_hidden], b2[odim]
  *   head IDENTITY       (nothing; odim == hdim)
+ *
+ * FSMN (fsmn.py:394-495; always preprocessing none + identity head, fsmn_ctc.yaml:36-56) has no preprocessing /
+ * head sections; its blob is
+ *   in_linear1 W[aux0][idim], b[aux0]  (CMVN folded) ; in_linear2 W[hdim][aux0], b[hdim]
+ *   per layer  Wproj[proj][hdim] (no bias), taps[proj][lorder + rorder], Waff[hdim][proj], baff[hdim]
+ *              taps = [conv_left taps, +1 on the last (the block's identity path, fsmn.py:236-237) | conv_right taps]
+ *   out_linear1 W[aux1][hdim], b[aux1] ; out_linear2 W[odim][aux1], b[odim]
+ * with the descriptor slots read as: hdim = linear_dim, num_layers = fsmn layers, num_stack = proj_dim,
+ * kernel_size = left_order, stack_size = right_order, aux[0] = input_affine_dim, aux[1] = output_affine_dim.
+ * Memory blocks run with stride 1, as the reference builds them whatever left_stride / right_stride say
+ * (fsmn.py:381-383).  The cache is 4-D: (B, proj_dim, left_order - 1 + right_order, layers), layer index innermost.
  */
 typedef struct wekws_hip_desc {
   int32_t abi_version;  /* WEKWS_HIP_ABI_VERSION */
@@ -101,16 +113,16 @@ typedef struct wekws_hip_desc {
   int32_t idim;         /* input_dim  (feature dim, e.g. 40) */
   int32_t hdim;         /* hidden_dim (channels of the backbone) */
   int32_t odim;         /* output_dim (keywords / classes / tokens) */
-  int32_t num_layers;   /* tcn: num_layers; gru: num_layers; mdtc: unused (0) */
-  int32_t num_stack;    /* mdtc: num_stack, else 0 */
-  int32_t stack_size;   /* mdtc: stack_size, else 0 */
-  int32_t kernel_size;  /* tcn / mdtc conv kernel size, gru: 0 */
+  int32_t num_layers;   /* tcn / gru / fsmn: num_layers; mdtc: unused (0) */
+  int32_t num_stack;    /* mdtc: num_stack; fsmn: proj_dim; else 0 */
+  int32_t stack_size;   /* mdtc: stack_size; fsmn: right_order; else 0 */
+  int32_t kernel_size;  /* tcn / mdtc conv kernel size; fsmn: left_order; gru: 0 */
   int32_t preproc_relu; /* 1: LinearSubsampling1 (Linear+ReLU, subsampling.py:39-61); 0: no ReLU */
   int32_t head;         /* enum wekws_hip_head */
   int32_t head_hidden;  /* GLOBAL / LAST: width of the MLP (64 in kws_model.py:181-186), else 0 */
   int32_t activation;   /* enum wekws_hip_activation */
   int32_t precision;    /* enum wekws_hip_precision */
-  int32_t reserved[2];  /* must be 0 */
+  int32_t aux[2];       /* fsmn: input_affine_dim, output_affine_dim; every other backbone: must be 0 */
 } wekws_hip_desc;
 
 typedef struct wekws_hip_model wekws_hip_model;
@@ -138,7 +150,8 @@ void wekws_hip_destroy(wekws_hip_model* m);
 /* Streaming-cache geometry, as the exporter publishes it in the ONNX metadata
  * (wekws/bin/export_onnx.py:55-77: cache_dim, cache_len).  Conv backbones: cache is
  * (B, cache_dim = hdim, cache_len = sum of paddings); GRU: (num_layers, B, hdim) and
- * cache_len = 0 (the reference cannot export GRU). */
+ * cache_len = 0 (the reference cannot export GRU); FSMN: (B, cache_dim = proj_dim,
+ * cache_len = left_order - 1 + right_order, num_layers) as export_onnx.py:57-60 shapes it. */
 int wekws_hip_cache_dim(const wekws_hip_model* m);
 int wekws_hip_cache_len(const wekws_hip_model* m);
 /* float32 elements of the cache tensor for a batch of B streams */

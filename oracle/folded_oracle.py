@@ -1,7 +1,7 @@
 """numpy evaluator of the FOLDED weight blob (the layout include/wekws_hip.h documents)  --  TEST
 INFRASTRUCTURE, NOT PRODUCT.  It lets the CPU suite check the host packer (BatchNorm / CMVN folding, blob
 order, descriptor) against the unfolded oracle without a GPU: pack() -> this evaluator must reproduce
-oracle/kws_oracle.forward.  Conv backbones + GRU, one-shot (empty cache) only."""
+oracle/kws_oracle.forward.  Conv backbones, GRU and FSMN, one-shot (empty cache) only."""
 import numpy as np
 
 from oracle import kws_oracle as ko
@@ -20,8 +20,31 @@ class _Reader:
         return v
 
 
+def _fsmn(desc, r, x):
+    """FSMN blob (include/wekws_hip.h): the memory block as ONE tap vector per channel (identity path folded in)."""
+    C, I, K = desc["hdim"], desc["idim"], desc["odim"]
+    A1, A2, D, nt = desc["aux0"], desc["aux1"], desc["num_stack"], desc["kernel_size"] + desc["stack_size"]
+    h = ko.linear(np.asarray(x, F32), r.take(A1, I), r.take(A1))
+    h = ko.relu(ko.linear(h, r.take(C, A1), r.take(C)))
+    B, T, _ = h.shape
+    for _ in range(desc["num_layers"]):
+        p = np.matmul(h, r.take(D, C).T).astype(F32)
+        taps = r.take(D, nt)
+        xp = np.concatenate([np.zeros((B, nt - 1, D), F32), p], axis=1)
+        m = np.zeros((B, T, D), F32)
+        for j in range(nt):
+            m += taps[None, None, :, j] * xp[:, j:j + T]
+        h = ko.relu(ko.linear(m, r.take(C, D), r.take(C)))
+    h = ko.linear(h, r.take(A2, C), r.take(A2))
+    y = ko.linear(h, r.take(K, A2), r.take(K))
+    assert r.p == r.b.size, "blob not fully consumed"
+    return y
+
+
 def forward(desc, blob, x):
     r = _Reader(blob)
+    if desc["backbone"] == 4:
+        return _fsmn(desc, r, x)
     C, I, K, ks = desc["hdim"], desc["idim"], desc["odim"], desc["kernel_size"]
     W, b = r.take(C, I), r.take(C)
     h = ko.linear(np.asarray(x, F32), W, b)

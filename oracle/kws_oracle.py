@@ -206,6 +206,44 @@ def gru_forward(cfg, sd, x, in_cache):
     return seq, np.stack(hn, axis=0)
 
 
+def fsmn_forward(cfg, sd, x, in_cache):
+    """FSMN.forward -- wekws/model/fsmn.py:462-495: in_linear1 -> in_linear2 -> ReLU ->
+    fsmn_layers x [LinearTransform (no bias) -> FSMNBlock memory -> AffineTransform -> ReLU]
+    -> out_linear1 -> out_linear2.  FSMNBlock.forward (fsmn.py:214-253): with
+    P = (lorder-1) + rorder, x_pad = [cache (P) | p (T)],
+      out[t] = x_pad[t + lorder-1] + sum_k wl[k] x_pad[t + k] + sum_k wr[k] x_pad[t + lorder + k],
+    i.e. the block output lags its input by ``rorder`` frames; new cache = last P columns of x_pad.
+    The blocks are always built with stride 1 (``_build_repeats`` passes literal 1, 1 at
+    fsmn.py:381-383 and drops left_stride / right_stride), which this restatement follows.
+    x: (B, T, idim) -> (B, T, odim); cache (B, proj_dim, P, layers) (4-D, layer index last)."""
+    bb = cfg["backbone"]
+    L, lo, ro = int(bb["num_layers"]), int(bb["left_order"]), int(bb["right_order"])
+    P = (lo - 1) + ro
+    B, T, _ = x.shape
+    h = linear(x, sd["backbone.in_linear1.linear.weight"], sd["backbone.in_linear1.linear.bias"])
+    h = relu(linear(h, sd["backbone.in_linear2.linear.weight"], sd["backbone.in_linear2.linear.bias"]))
+    have = in_cache is not None and in_cache.size > 0
+    caches = []
+    for l in range(L):
+        pre = f"backbone.fsmn.{l}."
+        p = np.matmul(h, _f(sd[pre + "0.linear.weight"]).T).astype(F32)  # (B, T, D), no bias
+        D = p.shape[2]
+        left = _f(in_cache[:, :, :, l]) if have else np.zeros((B, D, P), F32)
+        xp = np.concatenate([left, np.transpose(p, (0, 2, 1))], axis=2)  # (B, D, P + T)
+        wl = _f(sd[pre + "1.conv_left.weight"])[:, 0, :, 0]  # (D, lorder)
+        wr = _f(sd[pre + "1.conv_right.weight"])[:, 0, :, 0]  # (D, rorder)
+        m = xp[:, :, lo - 1:lo - 1 + T].copy()
+        for k in range(lo):
+            m += wl[None, :, k, None] * xp[:, :, k:k + T]
+        for k in range(ro):
+            m += wr[None, :, k, None] * xp[:, :, lo + k:lo + k + T]
+        caches.append(xp[:, :, xp.shape[2] - P:].copy())
+        h = relu(linear(np.transpose(m, (0, 2, 1)), sd[pre + "2.linear.weight"], sd[pre + "2.linear.bias"]))
+    h = linear(h, sd["backbone.out_linear1.linear.weight"], sd["backbone.out_linear1.linear.bias"])
+    y = linear(h, sd["backbone.out_linear2.linear.weight"], sd["backbone.out_linear2.linear.bias"])
+    return y, np.stack(caches, axis=3)
+
+
 # --------------------------------------------------------------------------- #
 # whole model
 # --------------------------------------------------------------------------- #
@@ -246,6 +284,8 @@ def forward(cfg, sd, x, in_cache=None, softmax=False):
         h, cache = mdtc_forward(cfg, sd, h, in_cache)
     elif bt == "gru":
         h, cache = gru_forward(cfg, sd, h, in_cache)
+    elif bt == "fsmn":
+        h, cache = fsmn_forward(cfg, sd, h, in_cache)
     else:
         raise ValueError(bt)
     # 4. classifier -- wekws/model/classifier.py:26-28, :38-40, :63-67

@@ -60,6 +60,20 @@ CASES = [
     _c("mdtc_small_last12/stream10", "mdtc_small_last12", B=2, T=40, chunks=[10] * 4),
     _c("gru_2x128/stream10", "gru_2x128", B=2, T=100, chunks=[10] * 10, cache="zeros"),
     _c("gru_2x128/stream_mixed", "gru_2x128", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47], cache="random"),
+    # ---- FSMN (4-D cache, layer index last; fsmn.py:462-495) ----
+    _c("fsmn_ctc/full", "fsmn_ctc", B=1, T=33),
+    _c("fsmn_ctc/stream_mixed", "fsmn_ctc", B=1, T=24, chunks=[1, 3, 8, 12]),
+    _c("fsmn_ctc300/full", "fsmn_ctc300", B=3, T=33),
+    _c("fsmn_ctc300/full_cmvn", "fsmn_ctc300", B=2, T=33, cmvn=True, xseed=1),
+    _c("fsmn_ctc300/softmax", "fsmn_ctc300", B=2, T=20, softmax=True),
+    _c("fsmn_ctc300/T1", "fsmn_ctc300", B=2, T=1),
+    _c("fsmn_ctc300/T150", "fsmn_ctc300", B=2, T=150),
+    _c("fsmn_ctc300/cache_rand", "fsmn_ctc300", B=2, T=7, cache="random"),
+    _c("fsmn_ctc300/cache_zero", "fsmn_ctc300", B=2, T=40, cache="zeros"),
+    _c("fsmn_ctc300/stream10", "fsmn_ctc300", B=2, T=60, chunks=[10] * 6),
+    _c("fsmn_small/full", "fsmn_small", B=3, T=98),
+    _c("fsmn_small/stream1", "fsmn_small", B=2, T=12, chunks=[1] * 12),
+    _c("fsmn_small/stream_mixed", "fsmn_small", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47], cache="random"),
 ]
 
 
@@ -93,6 +107,8 @@ def cache_shape(cfg, B):
         k = bb["kernel_size"]
         per_stack = sum((k - 1) * 2 ** j for j in range(bb["stack_size"]))
         return (B, bb["hidden_dim"], (k - 1) + bb["num_stack"] * per_stack)
+    if bb["type"] == "fsmn":  # blocks are built with stride 1 whatever the config says (fsmn.py:381-383)
+        return (B, bb["proj_dim"], bb["left_order"] - 1 + bb["right_order"], bb["num_layers"])
     raise ValueError(bb["type"])
 
 

@@ -65,6 +65,8 @@ def models():
 def test_golden(case, precision, golden, models):
     """HIP vs the live-reference golden vectors (41 cases: every backbone/head, ragged T, caches, streaming), in
     both matrix precisions (wekws_hip_precision): exact-f32 MFMA and the fp16 hi/lo split."""
+    if precision == "f32" and case["model"].startswith("fsmn"):
+        pytest.skip("FSMN is built for the split-fp16 mode only (test_fsmn_f32_is_refused)")
     cfg, sd, model = models(case, precision)
     x = case_input(case)
     y, cache = run(model, x, case_in_cache(case, cfg), softmax=case.get("softmax", False), chunks=case.get("chunks"))
@@ -78,7 +80,8 @@ def test_golden(case, precision, golden, models):
 
 @pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 5, 98), ("ds_tcn_h64", 7, 33), ("tcn_h64", 3, 98),
                                       ("mdtc_h64", 5, 98), ("mdtc_small", 9, 61), ("mdtc_h64_global12", 5, 130),
-                                      ("mdtc_small_last12", 6, 98), ("gru_2x128", 19, 40), ("gru_1x128", 3, 98)])
+                                      ("mdtc_small_last12", 6, 98), ("gru_2x128", 19, 40), ("gru_1x128", 3, 98),
+                                      ("fsmn_ctc300", 5, 33), ("fsmn_small", 7, 61), ("fsmn_ctc", 2, 17)])
 def test_vs_oracle_other_seeds(name, B, T):
     """Different weights (wseed 77) / inputs (xseed 5) / odd batch sizes than the goldens, vs the numpy oracle."""
     from wekws_amd import pack
@@ -93,7 +96,7 @@ def test_vs_oracle_other_seeds(name, B, T):
 
 
 @pytest.mark.parametrize("name,B", [("ds_tcn_h256", 1024), ("mdtc_h64", 1024), ("mdtc_h64_global12", 1024),
-                                    ("gru_2x128", 256)])
+                                    ("gru_2x128", 256), ("fsmn_ctc300", 512)])
 def test_full_batch_properties(name, B):
     """BASELINE-size batches (configs 1-3): spot-check 6 utterances against the oracle, and check the
     size-independent properties: a sub-batch gives bit-identical rows; 10-frame streaming == one-shot."""
@@ -116,7 +119,7 @@ def test_full_batch_properties(name, B):
     assert np.array_equal(ys, y[idx])
     assert np.array_equal(cs, csel)
     # streaming in 10-frame chunks == one-shot (per-frame heads only)
-    if "classifier" not in cfg:
+    if cfg.get("classifier", {}).get("type", "linear") in ("linear", "identity"):
         chunks = [10] * (T // 10) + ([T % 10] if T % 10 else [])
         yst, cst = run(model, x, chunks=chunks)
         assert max_abs(yst, y) <= 2e-5
@@ -125,7 +128,7 @@ def test_full_batch_properties(name, B):
 
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
-    for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64"):
+    for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
         model = build(cfg, sd)
@@ -138,7 +141,7 @@ def test_empty_cache_equals_zero_cache():
 def test_long_input_tiling_matches_oracle():
     """T > 112 goes through several LDS tiles that hand the context over via the workspace cache."""
     from wekws_amd import pack
-    for name, T in (("ds_tcn_h64", 500), ("mdtc_small_global12", 333), ("tcn_h64", 225)):
+    for name, T in (("ds_tcn_h64", 500), ("mdtc_small_global12", 333), ("tcn_h64", 225), ("fsmn_small", 300)):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 5)
         model = build(cfg, sd)
@@ -159,6 +162,14 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 10, 41, device="cuda"))
     with pytest.raises(ValueError):
         m(torch.zeros(1, 10, 40, device="cuda"), torch.zeros(1, 64, 3, device="cuda"))
+
+
+def test_fsmn_f32_is_refused():
+    """The exact-f32 mode has no FSMN kernel: the library must say so (EUNSUPPORTED), not run something else."""
+    from wekws_amd import _capi
+    m = init_model(dict(synth.MODEL_CONFIGS["fsmn_small"])).to("cuda").set_precision("f32")
+    with pytest.raises(_capi.HipLibraryError, match="fsmn"):
+        m(torch.zeros(1, 4, 120, device="cuda"))
 
 
 def test_weight_update_repacks():

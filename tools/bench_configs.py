@@ -45,10 +45,23 @@ def timeit(fn, warm=5, reps=30, group=10):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # optional substring filter on the model name
     out = []
+    # FSMN-CTC: 400-d spliced features at frame_skip 3 (fsmn_ctc.yaml:21-25): T = 33 / 66 frames = 1 s / 2 s of audio
+    for name, B, T in (("fsmn_ctc", 1024, 33), ("fsmn_ctc", 1024, 64), ("fsmn_ctc", 4096, 33)):
+        if only not in name:
+            continue
+        cfg, m = build(name)
+        x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=1)).cuda()
+        med, p10, p90 = timeit(lambda: m(x), reps=6, group=6)
+        out.append(dict(kind="batch", model=name, B=B, T=T, ms=round(med, 4), p10=round(p10, 4), p90=round(p90, 4),
+                        utts_per_s=round(B / med * 1e3, 1), frames_per_s=round(B * T / med * 1e3, 1)))
+        print(json.dumps(out[-1]), flush=True)
     for name, B in (("ds_tcn_h256", 1024), ("ds_tcn_h256", 8192), ("mdtc_h64", 1024), ("mdtc_h64", 8192),
                     ("mdtc_h64_global12", 1024), ("mdtc_small", 1024), ("ds_tcn_h64", 1024), ("tcn_h64", 1024),
                     ("gru_2x128", 256), ("gru_2x128", 1024), ("gru_2x128", 16384)):
+        if only not in name:
+            continue
         cfg, m = build(name)
         x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=1)).cuda()
         med, p10, p90 = timeit(lambda: m(x), reps=10 if B <= 1024 else 4, group=10 if B <= 1024 else 4)
@@ -57,7 +70,9 @@ def main():
         print(json.dumps(out[-1]), flush=True)
     # streaming latency: B streams, 10-frame chunks, cache carried, host-timed per chunk (includes launch overhead)
     for name, B in (("gru_2x128", 1), ("gru_2x128", 256), ("ds_tcn_h256", 1), ("ds_tcn_h256", 256), ("mdtc_h64", 1),
-                    ("mdtc_h64", 256)):
+                    ("mdtc_h64", 256), ("fsmn_ctc", 1), ("fsmn_ctc", 256)):
+        if only not in name:
+            continue
         cfg, m = build(name)
         x = torch.from_numpy(synth.synth_feats(B, 10, cfg["input_dim"], seed=2)).cuda()
         _, cache = m(x)
@@ -81,7 +96,7 @@ def main():
                         ms_per_chunk_stream=round(dev, 4), us_per_frame=round(dev * 100, 2)))
         print(json.dumps(out[-1]), flush=True)
     fb = Fbank(40)
-    for B in (1024, 8192):
+    for B in ((1024, 8192) if only in "fbank" else ()):
         pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()
         med, p10, p90 = timeit(lambda: fb(pcm))
         out.append(dict(kind="fbank", B=B, nsamp=16000, ms=round(med, 4), utts_per_s=round(B / med * 1e3, 1),

@@ -18,7 +18,7 @@ class HipLibraryError(RuntimeError):
 class Desc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "backbone", "idim", "hdim", "odim", "num_layers", "num_stack", "stack_size", "kernel_size",
-        "preproc_relu", "head", "head_hidden", "activation", "precision")] + [("reserved", C.c_int32 * 2)]
+        "preproc_relu", "head", "head_hidden", "activation", "precision", "aux0", "aux1")]
 
 
 class FbankCfg(C.Structure):
@@ -90,6 +90,5 @@ def check(rc: int, what: str) -> None:
 def make_desc(fields: dict) -> Desc:
     d = Desc()
     for n, _ in Desc._fields_:
-        if n != "reserved":
-            setattr(d, n, int(fields[n]))
+        setattr(d, n, int(fields.get(n, 0)))
     return d

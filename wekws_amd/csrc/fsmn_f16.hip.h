@@ -1,0 +1,299 @@
+// FSMN backbone (wekws/model/fsmn.py:462-495) as ONE fused gfx950 kernel, split-precision fp16 MFMA.
+//
+//   y = out_linear2(out_linear1( L x [ReLU(affine(memory(proj(h))))] ( ReLU(in_linear2(in_linear1(x))) ) ))
+//
+// Every dense layer is D[o][t] = sum_k W[o][k] B[k][t] on v_mfma_f32_16x16x32_f16 with both operands split into
+// fp16 hi + lo (three MFMAs per product into one fp32 accumulator, see conv_stack_f16.hip.h).  A workgroup owns ONE
+// utterance x ONE tile of 16*NT frames; the activations of the tile never leave LDS:
+//
+//   R0: x planes (idim)                 -> later: linear planes (linear_dim) | memory-output planes (proj_dim)
+//   R1: in_linear1 planes (affine_dim)  -> later: projection tile p[proj][SS] f32 (+ left context) -> out_linear1 planes
+//
+// "planes" = the MFMA B operand layout [k-octet][frame][8 halves], one plane for hi and one for lo; weights are the
+// A operand, pre-split and pre-packed on the host ([o-tile][k32][hi|lo][lane][8], Image::put_packed_a16) and streamed
+// from L2.  All channel counts are zero-padded to multiples of 32 on the host, so no phase has edge cases.
+//
+// Memory block (FSMNBlock.forward, fsmn.py:214-253), stride 1 as the reference always builds it (fsmn.py:381-383):
+//   out[t] = sum_j taps[j] x_pad[t + j],  x_pad = [cache (P = lorder-1+rorder) | p],  taps = [wl .. wl_last + 1 | wr]
+// (the identity path is folded into the taps by wekws_amd/pack.py).  The tile keeps x_pad in f32 with the first frame
+// at column COL0 = round_up(P, 4); the new cache is its last P valid columns.  Cache tensor: (B, proj, P, layers),
+// layer index innermost (fsmn.py:495, torch.cat(in_cache, dim=-1)).
+//
+// Long inputs are cut into tiles of kFsmnTileFrames by the host, chained through the same cache format.
+#pragma once
+#include "conv_stack_f16.hip.h"
+
+namespace wekws {
+
+constexpr int kFsmnThreads = 512;
+constexpr int kFsmnWaves = kFsmnThreads / 64;
+constexpr int kFsmnMaxLayers = 16;
+constexpr int kFsmnMaxTaps = 32;
+constexpr int kFsmnTileFrames = 64;
+constexpr int kFsmnLdsLimit = 160 * 1024;
+
+struct FsmnLayer {
+  uint32_t wp_a;   // proj  (Dp x LINp) packed A16, no bias
+  uint32_t taps;   // [Dp][taps_ld] f32, zero padded
+  uint32_t wa_a;   // affine (LINp x Dp) packed A16
+  uint32_t wa_b;   // [LINp] f32
+};
+
+struct FsmnParams {
+  const float* w;
+  int32_t idim, odim, proj;            // true sizes (x row length, y row length, cache channels)
+  int32_t kin, a1p, linp, dp, a2p, op; // padded to multiples of 32
+  int32_t nlayers, ntaps, P, taps_ld;
+  uint32_t in1_a, in1_b, in2_a, in2_b, out1_a, out1_b, out2_a, out2_b;
+  FsmnLayer layer[kFsmnMaxLayers];
+};
+
+struct FsmnArgs {
+  const float* x;         // first frame of this tile, utterance 0
+  int64_t xs_b;           // floats between utterances in x
+  const float* in_cache;  // (B, proj, P, L) or nullptr
+  float* out_cache;       // (B, proj, P, L) or nullptr
+  float* y;               // first output row of this tile
+  int64_t ys_b;
+  int32_t B, T;           // T: valid frames in this tile (1..16*NT)
+};
+
+// LDS plan for a tile of TT frames (bytes); shared by host (capacity check) and device
+struct FsmnLds {
+  int ss, col0, r0, r1, m_off;
+  __host__ __device__ static inline FsmnLds make(const FsmnParams& P, int TT) {
+    FsmnLds g;
+    g.col0 = (P.P + 3) / 4 * 4;
+    int ss = g.col0 + TT;
+    ss = (ss + 7) / 8 * 8 + 4;                                  // == 4 (mod 8): 4 rows apart -> 16 banks apart
+    g.ss = ss;
+    const int xb = P.kin * TT * 4, linb = P.linp * TT * 4, mb = P.dp * TT * 4;
+    g.m_off = linb;
+    g.r0 = xb > linb + mb ? xb : linb + mb;
+    int r1 = P.a1p * TT * 4;
+    if (P.dp * ss * 4 > r1) r1 = P.dp * ss * 4;
+    if (P.a2p * TT * 4 > r1) r1 = P.a2p * TT * 4;
+    g.r1 = r1;
+    return g;
+  }
+  __host__ __device__ inline int bytes() const { return r0 + r1; }
+};
+
+// One dense layer: for every pair of o-tiles owned by this wave, acc = W x B over KS k-steps, then epi(ot, acc).
+// bh: this lane's 16-byte item of k-step 0 / t-tile 0 in the hi plane, lo plane PLB bytes behind it.
+template <int NT, class Epi>
+__device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict__ W, uint32_t a_off, int MT, int KS,
+                                                          const char* bh, int PLB, int lane, int wave, Epi epi) {
+  constexpr int TT = 16 * NT;
+  constexpr int KSB = 4 * TT * 16;                       // bytes per k-step inside a plane
+  const int ots = KS * 128;                              // uint4 per o-tile
+  for (int ot = wave * 2; ot < MT; ot += 2 * kFsmnWaves) {
+    f32x4 acc[2][NT];
+    zero_acc(acc);
+    const uint4* ap = reinterpret_cast<const uint4*>(W + a_off) + size_t(ot) * ots + lane;
+    F16Frag a0[2], a1[2];
+    load_a16<2>(a0, ap, ots);
+    int ks = 0;
+    for (; ks + 1 < KS; ks += 2) {
+      load_a16<2>(a1, ap + (ks + 1) * 128, ots);
+      mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
+      load_a16<2>(a0, ap + min(ks + 2, KS - 1) * 128, ots);
+      mfma16_step<2, NT>(acc, a1, bh + (ks + 1) * KSB, bh + PLB + (ks + 1) * KSB);
+    }
+    if (ks < KS) mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
+    epi(ot, acc);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams P, const FsmnArgs A) {
+  constexpr int TT = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) char fsmn_lds[];
+  const FsmnLds G = FsmnLds::make(P, TT);
+  char* const r0 = fsmn_lds;
+  char* const r1 = fsmn_lds + G.r0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x;
+  const int T = A.T;
+  const float* __restrict__ W = P.w;
+  const int frag_off = (lq * TT + l15) * 16;
+
+  // epilogue: (+bias) [ReLU] -> hi / lo planes of CH channels at `dst`
+  auto to_planes = [&](char* dst, int CH, uint32_t bias_off, bool relu) __attribute__((always_inline)) {
+    return [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+      const int plb = CH * TT * 2;
+#pragma unroll
+      for (int ow = 0; ow < 2; ++ow) {
+        const int o = (ot + ow) * 16 + lq * 4;
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias_off) bias = *reinterpret_cast<const float4*>(W + bias_off + o);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          f16x4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ow][tt][r] + f4c(bias, r);
+            if (relu) v = fmaxf(v, 0.f);
+            _Float16 h, l;
+            split16(v, h, l);
+            vh[r] = h; vl[r] = l;
+          }
+          char* d = dst + ((o >> 3) * TT + tt * 16 + l15) * 16 + (o & 4) * 2;
+          *reinterpret_cast<f16x4*>(d) = vh;
+          *reinterpret_cast<f16x4*>(d + plb) = vl;
+        }
+      }
+    };
+  };
+
+  // ---------------- x tile -> planes in R0 (frames beyond T read as zero) ----------------
+  {
+    const int KO = P.kin / 8;
+    const float* xb = A.x + int64_t(b) * A.xs_b;
+    const int plb = P.kin * TT * 2;
+    // item = (k-octet, frame); 8 consecutive lanes take 8 consecutive frames of one octet (conflict-free LDS rows),
+    // the next lane bit walks the octets (32-byte neighbours in memory)
+    for (int e = tid; e < KO * TT; e += kFsmnThreads) {
+      const int tl = e & 7;
+      const int q = e >> 3;
+      const int koct = q % KO, th = q / KO;
+      const int t = th * 8 + tl;
+      const int k0 = koct * 8;
+      const float* xr = xb + int64_t(t) * P.idim + k0;
+      f16x8 vh, vl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (t < T && k0 + i < P.idim) ? xr[i] : 0.f;
+        _Float16 h, l;
+        split16(v, h, l);
+        vh[i] = h; vl[i] = l;
+      }
+      char* d = r0 + (koct * TT + t) * 16;
+      *reinterpret_cast<f16x8*>(d) = vh;
+      *reinterpret_cast<f16x8*>(d + plb) = vl;
+    }
+  }
+  __syncthreads();
+  // ---------------- in_linear1: x planes (R0) -> a1 planes (R1) ----------------
+  fsmn_gemm<NT>(W, P.in1_a, P.a1p / 16, P.kin / 32, r0 + frag_off, P.kin * TT * 2, lane, wave,
+                to_planes(r1, P.a1p, P.in1_b, false));
+  __syncthreads();
+  // ---------------- in_linear2 + ReLU: a1 planes (R1) -> linear planes (R0) ----------------
+  fsmn_gemm<NT>(W, P.in2_a, P.linp / 16, P.a1p / 32, r1 + frag_off, P.a1p * TT * 2, lane, wave,
+                to_planes(r0, P.linp, P.in2_b, true));
+  __syncthreads();
+
+  float* const pt = reinterpret_cast<float*>(r1);           // p[dp][ss] f32
+  char* const mpl = r0 + G.m_off;                           // memory-output planes
+  const int SS = G.ss, COL0 = G.col0, Pc = P.P, L = P.nlayers;
+  for (int l = 0; l < L; ++l) {
+    const FsmnLayer ly = P.layer[l];
+    // left context of this layer's memory block: columns [COL0 - P, COL0)
+    for (int e = tid; e < P.dp * Pc; e += kFsmnThreads) {
+      const int c = e / Pc, j = e - c * Pc;
+      float v = 0.f;
+      if (A.in_cache && c < P.proj) v = A.in_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l];
+      pt[c * SS + COL0 - Pc + j] = v;
+    }
+    // projection (no bias): linear planes (R0) -> p tile (R1)
+    fsmn_gemm<NT>(W, ly.wp_a, P.dp / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
+                  [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ow = 0; ow < 2; ++ow) {
+                      const int o = (ot + ow) * 16 + lq * 4;
+#pragma unroll
+                      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pt[(o + r) * SS + COL0 + tt * 16 + l15] = acc[ow][tt][r];
+                    }
+                  });
+    __syncthreads();
+    // memory block: item = (channel octet, frame) -> one 16-byte hi + lo plane item
+    {
+      const int plb = P.dp * TT * 2;
+      const int nt_ = P.ntaps, ld = P.taps_ld;
+      for (int e = tid; e < (P.dp / 8) * TT; e += kFsmnThreads) {
+        const int t = e % TT, oct = e / TT;
+        const float* wt = W + ly.taps + oct * 8 * ld;
+        const float* src = pt + oct * 8 * SS + (COL0 - Pc) + t;
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int j = 0; j < nt_; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s[i] = fmaf(wt[i * ld + j], src[i * SS + j], s[i]);
+        }
+        f16x8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          _Float16 h, lo;
+          split16(s[i], h, lo);
+          vh[i] = h; vl[i] = lo;
+        }
+        char* d = mpl + (oct * TT + t) * 16;
+        *reinterpret_cast<f16x8*>(d) = vh;
+        *reinterpret_cast<f16x8*>(d + plb) = vl;
+      }
+      // new cache = last P valid columns of x_pad
+      if (A.out_cache) {
+        for (int e = tid; e < P.proj * Pc; e += kFsmnThreads) {
+          const int c = e / Pc, j = e - c * Pc;
+          A.out_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l] = pt[c * SS + COL0 - Pc + T + j];
+        }
+      }
+    }
+    __syncthreads();
+    // affine + ReLU: memory planes -> linear planes (R0)
+    fsmn_gemm<NT>(W, ly.wa_a, P.linp / 16, P.dp / 32, mpl + frag_off, P.dp * TT * 2, lane, wave,
+                  to_planes(r0, P.linp, ly.wa_b, true));
+    __syncthreads();
+  }
+  // ---------------- out_linear1: linear planes (R0) -> o1 planes (R1) ----------------
+  fsmn_gemm<NT>(W, P.out1_a, P.a2p / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
+                to_planes(r1, P.a2p, P.out1_b, false));
+  __syncthreads();
+  // ---------------- out_linear2: o1 planes (R1) -> y ----------------
+  {
+    float* yb = A.y + int64_t(b) * A.ys_b;
+    const int K = P.odim;
+    fsmn_gemm<NT>(W, P.out2_a, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave,
+                  [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ow = 0; ow < 2; ++ow) {
+                      const int o = (ot + ow) * 16 + lq * 4;
+                      const float4 bias = *reinterpret_cast<const float4*>(W + P.out2_b + o);
+#pragma unroll
+                      for (int tt = 0; tt < NT; ++tt) {
+                        const int t = tt * 16 + l15;
+                        if (t < T) {
+                          float* yr = yb + int64_t(t) * K + o;
+#pragma unroll
+                          for (int r = 0; r < 4; ++r)
+                            if (o + r < K) yr[r] = acc[ow][tt][r] + f4c(bias, r);
+                        }
+                      }
+                    }
+                  });
+  }
+}
+
+template <int NT>
+inline int launch_fsmn_nt(const FsmnParams& P, const FsmnArgs& A, hipStream_t stream) {
+  const int lds = FsmnLds::make(P, 16 * NT).bytes();
+  if (lds > kFsmnLdsLimit) return -4;
+  static int attr_bytes = 0;
+  auto kern = fsmn_f16_kernel<NT>;
+  if (lds > attr_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return -3;
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kFsmnThreads), lds, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_fsmn_f16(int nt, const FsmnParams& P, const FsmnArgs& A, hipStream_t stream);
+
+}  // namespace wekws

@@ -19,6 +19,7 @@
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
 #include "fbank.hip.h"
+#include "fsmn_f16.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
 
@@ -120,9 +121,22 @@ int n_blocks(const wekws_hip_desc& d) {
 size_t blob_elems(const wekws_hip_desc& d) {
   if (d.abi_version != WEKWS_HIP_ABI_VERSION) { fail(WEKWS_HIP_EINVAL, "desc.abi_version %d != %d", d.abi_version, WEKWS_HIP_ABI_VERSION); return 0; }
   if (d.idim <= 0 || d.hdim <= 0 || d.odim <= 0) { fail(WEKWS_HIP_EINVAL, "idim/hdim/odim must be positive"); return 0; }
-  if (d.reserved[0] || d.reserved[1]) { fail(WEKWS_HIP_EINVAL, "desc.reserved must be 0"); return 0; }
+  if (d.backbone != WEKWS_HIP_BACKBONE_FSMN && (d.aux[0] || d.aux[1])) { fail(WEKWS_HIP_EINVAL, "desc.aux must be 0 for this backbone"); return 0; }
   if (d.precision < 0 || d.precision > WEKWS_HIP_PRECISION_F16X3) { fail(WEKWS_HIP_EINVAL, "desc.precision %d", d.precision); return 0; }
   const size_t C = d.hdim, K = d.odim, ks = d.kernel_size;
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+    const size_t A1 = d.aux[0], A2 = d.aux[1], D = d.num_stack, ro = d.stack_size;
+    if (d.num_layers <= 0 || d.num_stack <= 0 || d.kernel_size <= 0 || d.stack_size <= 0 || d.aux[0] <= 0 || d.aux[1] <= 0) {
+      fail(WEKWS_HIP_EINVAL, "fsmn: num_layers/proj_dim/left_order/right_order/affine dims must be positive");
+      return 0;
+    }
+    if (d.head != WEKWS_HIP_HEAD_IDENTITY || d.activation != WEKWS_HIP_ACT_IDENTITY || d.preproc_relu) {
+      fail(WEKWS_HIP_EINVAL, "fsmn: preprocessing none, identity classifier and identity activation only");
+      return 0;
+    }
+    return A1 * d.idim + A1 + C * A1 + C + size_t(d.num_layers) * (D * C + D * (ks + ro) + C * D + C) + A2 * C + A2 +
+           K * A2 + K;
+  }
   size_t n = C * d.idim + C;  // preprocessing
   switch (d.backbone) {
     case WEKWS_HIP_BACKBONE_DS_TCN:
@@ -176,6 +190,8 @@ struct wekws_hip_model {
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
   wekws::GruF16Params gq{};
+  wekws::FsmnParams fq{};
+  int fsmn_max_nt = 0;
   int cache_len = 0;
   Workspace ws;
   std::mutex ws_mu;
@@ -186,6 +202,122 @@ struct wekws_hip_fbank {
   int device = 0;
   float* d_tables = nullptr;
 };
+
+// FSMN: validate, zero-pad every channel count to a multiple of 32, pre-split + pre-pack the six kinds of dense
+// layers as MFMA A operands (fsmn_f16.hip.h), upload.
+static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elems, int device, wekws_hip_model** out) {
+  if (d.precision == WEKWS_HIP_PRECISION_F32)
+    return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: only the split-fp16 (F16X3 / DEFAULT) kernel is built");
+  if (d.num_layers > wekws::kFsmnMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn num_layers %d > %d", d.num_layers, wekws::kFsmnMaxLayers);
+  const int I = d.idim, A1 = d.aux[0], A2 = d.aux[1], C = d.hdim, D = d.num_stack, K = d.odim;
+  const int ntaps = d.kernel_size + d.stack_size;
+  if (ntaps > wekws::kFsmnMaxTaps) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn left_order + right_order %d > %d", ntaps, wekws::kFsmnMaxTaps);
+  wekws::FsmnParams q{};
+  q.idim = I; q.odim = K; q.proj = D;
+  q.kin = round_up(I, 32); q.a1p = round_up(A1, 32); q.linp = round_up(C, 32); q.dp = round_up(D, 32);
+  q.a2p = round_up(A2, 32); q.op = round_up(K, 32);
+  q.nlayers = d.num_layers; q.ntaps = ntaps; q.P = ntaps - 1; q.taps_ld = round_up(ntaps, 4);
+  int max_nt = 0;
+  for (int nt = 1; nt <= wekws::kFsmnTileFrames / 16; ++nt)
+    if (wekws::FsmnLds::make(q, 16 * nt).bytes() <= wekws::kFsmnLdsLimit) max_nt = nt;
+  if (!max_nt) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: layer widths do not fit the 160 KiB LDS tile");
+
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  Image img;
+  img.reserve(4);
+  const float* p = blob;
+  // a dense layer W[O][Ksrc] (+ bias[O]): A operand padded to (Op x Kp); bias padded with zeros to Op
+  auto dense = [&](int O, int Ksrc, int Op, bool has_bias, uint32_t* a_off, uint32_t* b_off) {
+    std::vector<float> wp(size_t(Op) * Ksrc, 0.f);
+    std::memcpy(wp.data(), p, size_t(O) * Ksrc * sizeof(float));
+    *a_off = img.put_packed_a16(wp.data(), Op, Ksrc, Ksrc);
+    p += size_t(O) * Ksrc;
+    if (has_bias) {
+      std::vector<float> bp(Op, 0.f);
+      std::memcpy(bp.data(), p, size_t(O) * sizeof(float));
+      *b_off = img.put(bp.data(), Op);
+      p += O;
+    }
+  };
+  dense(A1, I, q.a1p, true, &q.in1_a, &q.in1_b);
+  dense(C, A1, q.linp, true, &q.in2_a, &q.in2_b);
+  for (int l = 0; l < d.num_layers; ++l) {
+    uint32_t none = 0;
+    dense(D, C, q.dp, false, &q.layer[l].wp_a, &none);
+    std::vector<float> tp(size_t(q.dp) * q.taps_ld, 0.f);
+    for (int c = 0; c < D; ++c)
+      for (int j = 0; j < ntaps; ++j) tp[size_t(c) * q.taps_ld + j] = p[size_t(c) * ntaps + j];
+    q.layer[l].taps = img.put(tp.data(), tp.size());
+    p += size_t(D) * ntaps;
+    dense(C, D, q.linp, true, &q.layer[l].wa_a, &q.layer[l].wa_b);
+  }
+  dense(A2, C, q.a2p, true, &q.out1_a, &q.out1_b);
+  dense(K, A2, q.op, true, &q.out2_a, &q.out2_b);
+  if (size_t(p - blob) != n_elems)
+    return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
+
+  wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
+  if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
+  m->desc = d;
+  m->device = device;
+  m->cache_len = q.P;
+  m->fsmn_max_nt = max_nt;
+  hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->d_w) (void)hipFree(m->d_w);
+    delete m;
+    return fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "weight upload: %s", hipGetErrorString(e));
+  }
+  q.w = m->d_w;
+  m->fq = q;
+  *out = m;
+  return WEKWS_HIP_OK;
+}
+
+// The frames of one FSMN call, cut into LDS tiles chained through ping-pong workspace caches
+static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
+                        float* out_cache, hipStream_t stream) {
+  const wekws_hip_desc& d = m->desc;
+  const int TILE = 16 * m->fsmn_max_nt;
+  const int ntiles = (T + TILE - 1) / TILE;
+  float* ws_cache[2] = {nullptr, nullptr};
+  std::unique_lock<std::mutex> lock(m->ws_mu, std::defer_lock);
+  if (ntiles > 1) {
+    lock.lock();
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t ce = size_t(B) * d.num_stack * m->cache_len * d.num_layers;
+    if (m->ws.cache_elems < ce) {
+      for (float*& c : m->ws.cache) { if (c) (void)hipFree(c); c = nullptr; }
+      m->ws.cache_elems = 0;
+      HIP_TRY(hipMalloc(&m->ws.cache[0], ce * sizeof(float)));
+      HIP_TRY(hipMalloc(&m->ws.cache[1], ce * sizeof(float)));
+      m->ws.cache_elems = ce;
+    }
+    ws_cache[0] = m->ws.cache[0];
+    ws_cache[1] = m->ws.cache[1];
+  }
+  for (int i = 0; i < ntiles; ++i) {
+    const int t0 = i * TILE;
+    const int Tt = (T - t0 < TILE) ? (T - t0) : TILE;
+    wekws::FsmnArgs a{};
+    a.x = x + size_t(t0) * d.idim;
+    a.xs_b = int64_t(T) * d.idim;
+    a.in_cache = (i == 0) ? in_cache : ws_cache[(i - 1) & 1];
+    a.out_cache = (i == ntiles - 1) ? out_cache : ws_cache[i & 1];
+    a.y = y + size_t(t0) * d.odim;
+    a.ys_b = int64_t(T) * d.odim;
+    a.B = B;
+    a.T = Tt;
+    const int rc = wekws::launch_fsmn_f16((Tt + 15) / 16, m->fq, a, stream);
+    if (rc) return fail(rc, "fsmn launch failed (nt=%d): %s", (Tt + 15) / 16, hipGetErrorString(hipGetLastError()));
+  }
+  return WEKWS_HIP_OK;
+}
 
 extern "C" {
 
@@ -206,6 +338,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   if (!need) return WEKWS_HIP_EINVAL;
   if (need != n_elems) return fail(WEKWS_HIP_EINVAL, "weight blob has %zu floats, descriptor needs %zu", n_elems, need);
   const int C = d.hdim, ks = d.kernel_size, K = d.odim;
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return create_fsmn(d, blob, n_elems, device, out);
   if (desc_conv(d)) {
     if (C != 32 && C != 64 && C != 128 && C != 256)
       return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for 32/64/128/256", C);
@@ -415,12 +548,16 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   delete m;
 }
 
-int wekws_hip_cache_dim(const wekws_hip_model* m) { return m ? m->desc.hdim : 0; }
+int wekws_hip_cache_dim(const wekws_hip_model* m) {
+  if (!m) return 0;
+  return m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN ? m->desc.num_stack : m->desc.hdim;
+}
 int wekws_hip_cache_len(const wekws_hip_model* m) { return m ? m->cache_len : 0; }
 
 size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
   if (!m || B <= 0) return 0;
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * m->desc.hdim;
+  if (m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN) return size_t(B) * m->desc.num_stack * m->cache_len * m->desc.num_layers;
   return size_t(B) * m->desc.hdim * m->cache_len;
 }
 
@@ -440,7 +577,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   const wekws_hip_desc& d = m->desc;
   const bool per_frame = d.head == WEKWS_HIP_HEAD_LINEAR || d.head == WEKWS_HIP_HEAD_IDENTITY;
 
-  if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+    const int rc = forward_fsmn(m, x, B, T, in_cache, y, out_cache, stream);
+    if (rc) return rc;
+  } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
     const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && d.odim <= 128;
     const int rc = f16 ? wekws::launch_gru_f16(m->gq, x, B, T, in_cache, y, out_cache, stream)
                        : wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);

@@ -90,7 +90,7 @@ class KWSModel(nn.Module):
         super().__init__()
         self._cfg = dict(configs)
         self._d = pack.parse_config(configs)
-        self.idim, self.odim, self.hdim = self._d["idim"], self._d["odim"], self._d["hdim"]
+        self.idim, self.odim, self.hdim = self._d["idim"], self._d["odim"], int(configs["hidden_dim"])
         for name, shape in pack.model_spec(configs):
             parts = name.split(".")
             mod = self

@@ -17,13 +17,15 @@ from typing import Dict, List, Mapping, Tuple
 import numpy as np
 
 ABI_VERSION = 1
-BACKBONE = dict(ds_tcn=0, tcn=1, mdtc=2, gru=3)
+BACKBONE = dict(ds_tcn=0, tcn=1, mdtc=2, gru=3, fsmn=4)
 HEAD = dict(linear=0, glob=1, last=2, identity=3)
 BN_EPS = 1e-5
 HEAD_HIDDEN = 64  # nn.Linear(hidden_dim, 64) in wekws/model/kws_model.py:181-186
 
 DESC_FIELDS = ("abi_version", "backbone", "idim", "hdim", "odim", "num_layers", "num_stack", "stack_size",
-               "kernel_size", "preproc_relu", "head", "head_hidden", "activation", "precision")
+               "kernel_size", "preproc_relu", "head", "head_hidden", "activation", "precision", "aux0", "aux1")
+# FSMN reuses the generic slots (include/wekws_hip.h): hdim = linear_dim, num_stack = proj_dim, kernel_size =
+# left_order, stack_size = right_order, aux0 = input_affine_dim, aux1 = output_affine_dim
 PRECISION = dict(default=0, f32=1, f16x3=2)  # enum wekws_hip_precision
 
 
@@ -41,7 +43,7 @@ def parse_config(configs: Mapping) -> dict:
     bb = configs["backbone"]
     bt = bb["type"]
     d = dict(abi_version=ABI_VERSION, idim=idim, hdim=hdim, odim=odim, num_layers=0, num_stack=0, stack_size=0,
-             kernel_size=0, preproc_relu=1 if prep == "linear" else 0, prep=prep,
+             kernel_size=0, preproc_relu=1 if prep == "linear" else 0, prep=prep, aux0=0, aux1=0,
              precision=PRECISION[str(configs.get("_precision", "default"))])
     if bt == "gru":
         d.update(backbone=BACKBONE["gru"], num_layers=int(bb["num_layers"]), kind="gru")
@@ -56,8 +58,30 @@ def parse_config(configs: Mapping) -> dict:
             raise ConfigError("mdtc: backbone.hidden_dim must equal hidden_dim")
         d.update(backbone=BACKBONE["mdtc"], num_stack=int(bb["num_stack"]), stack_size=int(bb["stack_size"]),
                  kernel_size=int(bb["kernel_size"]), kind="mdtc")
+    elif bt == "fsmn":
+        # the reference builds every FSMNBlock with stride 1 (fsmn.py:381-383 drops left_stride / right_stride),
+        # and a block with right_order 0 cannot run there (empty slice at fsmn.py:231); follow both
+        if prep != "none":
+            raise ConfigError("fsmn: only preprocessing none is supported (the reference recipe, fsmn_ctc.yaml:38-39)")
+        if int(bb["right_order"]) < 1 or int(bb["left_order"]) < 1:
+            raise ConfigError("fsmn: left_order and right_order must be >= 1")
+        hdim = int(bb["linear_dim"])
+        d.update(backbone=BACKBONE["fsmn"], kind="fsmn", hdim=hdim, num_layers=int(bb["num_layers"]),
+                 num_stack=int(bb["proj_dim"]), kernel_size=int(bb["left_order"]), stack_size=int(bb["right_order"]),
+                 aux0=int(bb["input_affine_dim"]), aux1=int(bb["output_affine_dim"]))
     else:
         raise ConfigError(f"Unknown body type {bt}")
+    if d["kind"] == "fsmn":
+        # FSMN ends in its own out_linear2 (-> output_dim): only the identity classifier is shape-consistent
+        if "classifier" not in configs or configs["classifier"]["type"] != "identity":
+            raise ConfigError("fsmn: classifier must be identity (the backbone already maps to output_dim)")
+        d.update(head=HEAD["identity"], activation=0, head_hidden=0)
+        if "activation" in configs and configs["activation"]["type"] != "identity":
+            raise ConfigError(f"Unknown activation type {configs['activation']['type']}")
+        cm = configs.get("cmvn", {}) or {}
+        d["cmvn"] = bool(configs.get("_cmvn")) or bool(cm.get("cmvn_file"))
+        d["norm_var"] = bool(cm.get("norm_var", True))
+        return d
     if prep == "none" and idim != hdim:
         raise ConfigError("preprocessing none needs input_dim == hidden_dim")
     if "classifier" in configs:
@@ -89,9 +113,11 @@ def mdtc_blocks(d: dict) -> List[Tuple[str, int]]:
     return out
 
 
-def cache_shape(d: dict, B: int) -> Tuple[int, int, int]:
+def cache_shape(d: dict, B: int) -> Tuple[int, ...]:
     if d["kind"] == "gru":
         return (d["num_layers"], B, d["hdim"])
+    if d["kind"] == "fsmn":  # (B, proj_dim, lorder - 1 + rorder, layers)  -- export_onnx.py:55-60, fsmn.py:495
+        return (B, d["num_stack"], d["kernel_size"] - 1 + d["stack_size"], d["num_layers"])
     k = d["kernel_size"]
     if d["kind"] == "mdtc":
         P = sum((k - 1) * dil for _, dil in mdtc_blocks(d))
@@ -114,6 +140,18 @@ def model_spec(configs: Mapping) -> List[Tuple[str, tuple]]:
         spec += [("global_cmvn.mean", (I,)), ("global_cmvn.istd", (I,))]
     if d["prep"] == "linear":
         spec += [("preprocessing.out.0.weight", (C, I)), ("preprocessing.out.0.bias", (C,))]
+    if d["kind"] == "fsmn":
+        A1, A2, D, lo, ro = d["aux0"], d["aux1"], d["num_stack"], d["kernel_size"], d["stack_size"]
+        spec += [("backbone.in_linear1.linear.weight", (A1, I)), ("backbone.in_linear1.linear.bias", (A1,)),
+                 ("backbone.in_linear2.linear.weight", (C, A1)), ("backbone.in_linear2.linear.bias", (C,))]
+        for l in range(d["num_layers"]):
+            p = f"backbone.fsmn.{l}."
+            spec += [(p + "0.linear.weight", (D, C)), (p + "1.conv_left.weight", (D, 1, lo, 1)),
+                     (p + "1.conv_right.weight", (D, 1, ro, 1)),
+                     (p + "2.linear.weight", (C, D)), (p + "2.linear.bias", (C,))]
+        spec += [("backbone.out_linear1.linear.weight", (A2, C)), ("backbone.out_linear1.linear.bias", (A2,)),
+                 ("backbone.out_linear2.linear.weight", (K, A2)), ("backbone.out_linear2.linear.bias", (K,))]
+        return spec
     if d["kind"] == "gru":
         for l in range(d["num_layers"]):
             spec += [(f"backbone.weight_ih_l{l}", (3 * C, C)), (f"backbone.weight_hh_l{l}", (3 * C, C)),
@@ -160,6 +198,9 @@ def pack(configs: Mapping, sd: Mapping) -> Tuple[dict, np.ndarray]:
     d = parse_config(configs)
     C, I = d["hdim"], d["idim"]
     parts: List[np.ndarray] = []
+
+    if d["kind"] == "fsmn":
+        return _pack_fsmn(d, sd)
 
     # ---- preprocessing (+ CMVN):  W (x - mean) * istd + b = (W * istd) x + (b - (W * istd) mean)
     if d["prep"] == "linear":
@@ -210,11 +251,39 @@ def pack(configs: Mapping, sd: Mapping) -> Tuple[dict, np.ndarray]:
     return desc, np.ascontiguousarray(blob)
 
 
+def _pack_fsmn(d: dict, sd: Mapping) -> Tuple[dict, np.ndarray]:
+    """FSMN blob: in1 W(A1,I) b | in2 W(C,A1) b | per layer: Wp(D,C), taps(D, lo+ro), Wa(C,D), ba | out1 W(A2,C) b |
+    out2 W(K,A2) b.  CMVN folds into in_linear1; the memory block's identity path (fsmn.py:236-237) folds into its
+    taps: out[t] = sum_j taps[j] x_pad[t + j] with taps = [wl_0 .. wl_{lo-1} + 1 | wr_0 .. wr_{ro-1}]."""
+    I, lo, ro = d["idim"], d["kernel_size"], d["stack_size"]
+    W, b = _f64(sd, "backbone.in_linear1.linear.weight"), _f64(sd, "backbone.in_linear1.linear.bias")
+    if d["cmvn"]:
+        mean = _f64(sd, "global_cmvn.mean")
+        istd = _f64(sd, "global_cmvn.istd") if d["norm_var"] else np.ones(I)
+        W = W * istd[None, :]
+        b = b - W @ mean
+    parts = [W, b, _f64(sd, "backbone.in_linear2.linear.weight"), _f64(sd, "backbone.in_linear2.linear.bias")]
+    for l in range(d["num_layers"]):
+        p = f"backbone.fsmn.{l}."
+        taps = np.concatenate([_f64(sd, p + "1.conv_left.weight")[:, 0, :, 0],
+                               _f64(sd, p + "1.conv_right.weight")[:, 0, :, 0]], axis=1)
+        taps[:, lo - 1] += 1.0
+        parts += [_f64(sd, p + "0.linear.weight"), taps, _f64(sd, p + "2.linear.weight"), _f64(sd, p + "2.linear.bias")]
+    parts += [_f64(sd, "backbone.out_linear1.linear.weight"), _f64(sd, "backbone.out_linear1.linear.bias"),
+              _f64(sd, "backbone.out_linear2.linear.weight"), _f64(sd, "backbone.out_linear2.linear.bias")]
+    blob = np.concatenate([np.ravel(p) for p in parts]).astype(np.float32)
+    return {k: int(d[k]) for k in DESC_FIELDS}, np.ascontiguousarray(blob)
+
+
 def blob_elems(desc: Mapping) -> int:
     """Python twin of wekws_hip_blob_elems (checked against the library in tests/test_capi.py)."""
     C, I, K, ks = desc["hdim"], desc["idim"], desc["odim"], desc["kernel_size"]
-    n = C * I + C
     bb = desc["backbone"]
+    if bb == BACKBONE["fsmn"]:
+        A1, A2, D, ro = desc["aux0"], desc["aux1"], desc["num_stack"], desc["stack_size"]
+        return (A1 * I + A1 + C * A1 + C + desc["num_layers"] * (D * C + D * (ks + ro) + C * D + C)
+                + A2 * C + A2 + K * A2 + K)
+    n = C * I + C
     if bb == BACKBONE["ds_tcn"]:
         n += desc["num_layers"] * (C * ks + C + C * C + C)
     elif bb == BACKBONE["tcn"]:
@@ -234,14 +303,14 @@ def blob_elems(desc: Mapping) -> int:
 # ------------------------------------------------------------------------------------------------
 # Packed-model file: what a C / C++ host reads instead of a torch checkpoint.
 #   bytes 0..7    magic b"WEKWSHIP"
-#   then          16 x int32 little-endian = struct wekws_hip_desc (14 fields + 2 reserved zeros)
+#   then          16 x int32 little-endian = struct wekws_hip_desc
 #   then          uint64 n_elems, n_elems x float32 little-endian = the folded blob
 # ------------------------------------------------------------------------------------------------
 MAGIC = b"WEKWSHIP"
 
 
 def save_packed(path: str, desc: Mapping, blob: np.ndarray) -> None:
-    fields = [int(desc[k]) for k in DESC_FIELDS] + [0, 0]
+    fields = [int(desc.get(k, 0)) for k in DESC_FIELDS]
     blob = np.ascontiguousarray(blob, dtype="<f4")
     if blob.size != blob_elems(desc):
         raise ValueError(f"blob has {blob.size} floats, descriptor needs {blob_elems(desc)}")
@@ -261,7 +330,7 @@ def load_packed(path: str) -> Tuple[dict, np.ndarray]:
         blob = np.frombuffer(f.read(4 * n), dtype="<f4").astype(np.float32)
     if blob.size != n or fields.size != 16:
         raise ValueError(f"{path}: truncated")
-    desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields[:14])}
+    desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields)}
     if desc["abi_version"] != ABI_VERSION or blob.size != blob_elems(desc):
         raise ValueError(f"{path}: ABI version / size mismatch")
     return desc, blob

@@ -67,6 +67,27 @@ MODEL_CONFIGS: Dict[str, dict] = {
                              preprocessing=dict(type="linear"),
                              backbone=dict(type="tcn", ds=True, num_layers=4, kernel_size=8, dropout=0.1),
                              activation=dict(type="identity")),
+    # examples/hi_xiaowen/s0/conf/fsmn_ctc.yaml:36-56 (400-d spliced fbank, 2599 CTC tokens, 756 k params)
+    "fsmn_ctc": dict(input_dim=400, output_dim=2599, hidden_dim=128,
+                     preprocessing=dict(type="none"),
+                     backbone=dict(type="fsmn", input_affine_dim=140, num_layers=4, linear_dim=250, proj_dim=128,
+                                   left_order=10, right_order=2, left_stride=1, right_stride=1,
+                                   output_affine_dim=140),
+                     classifier=dict(type="identity", dropout=0.1), activation=dict(type="identity")),
+    # same body, 300 tokens: keeps the committed fixtures small
+    "fsmn_ctc300": dict(input_dim=400, output_dim=300, hidden_dim=128,
+                        preprocessing=dict(type="none"),
+                        backbone=dict(type="fsmn", input_affine_dim=140, num_layers=4, linear_dim=250, proj_dim=128,
+                                      left_order=10, right_order=2, left_stride=1, right_stride=1,
+                                      output_affine_dim=140),
+                        classifier=dict(type="identity", dropout=0.1), activation=dict(type="identity")),
+    # odd sizes everywhere: exercises every zero-padding rule of the packed operands
+    "fsmn_small": dict(input_dim=120, output_dim=11, hidden_dim=64,
+                       preprocessing=dict(type="none"),
+                       backbone=dict(type="fsmn", input_affine_dim=72, num_layers=2, linear_dim=100, proj_dim=40,
+                                     left_order=5, right_order=1, left_stride=1, right_stride=1,
+                                     output_affine_dim=56),
+                       classifier=dict(type="identity", dropout=0.1), activation=dict(type="identity")),
 }
 
 

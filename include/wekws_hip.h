@@ -205,6 +205,23 @@ int wekws_hip_fbank_num_frames(const wekws_hip_fbank* f, int nsamp);
 int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsamp, float* feats,
                             void* stream);
 
+/*
+ * Context expansion + frame skip  --  replaces context_expansion / frame_skip of the data pipeline
+ * (wekws/dataset/init_dataset.py:24-68, wekws/dataset/processor.py:267-311; fsmn_ctc.yaml:21-25 uses left 2,
+ * right 2, skip 3: 80-d fbank -> the 400-d FSMN input at a third of the frame rate), fused into one gather:
+ *   out[b][i][(lag + left) * F + f] = feats[b][max(i * skip + lag, 0)][f],   lag = -left .. right,
+ *   i = 0 .. wekws_hip_splice_frames(T, right, skip) - 1
+ * (the left margin replicates frame 0, the last `right` frames are dropped, then every skip-th frame is kept).
+ */
+/* ceil((T - right) / skip), 0 if T <= right */
+int wekws_hip_splice_frames(int T, int right, int skip);
+/*
+ * feats  (B, T, F) device float32
+ * out    (B, wekws_hip_splice_frames(T, right, skip), (left + right + 1) * F) device float32
+ */
+int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

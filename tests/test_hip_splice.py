@@ -1,0 +1,66 @@
+"""GPU: wekws_hip_splice (context expansion + frame skip) against the reference goldens and the oracle; the op is
+a gather, so every comparison is bit-exact.  Also the fbank -> splice -> FSMN chain against the oracles."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kws_oracle, splice_oracle
+from tests.golden.splice_cases import CASES, case_input
+from wekws_amd import frontend, pack
+from wekws_amd.model.kws_model import init_model
+from wekws_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "splice_golden.npz"))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_splice_golden(case):
+    name, B, T, F, left, right, skip = case
+    x = torch.from_numpy(case_input(B, T, F)).cuda()
+    y, lens = frontend.splice_skip(x, left, right, skip, feats_lengths=torch.full((B,), T, dtype=torch.int32))
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), GOLD[name + "/y"])
+    assert np.array_equal(lens.numpy(), GOLD[name + "/lens"])
+
+
+def test_splice_large_and_edges():
+    x = case_input(512, 98, 80, seed=9)
+    xt = torch.from_numpy(x).cuda()
+    y = frontend.splice_skip(xt, 2, 2, 3).cpu().numpy()
+    assert np.array_equal(y, splice_oracle.splice_skip(x, 2, 2, 3))
+    assert np.array_equal(frontend.context_expansion(xt[:4], 1, 1).cpu().numpy(), splice_oracle.context_expansion(x[:4], 1, 1))
+    assert np.array_equal(frontend.frame_skip(xt[:4], 3).cpu().numpy(), splice_oracle.frame_skip(x[:4], 3))
+    # T <= right: nothing left; B = 0
+    assert frontend.splice_skip(xt[:2, :2], 2, 2, 3).shape == (2, 0, 400)
+    assert frontend.splice_skip(xt[:0], 2, 2, 3).shape == (0, 32, 400)
+    # unaligned view -> the scalar path
+    z = frontend.splice_skip(xt[:3, 1:, :][:, :, :79].contiguous(), 1, 2, 2).cpu().numpy()
+    assert np.array_equal(z, splice_oracle.splice_skip(x[:3, 1:, :79], 1, 2, 2))
+    with pytest.raises(ValueError):
+        frontend.splice_skip(torch.zeros(1, 4, 8), 1, 1, 1)
+
+
+def test_fbank80_splice_fsmn_chain():
+    """pcm -> HIP fbank(80) -> HIP splice(2,2)/skip 3 -> HIP FSMN-CTC, each stage's input being the previous HIP
+    output, against the oracles fed the same way (fsmn_ctc.yaml recipe shape: 1 s of audio -> 32 x 400 -> 32 x 300)."""
+    from oracle import fbank_oracle
+    cfg = dict(synth.MODEL_CONFIGS["fsmn_ctc300"])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    model = init_model(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.cuda().eval()
+    pcm = synth.synth_pcm(3, 16000, seed=4)
+    feats = frontend.Fbank(num_bins=80)(torch.from_numpy(pcm).cuda())
+    ref_feats = np.stack([fbank_oracle.fbank(p, 80) for p in pcm])
+    assert np.abs(feats.cpu().numpy() - ref_feats).max() <= 1e-3
+    x = frontend.splice_skip(feats, 2, 2, 3)
+    assert x.shape == (3, 32, 400)
+    y, cache = model(x)
+    torch.cuda.synchronize()
+    ry, rc = kws_oracle.forward(cfg, sd, splice_oracle.splice_skip(feats.cpu().numpy(), 2, 2, 3), None)
+    assert np.abs(y.cpu().numpy() - ry).max() <= 1e-4 * max(1.0, float(np.abs(ry).max()))
+    assert cache.shape == (3, 128, 11, 4)
+    assert np.abs(cache.cpu().numpy() - rc).max() <= 1e-4 * max(1.0, float(np.abs(rc).max()))

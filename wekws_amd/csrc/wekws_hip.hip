@@ -22,6 +22,7 @@
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
+#include "splice.hip.h"
 
 namespace {
 
@@ -715,6 +716,24 @@ int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsa
   if (B == 0 || nf == 0) return WEKWS_HIP_OK;
   const int rc = wekws::launch_fbank(f->fp, pcm, B, nsamp, nf, feats, static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "fbank launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+// --------------------------------------------- context expansion + frame skip ---------------------------------------------
+int wekws_hip_splice_frames(int T, int right, int skip) {
+  if (skip <= 0 || right < 0 || T <= right) return 0;
+  return (T - right + skip - 1) / skip;  // init_dataset.py:50-51 then :64-65
+}
+
+int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out, void* stream_) {
+  if (!feats || !out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || T < 0 || F <= 0 || left < 0 || right < 0 || skip <= 0)
+    return fail(WEKWS_HIP_EINVAL, "B=%d T=%d F=%d left=%d right=%d skip=%d", B, T, F, left, right, skip);
+  const int To = wekws_hip_splice_frames(T, right, skip);
+  if (B == 0 || To == 0) return WEKWS_HIP_OK;
+  if ((int64_t(B) * To * (left + right + 1) * F + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "splice: too many elements for one launch");
+  const int rc = wekws::launch_splice(feats, B, T, F, left, right, skip, To, out, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "splice launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }
 

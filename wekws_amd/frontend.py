@@ -1,7 +1,8 @@
-"""Batched on-device log-mel filterbank: MI355X replacement for ``wenet::Fbank::Compute``
-(runtime/core/frontend/fbank.h:138-198) behind ``FeaturePipeline::AcceptWaveform``'s framing rule
-(runtime/core/frontend/feature_pipeline.cc:30-47).  Thin host wrapper over the C ABI
-(wekws_hip_fbank_*); no CPU fallback."""
+"""Batched on-device front-end: log-mel filterbank (MI355X replacement for ``wenet::Fbank::Compute``,
+runtime/core/frontend/fbank.h:138-198, behind ``FeaturePipeline::AcceptWaveform``'s framing rule,
+runtime/core/frontend/feature_pipeline.cc:30-47) and the context-expansion / frame-skip step of the data pipeline
+(wekws/dataset/init_dataset.py:24-68).  Thin host wrappers over the C ABI (wekws_hip_fbank_*, wekws_hip_splice);
+no CPU fallback."""
 from __future__ import annotations
 
 import ctypes
@@ -68,3 +69,35 @@ class Fbank:
         samples[frame_shift * frames:] for the next push (feature_pipeline.cc:41-44)."""
         nf = self.num_frames(nsamp)
         return nf, self.frame_shift * nf
+
+
+def splice_skip(feats: torch.Tensor, left: int = 0, right: int = 0, skip: int = 1,
+                feats_lengths: Optional[torch.Tensor] = None):
+    """context_expansion(left, right) followed by frame_skip(skip) (wekws/dataset/init_dataset.py:24-68) as ONE
+    gather on the device: (B, T, F) -> (B, ceil((T - right) / skip), (left + right + 1) * F).
+    With ``feats_lengths`` also returns the reference's updated lengths (:51 then :64-65)."""
+    if feats.dim() != 3 or not feats.is_cuda or feats.dtype != torch.float32:
+        raise ValueError("feats must be a (B, T, F) float32 tensor on a ROCm device (no CPU fallback)")
+    lib = _capi.load()
+    feats = feats.contiguous()
+    B, T, F = (int(v) for v in feats.shape)
+    To = int(lib.wekws_hip_splice_frames(T, int(right), int(skip)))
+    out = torch.empty((B, To, (left + right + 1) * F), dtype=torch.float32, device=feats.device)
+    if B and To:
+        stream = torch.cuda.current_stream(feats.device).cuda_stream
+        _capi.check(lib.wekws_hip_splice(feats.data_ptr(), B, T, F, int(left), int(right), int(skip), out.data_ptr(),
+                                         ctypes.c_void_p(stream)), "wekws_hip_splice")
+    if feats_lengths is None:
+        return out
+    lens = torch.ceil((feats_lengths - right) / skip).to(dtype=torch.int16)
+    return out, lens
+
+
+def context_expansion(feats: torch.Tensor, left: int = 1, right: int = 1) -> torch.Tensor:
+    """wekws/dataset/init_dataset.py:24-52 on a (B, T, F) device batch."""
+    return splice_skip(feats, left, right, 1)
+
+
+def frame_skip(feats: torch.Tensor, skip_rate: int = 1) -> torch.Tensor:
+    """wekws/dataset/init_dataset.py:54-68 on a (B, T, F) device batch."""
+    return splice_skip(feats, 0, 0, skip_rate)

@@ -15,8 +15,9 @@
 //
 // Memory block (FSMNBlock.forward, fsmn.py:214-253), stride 1 as the reference always builds it (fsmn.py:381-383):
 //   out[t] = sum_j taps[j] x_pad[t + j],  x_pad = [cache (P = lorder-1+rorder) | p],  taps = [wl .. wl_last + 1 | wr]
-// (the identity path is folded into the taps by wekws_amd/pack.py).  The tile keeps x_pad in f32 with the first frame
-// at column COL0 = round_up(P, 4); the new cache is its last P valid columns.  Cache tensor: (B, proj, P, layers),
+// (the identity path is folded into the taps by wekws_amd/pack.py).  The tile keeps x_pad in f32, column j = x_pad[j]
+// (first frame at column P), so the 4-frame run a lane computes reads a 16-byte aligned window; the new cache is the
+// last P valid columns.  Cache tensor: (B, proj, P, layers),
 // layer index innermost (fsmn.py:495, torch.cat(in_cache, dim=-1)).
 //
 // Long inputs are cut into tiles of kFsmnTileFrames by the host, chained through the same cache format.
@@ -31,6 +32,19 @@ constexpr int kFsmnMaxLayers = 16;
 constexpr int kFsmnMaxTaps = 32;
 constexpr int kFsmnTileFrames = 64;
 constexpr int kFsmnLdsLimit = 160 * 1024;
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte store that only needs dword alignment
+
+// v = hi + lo with hi = fp16(v), lo = fp16(v - hi): v_cvt_pk_f16_f32 / v_pk_add_f32 on gfx950
+__device__ __forceinline__ void split16x4(f32x4 v, f16x4& h, f16x4& l) {
+  h = __builtin_convertvector(v, f16x4);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+}
+__device__ __forceinline__ void split16x8(f32x8 v, f16x8& h, f16x8& l) {
+  h = __builtin_convertvector(v, f16x8);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, f32x8), f16x8);
+}
 
 struct FsmnLayer {
   uint32_t wp_a;   // proj  (Dp x LINp) packed A16, no bias
@@ -63,8 +77,8 @@ struct FsmnLds {
   int ss, col0, r0, r1, m_off;
   __host__ __device__ static inline FsmnLds make(const FsmnParams& P, int TT) {
     FsmnLds g;
-    g.col0 = (P.P + 3) / 4 * 4;
-    int ss = g.col0 + TT;
+    g.col0 = P.P;                                               // frame t sits at column P + t: the window of a
+    int ss = TT + P.taps_ld;                                    // 4-frame run starts 16-byte aligned at column t
     ss = (ss + 7) / 8 * 8 + 4;                                  // == 4 (mod 8): 4 rows apart -> 16 banks apart
     g.ss = ss;
     const int xb = P.kin * TT * 4, linb = P.linp * TT * 4, mb = P.dp * TT * 4;
@@ -82,26 +96,47 @@ struct FsmnLds {
 // One dense layer: for every pair of o-tiles owned by this wave, acc = W x B over KS k-steps, then epi(ot, acc).
 // bh: this lane's 16-byte item of k-step 0 / t-tile 0 in the hi plane, lo plane PLB bytes behind it.
 template <int NT, class Epi>
-__device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict__ W, uint32_t a_off, int MT, int KS,
-                                                          const char* bh, int PLB, int lane, int wave, Epi epi) {
+__device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict__ W, uint32_t a_off, uint32_t bias_off,
+                                                          int MT, int KS, const char* bh, int PLB, int lane, int wave,
+                                                          Epi epi) {
   constexpr int TT = 16 * NT;
   constexpr int KSB = 4 * TT * 16;                       // bytes per k-step inside a plane
   const int ots = KS * 128;                              // uint4 per o-tile
-  for (int ot = wave * 2; ot < MT; ot += 2 * kFsmnWaves) {
+  int ot = wave * 2;
+  if (ot >= MT) return;
+  const uint4* const abase = reinterpret_cast<const uint4*>(W + a_off) + lane;
+  const int k1 = min(1, KS - 1);
+  // Weight fragments run one pair of k-steps ahead and are software-pipelined ACROSS o-tile pairs: the first two
+  // k-steps of the next pair are requested before this pair's epilogue, so the wait for them never has to drain the
+  // epilogue's stores (loads and stores share one in-order counter on gfx9).
+  F16Frag a0[2], a1[2];
+  load_a16<2>(a0, abase + size_t(ot) * ots, ots);
+  load_a16<2>(a1, abase + size_t(ot) * ots + k1 * 128, ots);
+  for (; ot < MT; ot += 2 * kFsmnWaves) {
     f32x4 acc[2][NT];
     zero_acc(acc);
-    const uint4* ap = reinterpret_cast<const uint4*>(W + a_off) + size_t(ot) * ots + lane;
-    F16Frag a0[2], a1[2];
-    load_a16<2>(a0, ap, ots);
-    int ks = 0;
-    for (; ks + 1 < KS; ks += 2) {
-      load_a16<2>(a1, ap + (ks + 1) * 128, ots);
-      mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
-      load_a16<2>(a0, ap + min(ks + 2, KS - 1) * 128, ots);
-      mfma16_step<2, NT>(acc, a1, bh + (ks + 1) * KSB, bh + PLB + (ks + 1) * KSB);
+    // bias of this pair: requested BEFORE the k loop so that the epilogue's wait for it does not drain the younger
+    // weight prefetches behind it
+    f32x4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (bias_off) {
+      bias[0] = *reinterpret_cast<const f32x4*>(W + bias_off + ot * 16 + (lane >> 4) * 4);
+      bias[1] = *reinterpret_cast<const f32x4*>(W + bias_off + ot * 16 + 16 + (lane >> 4) * 4);
     }
-    if (ks < KS) mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
-    epi(ot, acc);
+    const uint4* ap = abase + size_t(ot) * ots;
+    const int otn = (ot + 2 * kFsmnWaves < MT) ? ot + 2 * kFsmnWaves : ot;
+    const uint4* apn = abase + size_t(otn) * ots;
+    int ks = 0;
+    for (; ks + 2 < KS; ks += 2) {
+      mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
+      load_a16<2>(a0, ap + (ks + 2) * 128, ots);
+      mfma16_step<2, NT>(acc, a1, bh + (ks + 1) * KSB, bh + PLB + (ks + 1) * KSB);
+      load_a16<2>(a1, ap + min(ks + 3, KS - 1) * 128, ots);
+    }
+    mfma16_step<2, NT>(acc, a0, bh + ks * KSB, bh + PLB + ks * KSB);
+    load_a16<2>(a0, apn, ots);
+    if (ks + 1 < KS) mfma16_step<2, NT>(acc, a1, bh + (ks + 1) * KSB, bh + PLB + (ks + 1) * KSB);
+    load_a16<2>(a1, apn + k1 * 128, ots);
+    epi(ot, acc, bias);
   }
 }
 
@@ -120,25 +155,18 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   const int frag_off = (lq * TT + l15) * 16;
 
   // epilogue: (+bias) [ReLU] -> hi / lo planes of CH channels at `dst`
-  auto to_planes = [&](char* dst, int CH, uint32_t bias_off, bool relu) __attribute__((always_inline)) {
-    return [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+  auto to_planes = [&](char* dst, int CH, bool relu) __attribute__((always_inline)) {
+    return [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
       const int plb = CH * TT * 2;
 #pragma unroll
       for (int ow = 0; ow < 2; ++ow) {
         const int o = (ot + ow) * 16 + lq * 4;
-        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias_off) bias = *reinterpret_cast<const float4*>(W + bias_off + o);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
+          f32x4 v = acc[ow][tt] + bias[ow];
+          if (relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
           f16x4 vh, vl;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[ow][tt][r] + f4c(bias, r);
-            if (relu) v = fmaxf(v, 0.f);
-            _Float16 h, l;
-            split16(v, h, l);
-            vh[r] = h; vl[r] = l;
-          }
+          split16x4(v, vh, vl);
           char* d = dst + ((o >> 3) * TT + tt * 16 + l15) * 16 + (o & 4) * 2;
           *reinterpret_cast<f16x4*>(d) = vh;
           *reinterpret_cast<f16x4*>(d + plb) = vl;
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
     const int KO = P.kin / 8;
     const float* xb = A.x + int64_t(b) * A.xs_b;
     const int plb = P.kin * TT * 2;
+    const bool xvec = (P.idim % 4 == 0) && (A.xs_b % 4 == 0) && (reinterpret_cast<uintptr_t>(A.x) % 16 == 0);
     // item = (k-octet, frame); 8 consecutive lanes take 8 consecutive frames of one octet (conflict-free LDS rows),
     // the next lane bit walks the octets (32-byte neighbours in memory)
     for (int e = tid; e < KO * TT; e += kFsmnThreads) {
@@ -161,14 +190,19 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       const int t = th * 8 + tl;
       const int k0 = koct * 8;
       const float* xr = xb + int64_t(t) * P.idim + k0;
-      f16x8 vh, vl;
+      f32x8 xv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (t < T) {
+        if (xvec && k0 + 8 <= P.idim) {
+          const f32x4 lo4 = *reinterpret_cast<const f32x4*>(xr), hi4 = *reinterpret_cast<const f32x4*>(xr + 4);
+          xv = f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = (t < T && k0 + i < P.idim) ? xr[i] : 0.f;
-        _Float16 h, l;
-        split16(v, h, l);
-        vh[i] = h; vl[i] = l;
+          for (int i = 0; i < 8; ++i)
+            if (k0 + i < P.idim) xv[i] = xr[i];
+        }
       }
+      f16x8 vh, vl;
+      split16x8(xv, vh, vl);
       char* d = r0 + (koct * TT + t) * 16;
       *reinterpret_cast<f16x8*>(d) = vh;
       *reinterpret_cast<f16x8*>(d + plb) = vl;
@@ -176,12 +210,12 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   }
   __syncthreads();
   // ---------------- in_linear1: x planes (R0) -> a1 planes (R1) ----------------
-  fsmn_gemm<NT>(W, P.in1_a, P.a1p / 16, P.kin / 32, r0 + frag_off, P.kin * TT * 2, lane, wave,
-                to_planes(r1, P.a1p, P.in1_b, false));
+  fsmn_gemm<NT>(W, P.in1_a, P.in1_b, P.a1p / 16, P.kin / 32, r0 + frag_off, P.kin * TT * 2, lane, wave,
+                to_planes(r1, P.a1p, false));
   __syncthreads();
   // ---------------- in_linear2 + ReLU: a1 planes (R1) -> linear planes (R0) ----------------
-  fsmn_gemm<NT>(W, P.in2_a, P.linp / 16, P.a1p / 32, r1 + frag_off, P.a1p * TT * 2, lane, wave,
-                to_planes(r0, P.linp, P.in2_b, true));
+  fsmn_gemm<NT>(W, P.in2_a, P.in2_b, P.linp / 16, P.a1p / 32, r1 + frag_off, P.a1p * TT * 2, lane, wave,
+                to_planes(r0, P.linp, true));
   __syncthreads();
 
   float* const pt = reinterpret_cast<float*>(r1);           // p[dp][ss] f32
@@ -189,16 +223,20 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   const int SS = G.ss, COL0 = G.col0, Pc = P.P, L = P.nlayers;
   for (int l = 0; l < L; ++l) {
     const FsmnLayer ly = P.layer[l];
-    // left context of this layer's memory block: columns [COL0 - P, COL0)
-    for (int e = tid; e < P.dp * Pc; e += kFsmnThreads) {
-      const int c = e / Pc, j = e - c * Pc;
-      float v = 0.f;
-      if (A.in_cache && c < P.proj) v = A.in_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l];
-      pt[c * SS + COL0 - Pc + j] = v;
+    // left context of this layer's memory block: columns [0, P); the slack columns behind the tile are zeroed because
+    // the zero-padded tap groups multiply them
+    {
+      const int slack = SS - (Pc + TT), per = Pc + slack;
+      for (int e = tid; e < P.dp * per; e += kFsmnThreads) {
+        const int c = e / per, j = e - c * per;
+        float v = 0.f;
+        if (j < Pc && A.in_cache && c < P.proj) v = A.in_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l];
+        pt[c * SS + (j < Pc ? j : TT + j)] = v;
+      }
     }
     // projection (no bias): linear planes (R0) -> p tile (R1)
-    fsmn_gemm<NT>(W, ly.wp_a, P.dp / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
-                  [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+    fsmn_gemm<NT>(W, ly.wp_a, 0, P.dp / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
+                  [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&)[2]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int ow = 0; ow < 2; ++ow) {
                       const int o = (ot + ow) * 16 + lq * 4;
@@ -209,68 +247,80 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
                     }
                   });
     __syncthreads();
-    // memory block: item = (channel octet, frame) -> one 16-byte hi + lo plane item
+    // memory block: item = (channel, run of 4 frames).  Lane bits: [0:2] channel within its octet, [3:4] run, [5]
+    // octet -> conflict-free 16-byte window reads, 4-way conflicts on the 2-byte plane writes.
     {
       const int plb = P.dp * TT * 2;
-      const int nt_ = P.ntaps, ld = P.taps_ld;
-      for (int e = tid; e < (P.dp / 8) * TT; e += kFsmnThreads) {
-        const int t = e % TT, oct = e / TT;
-        const float* wt = W + ly.taps + oct * 8 * ld;
-        const float* src = pt + oct * 8 * SS + (COL0 - Pc) + t;
-        float s[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s[i] = 0.f;
-        for (int j = 0; j < nt_; ++j) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) s[i] = fmaf(wt[i * ld + j], src[i * SS + j], s[i]);
+      const int ng = P.taps_ld / 4, nq4 = TT / 16;
+      for (int e = tid; e < P.dp * (TT / 4); e += kFsmnThreads) {
+        const int r = e >> 6;
+        const int c = (r / nq4) * 16 + ((e >> 5) & 1) * 8 + (e & 7);
+        const int q = (r % nq4) * 4 + ((e >> 3) & 3);
+        const float* wt = W + ly.taps + c * P.taps_ld;
+        const float* src = pt + c * SS + 4 * q;
+        f32x4 k = *reinterpret_cast<const f32x4*>(wt);
+        f32x4 w0 = *reinterpret_cast<const f32x4*>(src);
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < ng; ++g) {
+          const f32x4 kn = *reinterpret_cast<const f32x4*>(wt + 4 * min(g + 1, ng - 1));
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(src + 4 * g + 4);
+          acc4[0] = fmaf(k[3], w0[3], fmaf(k[2], w0[2], fmaf(k[1], w0[1], fmaf(k[0], w0[0], acc4[0]))));
+          acc4[1] = fmaf(k[3], w1[0], fmaf(k[2], w0[3], fmaf(k[1], w0[2], fmaf(k[0], w0[1], acc4[1]))));
+          acc4[2] = fmaf(k[3], w1[1], fmaf(k[2], w1[0], fmaf(k[1], w0[3], fmaf(k[0], w0[2], acc4[2]))));
+          acc4[3] = fmaf(k[3], w1[2], fmaf(k[2], w1[1], fmaf(k[1], w1[0], fmaf(k[0], w0[3], acc4[3]))));
+          w0 = w1;
+          k = kn;
         }
-        f16x8 vh, vl;
+        f16x4 vh, vl;
+        split16x4(acc4, vh, vl);
+        char* d = mpl + ((c >> 3) * TT + 4 * q) * 16 + (c & 7) * 2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          _Float16 h, lo;
-          split16(s[i], h, lo);
-          vh[i] = h; vl[i] = lo;
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<_Float16*>(d + i * 16) = vh[i];
+          *reinterpret_cast<_Float16*>(d + i * 16 + plb) = vl[i];
         }
-        char* d = mpl + (oct * TT + t) * 16;
-        *reinterpret_cast<f16x8*>(d) = vh;
-        *reinterpret_cast<f16x8*>(d + plb) = vl;
       }
       // new cache = last P valid columns of x_pad
       if (A.out_cache) {
         for (int e = tid; e < P.proj * Pc; e += kFsmnThreads) {
           const int c = e / Pc, j = e - c * Pc;
-          A.out_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l] = pt[c * SS + COL0 - Pc + T + j];
+          A.out_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l] = pt[c * SS + T + j];
         }
       }
     }
     __syncthreads();
     // affine + ReLU: memory planes -> linear planes (R0)
-    fsmn_gemm<NT>(W, ly.wa_a, P.linp / 16, P.dp / 32, mpl + frag_off, P.dp * TT * 2, lane, wave,
-                  to_planes(r0, P.linp, ly.wa_b, true));
+    fsmn_gemm<NT>(W, ly.wa_a, ly.wa_b, P.linp / 16, P.dp / 32, mpl + frag_off, P.dp * TT * 2, lane, wave,
+                  to_planes(r0, P.linp, true));
     __syncthreads();
   }
   // ---------------- out_linear1: linear planes (R0) -> o1 planes (R1) ----------------
-  fsmn_gemm<NT>(W, P.out1_a, P.a2p / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
-                to_planes(r1, P.a2p, P.out1_b, false));
+  fsmn_gemm<NT>(W, P.out1_a, P.out1_b, P.a2p / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
+                to_planes(r1, P.a2p, false));
   __syncthreads();
   // ---------------- out_linear2: o1 planes (R1) -> y ----------------
   {
     float* yb = A.y + int64_t(b) * A.ys_b;
     const int K = P.odim;
-    fsmn_gemm<NT>(W, P.out2_a, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave,
-                  [=](int ot, f32x4 (&acc)[2][NT]) __attribute__((always_inline)) {
+    fsmn_gemm<NT>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave,
+                  [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
+                    // rows of y are only dword aligned (odim is odd in the recipes): 16-byte stores through a
+                    // 4-byte-aligned type.  Only the last pair can run past odim; that test is wave-uniform.
+                    const bool whole = (ot + 2) * 16 <= K;
 #pragma unroll
                     for (int ow = 0; ow < 2; ++ow) {
                       const int o = (ot + ow) * 16 + lq * 4;
-                      const float4 bias = *reinterpret_cast<const float4*>(W + P.out2_b + o);
 #pragma unroll
                       for (int tt = 0; tt < NT; ++tt) {
                         const int t = tt * 16 + l15;
-                        if (t < T) {
-                          float* yr = yb + int64_t(t) * K + o;
+                        const f32x4 v = acc[ow][tt] + bias[ow];
+                        float* yr = yb + int64_t(t) * K + o;
+                        if (whole) {
+                          if (t < T) *reinterpret_cast<F32x4U*>(yr) = F32x4U{{v[0], v[1], v[2], v[3]}};
+                        } else if (t < T) {
 #pragma unroll
                           for (int r = 0; r < 4; ++r)
-                            if (o + r < K) yr[r] = acc[ow][tt][r] + f4c(bias, r);
+                            if (o + r < K) yr[r] = v[r];
                         }
                       }
                     }

@@ -29,6 +29,7 @@ namespace wekws {
 constexpr int kFsmnThreads = 512;
 constexpr int kFsmnWaves = kFsmnThreads / 64;
 constexpr int kFsmnMaxLayers = 16;
+constexpr int kFsmnHeldK = 5;       // layers with <= this many k-steps keep a whole o-tile pair of weights in registers
 constexpr int kFsmnMaxTaps = 32;
 constexpr int kFsmnTileFrames = 64;
 constexpr int kFsmnLdsLimit = 160 * 1024;
@@ -140,6 +141,44 @@ __device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict
   }
 }
 
+// Same contract as fsmn_gemm for layers with at most KH k-steps: ALL weight fragments of an o-tile pair live in
+// registers, and each one is re-requested for the wave's NEXT pair right after its last use, so every fragment has a
+// whole pair of MFMA work (not one k-step) to arrive and never queues behind the epilogue's stores.
+template <int NT, int KH, class Epi>
+__device__ __attribute__((always_inline)) void fsmn_gemm_held(const float* __restrict__ W, uint32_t a_off,
+                                                               uint32_t bias_off, int MT, int KS, const char* bh,
+                                                               int PLB, int lane, int wave, Epi epi) {
+  constexpr int TT = 16 * NT;
+  constexpr int KSB = 4 * TT * 16;
+  const int ots = KS * 128;
+  int ot = wave * 2;
+  if (ot >= MT) return;
+  const uint4* const abase = reinterpret_cast<const uint4*>(W + a_off) + lane;
+  F16Frag a[KH][2];
+#pragma unroll
+  for (int ks = 0; ks < KH; ++ks)
+    if (ks < KS) load_a16<2>(a[ks], abase + size_t(ot) * ots + ks * 128, ots);
+  for (; ot < MT; ot += 2 * kFsmnWaves) {
+    f32x4 acc[2][NT];
+    zero_acc(acc);
+    f32x4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (bias_off) {
+      bias[0] = *reinterpret_cast<const f32x4*>(W + bias_off + ot * 16 + (lane >> 4) * 4);
+      bias[1] = *reinterpret_cast<const f32x4*>(W + bias_off + ot * 16 + 16 + (lane >> 4) * 4);
+    }
+    const int otn = (ot + 2 * kFsmnWaves < MT) ? ot + 2 * kFsmnWaves : ot;
+    const uint4* apn = abase + size_t(otn) * ots;
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+      if (ks < KS) {
+        mfma16_step<2, NT>(acc, a[ks], bh + ks * KSB, bh + PLB + ks * KSB);
+        load_a16<2>(a[ks], apn + ks * 128, ots);
+      }
+    }
+    epi(ot, acc, bias);
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams P, const FsmnArgs A) {
   constexpr int TT = 16 * NT;
@@ -147,7 +186,8 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   const FsmnLds G = FsmnLds::make(P, TT);
   char* const r0 = fsmn_lds;
   char* const r1 = fsmn_lds + G.r0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: o-tile loops and their branches go scalar
   const int l15 = lane & 15, lq = lane >> 4;
   const int b = blockIdx.x;
   const int T = A.T;
@@ -302,8 +342,7 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   {
     float* yb = A.y + int64_t(b) * A.ys_b;
     const int K = P.odim;
-    fsmn_gemm<NT>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave,
-                  [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
+    auto store_y = [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
                     // rows of y are only dword aligned (odim is odd in the recipes): 16-byte stores through a
                     // 4-byte-aligned type.  Only the last pair can run past odim; that test is wave-uniform.
                     const bool whole = (ot + 2) * 16 <= K;
@@ -324,7 +363,12 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
                         }
                       }
                     }
-                  });
+                  };
+    if (P.a2p / 32 <= kFsmnHeldK)
+      fsmn_gemm_held<NT, kFsmnHeldK>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane,
+                                     wave, store_y);
+    else
+      fsmn_gemm<NT>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave, store_y);
   }
 }
 

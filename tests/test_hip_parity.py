@@ -164,6 +164,29 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 10, 40, device="cuda"), torch.zeros(1, 64, 3, device="cuda"))
 
 
+@pytest.mark.parametrize("name,B,T", [("fsmn_ctc300", 601, 30), ("fsmn_small", 1027, 9), ("fsmn_small", 515, 32),
+                                      ("fsmn_ctc300", 1030, 16)])
+def test_fsmn_packed_utterances(name, B, T):
+    """Short inputs in large batches run 2 or 4 utterances per workgroup (odd B exercises the batch tail): every row
+    must equal the unpacked result (a small batch of the same rows) bit for bit, and the oracle within tolerance, with
+    a random carried cache."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 21)
+    model = build(cfg, sd)
+    x = synth.synth_feats(B, T, cfg["input_dim"], seed=13)
+    cshape = pack.cache_shape(pack.parse_config(cfg), B)
+    cache0 = np.random.default_rng(5).standard_normal(cshape).astype(np.float32)
+    y, c = run(model, x, cache0)
+    idx = np.array([0, 1, 2, 3, B // 2, B - 3, B - 2, B - 1])
+    ys, cs = run(model, np.ascontiguousarray(x[idx]), np.ascontiguousarray(cache0[idx]))   # 8 rows: unpacked path
+    assert np.array_equal(y[idx], ys) and np.array_equal(c[idx], cs)
+    ry, rc = kws_oracle.forward(cfg, sd, x[idx], cache0[idx])
+    assert max_abs(ys, ry) <= tol_for(ry)
+    assert max_abs(cs, rc) <= tol_for(rc)
+    assert np.isfinite(y).all() and np.isfinite(c).all()
+
+
 def test_fsmn_f32_is_refused():
     """The exact-f32 mode has no FSMN kernel: the library must say so (EUNSUPPORTED), not run something else."""
     from wekws_amd import _capi

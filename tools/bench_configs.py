@@ -47,8 +47,8 @@ def timeit(fn, warm=5, reps=30, group=10):
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""   # optional substring filter on the model name
     out = []
-    # FSMN-CTC: 400-d spliced features at frame_skip 3 (fsmn_ctc.yaml:21-25): T = 33 / 66 frames = 1 s / 2 s of audio
-    for name, B, T in (("fsmn_ctc", 1024, 33), ("fsmn_ctc", 1024, 64), ("fsmn_ctc", 4096, 33)):
+    # FSMN-CTC: 400-d spliced features at frame_skip 3 (fsmn_ctc.yaml:21-25): 98 fbank frames (1 s) -> T = 32; 2 s -> 64
+    for name, B, T in (("fsmn_ctc", 1024, 32), ("fsmn_ctc", 1024, 64), ("fsmn_ctc", 4096, 32)):
         if only not in name:
             continue
         cfg, m = build(name)

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
   const int wo = wave % G::WO;             // which o-tile group
   const int wu = wave / G::WO;             // which utterance of the workgroup
   const int l15 = lane & 15, lq = lane >> 4;

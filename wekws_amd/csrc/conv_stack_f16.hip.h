@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   float* const hbuf = lds + G::S_FLOATS;                   // [U][C][SS] f32 resident activations
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
   const int wo = wave % G::WO, wu = wave / G::WO;
   const int l15 = lane & 15, lq = lane >> 4;
   const int T = A.T;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
   constexpr int HP = D::HPLANE, XP = D::XPLANE, UB = D::UB;
   extern __shared__ __attribute__((aligned(16))) char dense_lds[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave % G::WO, wu = wave / G::WO;
   const int l15 = lane & 15, lq = lane >> 4;
   const int T = A.T;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   float* const hbuf = w16_lds + G::SLAB / 4;                 // [256][SS] f32 resident activations
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
   const int l15 = lane & 15, lq = lane >> 4;
   const int T = A.T;
   const int b = blockIdx.x;                                  // one utterance per workgroup

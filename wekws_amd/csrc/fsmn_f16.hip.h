@@ -20,7 +20,8 @@
 // last P valid columns.  Cache tensor: (B, proj, P, layers),
 // layer index innermost (fsmn.py:495, torch.cat(in_cache, dim=-1)).
 //
-// Long inputs are cut into tiles of kFsmnTileFrames by the host, chained through the same cache format.
+// Long inputs are cut into tiles of kFsmnTileFrames by the host, chained through the same cache format; short ones
+// (<= 32 frames, e.g. a 1-s utterance at frame_skip 3, or streaming chunks) are packed 2 or 4 utterances to a workgroup.
 #pragma once
 #include "conv_stack_f16.hip.h"
 
@@ -73,13 +74,15 @@ struct FsmnArgs {
   int32_t B, T;           // T: valid frames in this tile (1..16*NT)
 };
 
-// LDS plan for a tile of TT frames (bytes); shared by host (capacity check) and device
+// LDS plan for a tile of TT frames = U utterances x TT / U frames (bytes); shared by host (capacity check) and device
 struct FsmnLds {
-  int ss, col0, r0, r1, m_off;
-  __host__ __device__ static inline FsmnLds make(const FsmnParams& P, int TT) {
+  int ss, seg, r0, r1, m_off;
+  __host__ __device__ static inline FsmnLds make(const FsmnParams& P, int TT, int U) {
     FsmnLds g;
-    g.col0 = P.P;                                               // frame t sits at column P + t: the window of a
-    int ss = TT + P.taps_ld;                                    // 4-frame run starts 16-byte aligned at column t
+    // x_pad row of the projection tile: per utterance [P cache columns | TT/U frames | slack], column j = x_pad[j], so
+    // the window of a 4-frame run starts 16-byte aligned; the slack absorbs the zero-padded tap groups
+    g.seg = (TT / U + P.taps_ld + 3) / 4 * 4;
+    int ss = U * g.seg;
     ss = (ss + 7) / 8 * 8 + 4;                                  // == 4 (mod 8): 4 rows apart -> 16 banks apart
     g.ss = ss;
     const int xb = P.kin * TT * 4, linb = P.linp * TT * 4, mb = P.dp * TT * 4;
@@ -179,17 +182,20 @@ __device__ __attribute__((always_inline)) void fsmn_gemm_held(const float* __res
   }
 }
 
-template <int NT>
+// NT frame tiles per workgroup = U utterances x NT / U tiles each (short inputs are packed U to a workgroup so that a
+// weight fragment, whose trip through the CU's 64 B/clk L1 path is the fixed cost of a workgroup, feeds NT MFMA tiles)
+template <int NT, int U>
 __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams P, const FsmnArgs A) {
-  constexpr int TT = 16 * NT;
+  constexpr int TT = 16 * NT, NTU = NT / U, TTU = 16 * NTU;
+  static_assert(NTU * U == NT, "tiles split evenly over the packed utterances");
   extern __shared__ __attribute__((aligned(16))) char fsmn_lds[];
-  const FsmnLds G = FsmnLds::make(P, TT);
+  const FsmnLds G = FsmnLds::make(P, TT, U);
   char* const r0 = fsmn_lds;
   char* const r1 = fsmn_lds + G.r0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: o-tile loops and their branches go scalar
   const int l15 = lane & 15, lq = lane >> 4;
-  const int b = blockIdx.x;
+  const int b0 = blockIdx.x * U;                              // first utterance of this workgroup
   const int T = A.T;
   const float* __restrict__ W = P.w;
   const int frag_off = (lq * TT + l15) * 16;
@@ -218,7 +224,6 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   // ---------------- x tile -> planes in R0 (frames beyond T read as zero) ----------------
   {
     const int KO = P.kin / 8;
-    const float* xb = A.x + int64_t(b) * A.xs_b;
     const int plb = P.kin * TT * 2;
     const bool xvec = (P.idim % 4 == 0) && (A.xs_b % 4 == 0) && (reinterpret_cast<uintptr_t>(A.x) % 16 == 0);
     // item = (k-octet, frame); 8 consecutive lanes take 8 consecutive frames of one octet (conflict-free LDS rows),
@@ -227,11 +232,12 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       const int tl = e & 7;
       const int q = e >> 3;
       const int koct = q % KO, th = q / KO;
-      const int t = th * 8 + tl;
+      const int f = th * 8 + tl;                              // frame slot of the tile
+      const int u = f / TTU, t = f - u * TTU;
       const int k0 = koct * 8;
-      const float* xr = xb + int64_t(t) * P.idim + k0;
+      const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + k0;
       f32x8 xv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (t < T) {
+      if (t < T && b0 + u < A.B) {
         if (xvec && k0 + 8 <= P.idim) {
           const f32x4 lo4 = *reinterpret_cast<const f32x4*>(xr), hi4 = *reinterpret_cast<const f32x4*>(xr + 4);
           xv = f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       }
       f16x8 vh, vl;
       split16x8(xv, vh, vl);
-      char* d = r0 + (koct * TT + t) * 16;
+      char* d = r0 + (koct * TT + f) * 16;
       *reinterpret_cast<f16x8*>(d) = vh;
       *reinterpret_cast<f16x8*>(d + plb) = vl;
     }
@@ -260,18 +266,20 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
 
   float* const pt = reinterpret_cast<float*>(r1);           // p[dp][ss] f32
   char* const mpl = r0 + G.m_off;                           // memory-output planes
-  const int SS = G.ss, COL0 = G.col0, Pc = P.P, L = P.nlayers;
+  const int SS = G.ss, SEG = G.seg, Pc = P.P, L = P.nlayers;
   for (int l = 0; l < L; ++l) {
     const FsmnLayer ly = P.layer[l];
-    // left context of this layer's memory block: columns [0, P); the slack columns behind the tile are zeroed because
-    // the zero-padded tap groups multiply them
+    // left context of this layer's memory block: columns [0, P) of every utterance segment; the slack columns behind
+    // its frames are zeroed because the zero-padded tap groups multiply them
     {
-      const int slack = SS - (Pc + TT), per = Pc + slack;
-      for (int e = tid; e < P.dp * per; e += kFsmnThreads) {
-        const int c = e / per, j = e - c * per;
+      const int per = SEG - TTU;                               // P cache columns + slack
+      for (int e = tid; e < P.dp * U * per; e += kFsmnThreads) {
+        const int c = e / (U * per), r = e - c * (U * per);
+        const int u = r / per, j = r - u * per;
         float v = 0.f;
-        if (j < Pc && A.in_cache && c < P.proj) v = A.in_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l];
-        pt[c * SS + (j < Pc ? j : TT + j)] = v;
+        if (j < Pc && A.in_cache && c < P.proj && b0 + u < A.B)
+          v = A.in_cache[((int64_t(b0 + u) * P.proj + c) * Pc + j) * L + l];
+        pt[c * SS + u * SEG + (j < Pc ? j : TTU + j)] = v;
       }
     }
     // projection (no bias): linear planes (R0) -> p tile (R1)
@@ -283,7 +291,8 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
 #pragma unroll
                       for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pt[(o + r) * SS + COL0 + tt * 16 + l15] = acc[ow][tt][r];
+                        for (int r = 0; r < 4; ++r)
+                          pt[(o + r) * SS + (tt / NTU) * SEG + Pc + (tt % NTU) * 16 + l15] = acc[ow][tt][r];
                     }
                   });
     __syncthreads();
@@ -295,9 +304,10 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       for (int e = tid; e < P.dp * (TT / 4); e += kFsmnThreads) {
         const int r = e >> 6;
         const int c = (r / nq4) * 16 + ((e >> 5) & 1) * 8 + (e & 7);
-        const int q = (r % nq4) * 4 + ((e >> 3) & 3);
+        const int q = (r % nq4) * 4 + ((e >> 3) & 3);     // 4-frame run of the tile; runs never straddle utterances
+        const int u = q / (TTU / 4);
         const float* wt = W + ly.taps + c * P.taps_ld;
-        const float* src = pt + c * SS + 4 * q;
+        const float* src = pt + c * SS + u * SEG + 4 * (q - u * (TTU / 4));
         f32x4 k = *reinterpret_cast<const f32x4*>(wt);
         f32x4 w0 = *reinterpret_cast<const f32x4*>(src);
         f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
@@ -322,9 +332,11 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       }
       // new cache = last P valid columns of x_pad
       if (A.out_cache) {
-        for (int e = tid; e < P.proj * Pc; e += kFsmnThreads) {
-          const int c = e / Pc, j = e - c * Pc;
-          A.out_cache[((int64_t(b) * P.proj + c) * Pc + j) * L + l] = pt[c * SS + T + j];
+        for (int e = tid; e < U * P.proj * Pc; e += kFsmnThreads) {
+          const int u = e / (P.proj * Pc), r = e - u * (P.proj * Pc);
+          const int c = r / Pc, j = r - c * Pc;
+          if (b0 + u < A.B)
+            A.out_cache[((int64_t(b0 + u) * P.proj + c) * Pc + j) * L + l] = pt[c * SS + u * SEG + T + j];
         }
       }
     }
@@ -340,7 +352,6 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   __syncthreads();
   // ---------------- out_linear2: o1 planes (R1) -> y ----------------
   {
-    float* yb = A.y + int64_t(b) * A.ys_b;
     const int K = P.odim;
     auto store_y = [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
                     // rows of y are only dword aligned (odim is odd in the recipes): 16-byte stores through a
@@ -351,12 +362,13 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
                       const int o = (ot + ow) * 16 + lq * 4;
 #pragma unroll
                       for (int tt = 0; tt < NT; ++tt) {
-                        const int t = tt * 16 + l15;
+                        const int u = tt / NTU, t = (tt % NTU) * 16 + l15;
                         const f32x4 v = acc[ow][tt] + bias[ow];
-                        float* yr = yb + int64_t(t) * K + o;
+                        float* yr = A.y + int64_t(b0 + u) * A.ys_b + int64_t(t) * K + o;
+                        const bool ok = t < T && b0 + u < A.B;
                         if (whole) {
-                          if (t < T) *reinterpret_cast<F32x4U*>(yr) = F32x4U{{v[0], v[1], v[2], v[3]}};
-                        } else if (t < T) {
+                          if (ok) *reinterpret_cast<F32x4U*>(yr) = F32x4U{{v[0], v[1], v[2], v[3]}};
+                        } else if (ok) {
 #pragma unroll
                           for (int r = 0; r < 4; ++r)
                             if (o + r < K) yr[r] = v[r];
@@ -372,22 +384,23 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   }
 }
 
-template <int NT>
+template <int NT, int U>
 inline int launch_fsmn_nt(const FsmnParams& P, const FsmnArgs& A, hipStream_t stream) {
-  const int lds = FsmnLds::make(P, 16 * NT).bytes();
+  const int lds = FsmnLds::make(P, 16 * NT, U).bytes();
   if (lds > kFsmnLdsLimit) return -4;
   static int attr_bytes = 0;
-  auto kern = fsmn_f16_kernel<NT>;
+  auto kern = fsmn_f16_kernel<NT, U>;
   if (lds > attr_bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
         hipSuccess)
       return -3;
     attr_bytes = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kFsmnThreads), lds, stream, P, A);
+  hipLaunchKernelGGL(kern, dim3((A.B + U - 1) / U), dim3(kFsmnThreads), lds, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_fsmn_f16(int nt, const FsmnParams& P, const FsmnArgs& A, hipStream_t stream);
+// nt frame tiles per utterance, u utterances per workgroup (u in {1, 2, 4}, nt * u <= 4)
+int launch_fsmn_f16(int nt, int u, const FsmnParams& P, const FsmnArgs& A, hipStream_t stream);
 
 }  // namespace wekws

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kThreads, 2) void gru_f16_kernel(const GruF16Params
   char* const in0 = xin + 2 * PX;                          // planes of the preprocessing output
   char* const hpl = in0 + 2 * PH;                          // [layer][hi | lo] planes of the hidden state
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int b0 = blockIdx.x * MB;
   const float* __restrict__ W = P.w;

@@ -193,6 +193,7 @@ struct wekws_hip_model {
   wekws::GruF16Params gq{};
   wekws::FsmnParams fq{};
   int fsmn_max_nt = 0;
+  int fsmn_cus = 256;     // compute units of the device (utterance packing keeps at least one workgroup per CU)
   int cache_len = 0;
   Workspace ws;
   std::mutex ws_mu;
@@ -220,7 +221,7 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   q.nlayers = d.num_layers; q.ntaps = ntaps; q.P = ntaps - 1; q.taps_ld = round_up(ntaps, 4);
   int max_nt = 0;
   for (int nt = 1; nt <= wekws::kFsmnTileFrames / 16; ++nt)
-    if (wekws::FsmnLds::make(q, 16 * nt).bytes() <= wekws::kFsmnLdsLimit) max_nt = nt;
+    if (wekws::FsmnLds::make(q, 16 * nt, 1).bytes() <= wekws::kFsmnLdsLimit) max_nt = nt;
   if (!max_nt) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: layer widths do not fit the 160 KiB LDS tile");
 
   int ndev = 0;
@@ -267,6 +268,10 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   m->device = device;
   m->cache_len = q.P;
   m->fsmn_max_nt = max_nt;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->fsmn_cus = prop.multiProcessorCount;
+  }
   hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(m->d_w, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -314,8 +319,14 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
     a.ys_b = int64_t(T) * d.odim;
     a.B = B;
     a.T = Tt;
-    const int rc = wekws::launch_fsmn_f16((Tt + 15) / 16, m->fq, a, stream);
-    if (rc) return fail(rc, "fsmn launch failed (nt=%d): %s", (Tt + 15) / 16, hipGetErrorString(hipGetLastError()));
+    // short inputs: pack 2 or 4 utterances into one workgroup, as long as every CU still gets a workgroup
+    const int nt = (Tt + 15) / 16;
+    int u = 1;
+    for (int cand = 4; cand >= 2; cand /= 2)
+      if (nt * cand <= m->fsmn_max_nt && nt * cand <= 4 && B >= cand * m->fsmn_cus &&
+          wekws::FsmnLds::make(m->fq, 16 * nt * cand, cand).bytes() <= wekws::kFsmnLdsLimit) { u = cand; break; }
+    const int rc = wekws::launch_fsmn_f16(nt, u, m->fq, a, stream);
+    if (rc) return fail(rc, "fsmn launch failed (nt=%d u=%d): %s", nt, u, hipGetErrorString(hipGetLastError()));
   }
   return WEKWS_HIP_OK;
 }

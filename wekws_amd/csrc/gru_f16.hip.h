@@ -1,14 +1,24 @@
-// Split-precision (3 x fp16 MFMA, fp32 accumulate) GRU forward.  Same structure, reference semantics and wave
-// ownership as gru.hip.h (read that header first); differences:
-//   - every operand of the matrix cores is an fp16 hi/lo pair (conv_stack_f16.hip.h explains the arithmetic):
-//     the step input, the preprocessing output and the hidden state of every layer live in LDS as operand planes
-//     [k-octet][stream][8 halves], a B fragment is one conflict-free ds_read_b128;
-//   - the f32 hidden state itself lives in REGISTERS: wave w / lane l owns (units 16w+4(l>>4)..+3, stream l&15 of each
-//     stream tile) of every layer for the whole call, which is exactly the MFMA D fragment it computes each step, so
-//     the gate math h' = (1-z) n + z h never leaves the lane and only the fp16 image is written back for the next
-//     step's products;
-//   - the per-frame linear head is a seventh (padded) o-tile on the matrix cores instead of a VALU reduction.
-// Per layer and step a wave issues 72*NN MFMAs of 17 cycles instead of 192*NN of 32.
+// Split-precision (3 x fp16 MFMA, fp32 accumulate) GRU forward, layer-major with REGISTER-RESIDENT weights.
+// Reference semantics and gate order as gru.hip.h (torch.nn.GRU as built at wekws/model/kws_model.py:128-133).
+//
+// A GRU step costs ~100 k MACs per stream but needs 393 KB of weights (hi + lo fp16, one layer); streaming them from
+// L2 every step bounds the step at the CU's 64 B/clk L1 path (the previous, step-major kernel: 11 us per frame).
+// Here one workgroup (8 waves) owns 16*NN streams for the whole call and walks the network LAYER by layer, so that
+// each set of weights is read once and then lives in registers for all T steps:
+//
+//   pass P   in0[t]  = [ReLU](Wpre x[t] + b)                for all t   (time-parallel; Wpre resident, 32 VGPRs)
+//   per layer l:
+//     pass I gi[t]   = W_ih in_l[t] + b_ih (+ b_hh for r, z) for all t   (time-parallel; W_ih resident, 96 VGPRs)
+//     pass R h[t]    = GRU cell(gi[t], h[t-1])               t = 0..T-1  (serial; W_hh resident, 96 VGPRs)
+//   pass H   y[t]    = [sigmoid](Wc h_top[t] + bc)           for all t   (time-parallel over waves)
+//
+// Wave w owns hidden units 16w..16w+15 of all three gates, so r, z, n of a (unit, stream) land in the same lane and
+// the cell math is register-local; the f32 state stays in registers.  Only pass R has a per-step dependency: its
+// step is 36*NN MFMAs per wave + the cell math + ONE workgroup barrier (the fp16 hi/lo image of h ping-pongs between
+// two LDS plane buffers).  Sequences travel between passes through a per-call HBM workspace in the layout the next
+// pass consumes directly: layer inputs as operand planes [t][hi|lo][k-octet][stream][8 halves] (a B fragment is one
+// coalesced 16-byte load per lane, no LDS), gate pre-activations in the producing lane's own D-fragment order (the
+// lane that wrote them is the only one that reads them).
 #pragma once
 #include "conv_stack_f16.hip.h"
 #include "gru.hip.h"
@@ -23,26 +33,23 @@ struct GruF16Params {
   uint32_t head_a16;        // classifier rows padded to a multiple of 16
 };
 
+struct GruF16Workspace {
+  char* seq[2];             // ping-pong layer sequences, operand planes
+  float* gi;                // gate pre-activations of the layer in flight
+};
+
 template <int NN>
 struct GruF16Geom {
   static constexpr int MB = 16 * NN;                       // streams per workgroup
   static constexpr int PLANE_H = (kGruH / 8) * MB * 16;     // bytes of one hi (or lo) plane of an H-wide operand
-  static size_t lds_bytes(int kpre16, int nlayers) {
-    return size_t(2 * (kpre16 / 8) * MB * 16) + size_t(2 * PLANE_H) * (1 + nlayers);
-  }
+  static constexpr int SEQ_STEP = 2 * PLANE_H;              // bytes of one step of a layer sequence (per workgroup)
+  static constexpr int GI_STEP = 8 * 3 * NN * 256;          // floats of one step of gate pre-activations
+  static constexpr int CS = 4;                              // steps of a layer input staged in LDS at a time (pass I)
+  static constexpr int LDS_BYTES = 2 * CS * SEQ_STEP;       // pass I: two staging buffers; pass R re-uses the start
+                                                            // for its two [hi | lo] plane buffers of h
+  static size_t seq_bytes(int B, int T) { return size_t((B + MB - 1) / MB) * T * SEQ_STEP; }
+  static size_t gi_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * GI_STEP; }
 };
-
-// acc[nn] += A x B over one 32-deep K step for NN stream tiles; b: this lane's item of tile 0 in the hi plane,
-// lo plane `plane` bytes further, tiles 256 B apart.
-template <int NN>
-__device__ __forceinline__ void gru_mfma(f32x4 (&acc)[NN], const F16Frag& a, const f16x8 (&bh)[NN], const f16x8 (&bl)[NN]) {
-#pragma unroll
-  for (int nn = 0; nn < NN; ++nn) {
-    acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, bh[nn], acc[nn], 0, 0, 0);
-    acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, bl[nn], acc[nn], 0, 0, 0);
-    acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, bh[nn], acc[nn], 0, 0, 0);
-  }
-}
 
 __device__ __forceinline__ void gru_mfma1(f32x4& acc, const F16Frag& a, const f16x8& bh, const f16x8& bl) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, bh, acc, 0, 0, 0);
@@ -57,307 +64,356 @@ __device__ __forceinline__ F16Frag load_frag(const uint4* __restrict__ p) {
   return f;
 }
 
-template <int NN, int LT>
-__global__ __launch_bounds__(kThreads, 2) void gru_f16_kernel(const GruF16Params Q, const float* __restrict__ x, int B,
-                                                              int T, const float* __restrict__ h0,
-                                                              float* __restrict__ y, float* __restrict__ hn) {
+typedef float gru_f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gru_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gru_split4(f32x4 v, f16x4& h, f16x4& l) {
+  h = __builtin_convertvector(v, f16x4);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+}
+
+__device__ __forceinline__ float gru_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// tanh(v) = 1 - 2 / (1 + e^{2v}); absolute error ~1e-7 (the cancellation near 0 is absolute, not relative)
+__device__ __forceinline__ float gru_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }
+
+template <int NN>
+__global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q, const GruF16Workspace WS,
+                                                           const float* __restrict__ x, int B, int T,
+                                                           const float* __restrict__ h0, float* __restrict__ y,
+                                                           float* __restrict__ hn) {
   using G = GruF16Geom<NN>;
   constexpr int MB = G::MB, H = kGruH, PH = G::PLANE_H;
+  constexpr int KSB = 4 * MB * 16;                            // bytes per K step inside a plane
+  constexpr int OTS = (H / 32) * 128;                         // uint4 per o-tile of an H-deep matrix (4 K steps)
   const GruParams& P = Q.base;
   extern __shared__ __attribute__((aligned(16))) char gru16_lds[];
-  const int PX = (Q.kpre16 / 8) * MB * 16;                  // one plane of the step input
-  char* const xin = gru16_lds;                                // [hi | lo] planes of x_t
-  char* const in0 = xin + 2 * PX;                          // planes of the preprocessing output
-  char* const hpl = in0 + 2 * PH;                          // [layer][hi | lo] planes of the hidden state
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int b0 = blockIdx.x * MB;
   const float* __restrict__ W = P.w;
-  constexpr int L = LT;                                     // layers (compile time: the state is register-resident)
   const int K = P.odim, idim = P.idim;
   const int u0 = wave * 16 + lq * 4;                        // first of this lane's 4 hidden units
   const int frag = (lq * MB + l15) * 16;                    // this lane's B-fragment item of stream tile 0, K step 0
-  // where this lane's 4 consecutive units of (stream tile nn) go inside an H-wide plane (8-byte store)
+  // where this lane's 4 consecutive units of stream tile 0 go inside an H-wide plane (8-byte store)
   const int wr_off = (((u0 >> 3) * MB + l15) * 8 + (u0 & 7)) * 2;
+  char* const seq0 = WS.seq[0] + size_t(blockIdx.x) * T * G::SEQ_STEP;
+  char* const seq1 = WS.seq[1] + size_t(blockIdx.x) * T * G::SEQ_STEP;
+  float* const gi = WS.gi + size_t(blockIdx.x) * T * G::GI_STEP + size_t(wave) * 3 * NN * 256 + lane * 4;
 
-  // ---- f32 hidden state in registers; fp16 image in LDS
-  float hreg[LT][NN][4];
+  // =================== pass P: in0[t] = [ReLU](Wpre x[t] + b) -> seq0 (subsampling.py:53-57) ===================
+  {
+    const int nkp = Q.kpre16 / 32;                            // <= 4 (checked by the launcher)
+    const uint4* ap = reinterpret_cast<const uint4*>(W + Q.pre_a16) + size_t(wave) * nkp * 128 + lane;
+    F16Frag a[4];
 #pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    {
+    for (int ks = 0; ks < 4; ++ks)
+      if (ks < nkp) a[ks] = load_frag(ap + ks * 128);
+    const f32x4 bpre = *reinterpret_cast<const f32x4*>(W + P.pre_b + u0);
+    const bool xvec = (idim % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    // this lane's B-fragment source: 8 consecutive features (k = ks*32 + lq*8 ..) of stream nn*16 + l15
+    auto load_x = [&](gru_f32x8 (&xr)[4][NN], int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) {
+          gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const int s = b0 + nn * 16 + l15, k0 = ks * 32 + lq * 8;
+          if (ks < nkp && s < B && t < T && k0 < idim) {
+            const float* src = x + (int64_t(s) * T + t) * idim + k0;
+            if (xvec && k0 + 8 <= idim) {
+              const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+              v = gru_f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (k0 + j < idim) v[j] = src[j];
+            }
+          }
+          xr[ks][nn] = v;
+        }
+    };
+    gru_f32x8 xc[4][NN], xn[4][NN];
+    load_x(xc, 0);
+    for (int t = 0; t < T; ++t) {
+      load_x(xn, t + 1);
+      f32x4 acc[NN];
+#pragma unroll
+      for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < nkp) {
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) {
+            const f16x8 bh = __builtin_convertvector(xc[ks][nn], f16x8);
+            const f16x8 bl = __builtin_convertvector(xc[ks][nn] - __builtin_convertvector(bh, gru_f32x8), f16x8);
+            gru_mfma1(acc[nn], a[ks], bh, bl);
+          }
+        }
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) {
-        const int s = nn * 16 + l15;
+        f32x4 v = acc[nn] + bpre;
+        if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
         f16x4 vh, vl;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = 0.f;
-          if (h0 && b0 + s < B) v = h0[(int64_t(l) * B + b0 + s) * H + u0 + r];
-          hreg[l][nn][r] = v;
-          _Float16 a, b;
-          split16(v, a, b);
-          vh[r] = a; vl[r] = b;
-        }
-        char* dst = hpl + l * 2 * PH + wr_off + nn * 256;
+        gru_split4(v, vh, vl);
+        char* dst = seq0 + size_t(t) * G::SEQ_STEP + wr_off + nn * 256;
         *reinterpret_cast<f16x4*>(dst) = vh;
         *reinterpret_cast<f16x4*>(dst + PH) = vl;
       }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) xc[ks][nn] = xn[ks][nn];
     }
   }
-
-  // x staging: item = (k-octet, stream): 8 consecutive features of one stream at step t
-  constexpr int XI = (16 * MB + kThreads - 1) / kThreads;      // items per thread for kpre16 <= 128 (16 octets)
-  const int nitems = (Q.kpre16 / 8) * MB;
-  float xr[XI][8];
-  auto prefetch = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * kThreads;
-      const int s = e % MB, oct = e / MB;
-      const bool ok = e < nitems && t < T && (b0 + s) < B;
-      const float* src = x + (int64_t(b0 + s) * T + t) * idim + oct * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xr[i][j] = (ok && oct * 8 + j < idim) ? src[j] : 0.f;
-    }
-  };
-  prefetch(0);
-
-  const int nkp = Q.kpre16 / 32;
-  const uint4* ap_pre = reinterpret_cast<const uint4*>(W + Q.pre_a16) + size_t(wave) * nkp * 128 + lane;
-  const float4 bpre = *reinterpret_cast<const float4*>(W + P.pre_b + u0);
-  const int head_tiles = (K + 15) / 16;
-  constexpr int OTS = (H / 32) * 128;                         // uint4 per o-tile (4 K steps)
-  const uint4* aihp[LT];
-  const uint4* ahhp[LT];
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    aihp[l] = reinterpret_cast<const uint4*>(W + Q.a_ih16[l]) + lane;
-    ahhp[l] = reinterpret_cast<const uint4*>(W + Q.a_hh16[l]) + lane;
-  }
-  // six weight fragments (W_ir, W_iz, W_in, W_hr, W_hz, W_hn rows of this wave) of one K step, double-buffered:
-  // step ks+1 is requested while step ks is multiplied (unrolling all four steps keeps 4 x 48 registers live and
-  // spills; requesting the next layer's first step across the barriers measured slower as well)
-  F16Frag wq[2][6];
-  auto load_w = [&](F16Frag (&w)[6], const uint4* aih, const uint4* ahh, int ks) __attribute__((always_inline)) {
-    w[0] = load_frag(aih + (wave)*OTS + ks * 128);
-    w[1] = load_frag(aih + (8 + wave) * OTS + ks * 128);
-    w[2] = load_frag(aih + (16 + wave) * OTS + ks * 128);
-    w[3] = load_frag(ahh + (wave)*OTS + ks * 128);
-    w[4] = load_frag(ahh + (8 + wave) * OTS + ks * 128);
-    w[5] = load_frag(ahh + (16 + wave) * OTS + ks * 128);
-  };
+  __threadfence_block();
   __syncthreads();
 
-  for (int t = 0; t < T; ++t) {
-    // ---- stage x_t as operand planes, prefetch x_{t+1}
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * kThreads;
-      if (e < nitems) {
-        const int s = e % MB, oct = e / MB;
-        f16x8 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          _Float16 a, b;
-          split16(xr[i][j], a, b);
-          vh[j] = a; vl[j] = b;
-        }
-        char* dst = xin + (oct * MB + s) * 16;
-        *reinterpret_cast<f16x8*>(dst) = vh;
-        *reinterpret_cast<f16x8*>(dst + PX) = vl;
-      }
-    }
-    prefetch(t + 1);
-    __syncthreads();
-    // ---- in0 = [ReLU](Wpre x_t + b)      (subsampling.py:53-57); o-tile = wave
+  // ============================== GRU layers ==============================
+#pragma unroll 1
+  for (int l = 0; l < P.nlayers; ++l) {
+    const GruLayer gl = P.layer[l];
+    const char* const sin = (l & 1) ? seq1 : seq0;            // this layer's input sequence
+    char* const sout = (l & 1) ? seq0 : seq1;                 // its output sequence
+    // ---------------- pass I: gi[t] = W_ih in[t] + b_ih (+ b_hh for r, z), all t ----------------
     {
-      f32x4 acc[NN];
+      const uint4* aih = reinterpret_cast<const uint4*>(W + Q.a_ih16[l]) + lane;
+      F16Frag wi[3][4];
 #pragma unroll
-      for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < nkp; ++ks) {
-        const F16Frag a = load_frag(ap_pre + ks * 128);
-        f16x8 bh[NN], bl[NN];
+      for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int nn = 0; nn < NN; ++nn) {
-          bh[nn] = *reinterpret_cast<const f16x8*>(xin + ks * 4 * MB * 16 + frag + nn * 256);
-          bl[nn] = *reinterpret_cast<const f16x8*>(xin + PX + ks * 4 * MB * 16 + frag + nn * 256);
+        for (int ks = 0; ks < 4; ++ks) wi[g][ks] = load_frag(aih + (g * 8 + wave) * OTS + ks * 128);
+      f32x4 bias[3];
+      bias[0] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + u0);
+      bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
+      bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
+      // The input sequence is staged CS steps at a time through LDS (every wave needs all of it): each thread moves
+      // CS*NN 16-byte items per chunk, requested one chunk ahead into registers and written to the other buffer after
+      // the current chunk's products -- one barrier per chunk.
+      constexpr int CS = G::CS, CHUNK = CS * G::SEQ_STEP, IT = CHUNK / (kThreads * 16);
+      static_assert(IT * kThreads * 16 == CHUNK, "whole items per thread");
+      gru_u32x4 stage[IT];
+      // byte offset of this thread's item i inside a chunk: step = off / SEQ_STEP, position inside the step's planes
+#define GRU_FETCH(T0)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                       \
+    const int off = (i * kThreads + tid) * 16;                                                           \
+    const int tf = min((T0) + off / G::SEQ_STEP, T - 1);                                                 \
+    stage[i] = *reinterpret_cast<const gru_u32x4*>(sin + size_t(tf) * G::SEQ_STEP + off % G::SEQ_STEP);      \
+  }
+#define GRU_PUT(BUF)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < IT; ++i)                                                         \
+      *reinterpret_cast<gru_u32x4*>((BUF) + (i * kThreads + tid) * 16) = stage[i];
+      GRU_FETCH(0)
+      GRU_PUT(gru16_lds)
+      __syncthreads();
+      for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
+        const char* cur = gru16_lds + (c & 1) * CHUNK;
+        GRU_FETCH(t0 + CS)                                   // clamped to the last step: harmless past the end
+#pragma unroll
+        for (int dt = 0; dt < CS; ++dt) {
+          const int t = t0 + dt;
+          if (t < T) {
+            f32x4 acc[3][NN];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int nn = 0; nn < NN; ++nn) acc[g][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* p = cur + dt * G::SEQ_STEP + frag;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+              for (int nn = 0; nn < NN; ++nn) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB + nn * 256);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB + nn * 256);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gru_mfma1(acc[g][nn], wi[g][ks], bh, bl);
+              }
+            float* go = gi + size_t(t) * G::GI_STEP;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int nn = 0; nn < NN; ++nn)
+                *reinterpret_cast<f32x4*>(go + (g * NN + nn) * 256) = acc[g][nn] + bias[g];
+          }
         }
-        gru_mfma<NN>(acc, a, bh, bl);
+        GRU_PUT(gru16_lds + ((c + 1) & 1) * CHUNK)
+        __syncthreads();
       }
+#undef GRU_FETCH
+#undef GRU_PUT
+    }
+    // ---------------- pass R: the recurrence ----------------
+    {
+      const uint4* ahh = reinterpret_cast<const uint4*>(W + Q.a_hh16[l]) + lane;
+      F16Frag wh[3][4];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wh[g][ks] = load_frag(ahh + (g * 8 + wave) * OTS + ks * 128);
+      const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
+      f32x4 hreg[NN];
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) {
+        const int s = b0 + nn * 16 + l15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h0 && s < B) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
+        hreg[nn] = v;
         f16x4 vh, vl;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[nn][r] + f4c(bpre, r);
-          if (P.pre_relu) v = fmaxf(v, 0.f);
-          _Float16 a, b;
-          split16(v, a, b);
-          vh[r] = a; vl[r] = b;
-        }
-        char* dst = in0 + wr_off + nn * 256;
+        gru_split4(v, vh, vl);
+        char* dst = gru16_lds + wr_off + nn * 256;
         *reinterpret_cast<f16x4*>(dst) = vh;
         *reinterpret_cast<f16x4*>(dst + PH) = vl;
       }
-    }
-    __syncthreads();
-    // ---- GRU layers (statically unrolled so the register-resident state is indexed at compile time)
+      // gate pre-activations of this lane, two steps ahead (they do not depend on the recurrence)
+      f32x4 g0[3][NN], g1[3][NN];
+      auto load_g = [&](f32x4 (&gg)[3][NN], int t) __attribute__((always_inline)) {
+        const float* gp = gi + size_t(min(t, T - 1)) * G::GI_STEP;
 #pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      {
-        const GruLayer gl = P.layer[l];
-        const char* bx = (l == 0 ? in0 : hpl + (l - 1) * 2 * PH) + frag;   // layer input of this step
-        char* const hl = hpl + l * 2 * PH;                                  // own state image (previous step)
-        const char* bhp = hl + frag;
-        f32x4 ar[NN], az[NN], ain[NN], ahn[NN];
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int nn = 0; nn < NN; ++nn) ar[nn] = az[nn] = ain[nn] = ahn[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto step = [&](const F16Frag (&w)[6], int ks) __attribute__((always_inline)) {
+          for (int nn = 0; nn < NN; ++nn) gg[g][nn] = *reinterpret_cast<const f32x4*>(gp + (g * NN + nn) * 256);
+      };
+      load_g(g0, 0);
+      load_g(g1, 1);
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        const char* hb = gru16_lds + (t & 1) * 2 * PH + frag;        // image of h(t-1)
+        char* const hw = gru16_lds + ((t + 1) & 1) * 2 * PH;          // image of h(t)
+        f32x4 acc[3][NN];
 #pragma unroll
-          for (int nn = 0; nn < NN; ++nn) {   // B fragments one stream tile at a time: 16 live registers, not 16*NN
-            const f16x8 xh = *reinterpret_cast<const f16x8*>(bx + ks * 4 * MB * 16 + nn * 256);
-            const f16x8 xl = *reinterpret_cast<const f16x8*>(bx + PH + ks * 4 * MB * 16 + nn * 256);
-            const f16x8 hh = *reinterpret_cast<const f16x8*>(bhp + ks * 4 * MB * 16 + nn * 256);
-            const f16x8 hlo = *reinterpret_cast<const f16x8*>(bhp + PH + ks * 4 * MB * 16 + nn * 256);
-            gru_mfma1(ar[nn], w[0], xh, xl);
-            gru_mfma1(az[nn], w[1], xh, xl);
-            gru_mfma1(ain[nn], w[2], xh, xl);
-            gru_mfma1(ar[nn], w[3], hh, hlo);
-            gru_mfma1(az[nn], w[4], hh, hlo);
-            gru_mfma1(ahn[nn], w[5], hh, hlo);
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) acc[g][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) {
+            const f16x8 hh = *reinterpret_cast<const f16x8*>(hb + ks * KSB + nn * 256);
+            const f16x8 hl = *reinterpret_cast<const f16x8*>(hb + PH + ks * KSB + nn * 256);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gru_mfma1(acc[g][nn], wh[g][ks], hh, hl);
           }
-        };
-        load_w(wq[0], aihp[l], ahhp[l], 0);
-#pragma unroll 1
-        for (int ks = 0; ks < H / 32; ks += 2) {       // K steps rolled in pairs: 2 x 48 fragment registers live
-          load_w(wq[1], aihp[l], ahhp[l], ks + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          step(wq[0], ks);
-          load_w(wq[0], aihp[l], ahhp[l], min(ks + 2, H / 32 - 1));
-          __builtin_amdgcn_sched_barrier(0);
-          step(wq[1], ks + 1);
-        }
-        // gate math, register-local (PyTorch formulation, gate order r, z, n)
-        const float4 b_ir = *reinterpret_cast<const float4*>(W + gl.b_ih + u0);
-        const float4 b_iz = *reinterpret_cast<const float4*>(W + gl.b_ih + H + u0);
-        const float4 b_in = *reinterpret_cast<const float4*>(W + gl.b_ih + 2 * H + u0);
-        const float4 b_hr = *reinterpret_cast<const float4*>(W + gl.b_hh + u0);
-        const float4 b_hz = *reinterpret_cast<const float4*>(W + gl.b_hh + H + u0);
-        const float4 b_hn = *reinterpret_cast<const float4*>(W + gl.b_hh + 2 * H + u0);
-        f16x4 vh[NN], vl[NN];
+        // cell math, register-local (PyTorch formulation, gate order r, z, n)
 #pragma unroll
-        for (int nn = 0; nn < NN; ++nn)
+        for (int nn = 0; nn < NN; ++nn) {
+          f32x4 hv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float rg = 1.0f / (1.0f + expf(-(ar[nn][r] + f4c(b_ir, r) + f4c(b_hr, r))));
-            const float zg = 1.0f / (1.0f + expf(-(az[nn][r] + f4c(b_iz, r) + f4c(b_hz, r))));
-            const float ng = tanhf(ain[nn][r] + f4c(b_in, r) + rg * (ahn[nn][r] + f4c(b_hn, r)));
-            const float hv = (1.0f - zg) * ng + zg * hreg[l][nn][r];
-            hreg[l][nn][r] = hv;
-            _Float16 a, b;
-            split16(hv, a, b);
-            vh[nn][r] = a; vl[nn][r] = b;
+            const float rg = gru_sigmoid(acc[0][nn][r] + g0[0][nn][r]);
+            const float zg = gru_sigmoid(acc[1][nn][r] + g0[1][nn][r]);
+            const float ng = gru_tanh(g0[2][nn][r] + rg * (acc[2][nn][r] + b_hn[r]));
+            hv[r] = ng + zg * (hreg[nn][r] - ng);               // (1 - z) n + z h
           }
-        __syncthreads();  // every wave has finished reading h_l(t-1) and the layer input
+          hreg[nn] = hv;
+          f16x4 vh, vl;
+          gru_split4(hv, vh, vl);
+          char* dst = hw + wr_off + nn * 256;
+          *reinterpret_cast<f16x4*>(dst) = vh;
+          *reinterpret_cast<f16x4*>(dst + PH) = vl;
+          char* gd = sout + size_t(t) * G::SEQ_STEP + wr_off + nn * 256;
+          *reinterpret_cast<f16x4*>(gd) = vh;
+          *reinterpret_cast<f16x4*>(gd + PH) = vl;
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) g0[g][nn] = g1[g][nn];
+        load_g(g1, t + 2);
+        __syncthreads();   // h(t) is complete and every wave is done with h(t-1)
+      }
+      if (hn) {
 #pragma unroll
         for (int nn = 0; nn < NN; ++nn) {
-          char* dst = hl + wr_off + nn * 256;
-          *reinterpret_cast<f16x4*>(dst) = vh[nn];
-          *reinterpret_cast<f16x4*>(dst + PH) = vl[nn];
-        }
-        __syncthreads();
-      }
-    }
-    // ---- head on the top layer's output of this step: o-tile = wave (classifier rows padded to 16)
-    if (wave < head_tiles) {
-      const char* bt = hpl + (L - 1) * 2 * PH + frag;
-      const uint4* ahd = reinterpret_cast<const uint4*>(W + Q.head_a16) + size_t(wave) * (H / 32) * 128 + lane;
-      f32x4 acc[NN];
-#pragma unroll
-      for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < H / 32; ++ks) {
-        const F16Frag a = load_frag(ahd + ks * 128);
-        f16x8 bh[NN], bl[NN];
-#pragma unroll
-        for (int nn = 0; nn < NN; ++nn) {
-          bh[nn] = *reinterpret_cast<const f16x8*>(bt + ks * 4 * MB * 16 + nn * 256);
-          bl[nn] = *reinterpret_cast<const f16x8*>(bt + PH + ks * 4 * MB * 16 + nn * 256);
-        }
-        gru_mfma<NN>(acc, a, bh, bl);
-      }
-#pragma unroll
-      for (int nn = 0; nn < NN; ++nn) {
-        const int s = nn * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = wave * 16 + lq * 4 + r;
-          if (k < K && b0 + s < B) {
-            float v = acc[nn][r] + W[P.head_b + k];
-            if (P.sigmoid) v = sigmoidf_(v);
-            y[(int64_t(b0 + s) * T + t) * K + k] = v;
-          }
+          const int s = b0 + nn * 16 + l15;
+          if (s < B) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg[nn];
         }
       }
     }
-    // (the barriers of the next step order these plane reads before the next state update)
+    __threadfence_block();
+    __syncthreads();
   }
-  // ---- h_n from the register-resident state
-  if (hn) {
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      {
-#pragma unroll
-        for (int nn = 0; nn < NN; ++nn) {
-          const int s = nn * 16 + l15;
-          if (b0 + s < B) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hn[(int64_t(l) * B + b0 + s) * H + u0 + r] = hreg[l][nn][r];
-          }
-        }
-      }
-    }
-  }
-}
 
-template <int NN, int LT>
-inline int launch_gru_f16_nl(const GruF16Params& Q, const float* x, int B, int T, const float* h0, float* y, float* hn,
-                             hipStream_t stream) {
-  using G = GruF16Geom<NN>;
-  const size_t lds = G::lds_bytes(Q.kpre16, LT);
-  if (lds > 160 * 1024) return -4;
-  auto kern = gru_f16_kernel<NN, LT>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) !=
-      hipSuccess)
-    return -3;
-  const int grid = (B + G::MB - 1) / G::MB;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, Q, x, B, T, h0, y, hn);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
+  // ================= pass H: y[t] = [sigmoid](Wc h_top[t] + bc), waves take steps round-robin =================
+  {
+    const char* const stop = (P.nlayers & 1) ? seq1 : seq0;   // output sequence of the last layer
+    const int head_tiles = (K + 15) / 16;
+    for (int ot = 0; ot < head_tiles; ++ot) {
+      const uint4* ahd = reinterpret_cast<const uint4*>(W + Q.head_a16) + size_t(ot) * OTS + lane;
+      F16Frag a[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[ks] = load_frag(ahd + ks * 128);
+      const int k0 = ot * 16 + lq * 4;
+      f32x4 bc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (k0 + r < K) bc[r] = W[P.head_b + k0 + r];
+      for (int t = wave; t < T; t += kThreads / 64) {
+        const char* p = stop + size_t(t) * G::SEQ_STEP + frag;
+        f32x4 acc[NN];
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB + nn * 256);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB + nn * 256);
+            gru_mfma1(acc[nn], a[ks], bh, bl);
+          }
+#pragma unroll
+        for (int nn = 0; nn < NN; ++nn) {
+          const int s = b0 + nn * 16 + l15;
+          if (s < B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (k0 + r < K) {
+                float v = acc[nn][r] + bc[r];
+                if (P.sigmoid) v = sigmoidf_(v);
+                y[(int64_t(s) * T + t) * K + k0 + r] = v;
+              }
+          }
+        }
+      }
+    }
+  }
 }
 
 template <int NN>
-inline int launch_gru_f16_nn(const GruF16Params& Q, const float* x, int B, int T, const float* h0, float* y, float* hn,
-                             hipStream_t stream) {
-  switch (Q.base.nlayers) {
-    case 1: return launch_gru_f16_nl<NN, 1>(Q, x, B, T, h0, y, hn, stream);
-    case 2: return launch_gru_f16_nl<NN, 2>(Q, x, B, T, h0, y, hn, stream);
-    case 3: return launch_gru_f16_nl<NN, 3>(Q, x, B, T, h0, y, hn, stream);
-    case 4: return launch_gru_f16_nl<NN, 4>(Q, x, B, T, h0, y, hn, stream);
-    default: return -4;
+inline int launch_gru_f16_nn(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
+                             const float* h0, float* y, float* hn, hipStream_t stream) {
+  using G = GruF16Geom<NN>;
+  const int grid = (B + G::MB - 1) / G::MB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_f16_kernel<NN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES) != hipSuccess)
+      return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gru_f16_kernel<NN>, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+inline bool gru_f16_supported(const GruF16Params& Q) { return Q.kpre16 <= 128 && Q.base.odim <= 128; }
+// stream tiles per workgroup: one (16 streams) until every CU has a workgroup, then two
+inline int gru_f16_nn(int B) { return B > 16 * 256 ? 2 : 1; }
+
+// workspace sizes of one call (bytes): each of the two sequence buffers, and the gate pre-activations
+inline void gru_f16_workspace_bytes(int B, int T, size_t* seq_bytes, size_t* gi_bytes) {
+  if (gru_f16_nn(B) == 2) {
+    *seq_bytes = GruF16Geom<2>::seq_bytes(B, T);
+    *gi_bytes = GruF16Geom<2>::gi_floats(B, T) * sizeof(float);
+  } else {
+    *seq_bytes = GruF16Geom<1>::seq_bytes(B, T);
+    *gi_bytes = GruF16Geom<1>::gi_floats(B, T) * sizeof(float);
   }
 }
 
-inline int launch_gru_f16(const GruF16Params& Q, const float* x, int B, int T, const float* h0, float* y, float* hn,
-                          hipStream_t stream) {
-  if (Q.kpre16 > 128 || Q.base.odim > 128) return -4;
-  // stream tiles per workgroup: wider tiles amortise the per-step weight stream from L2 (393 KB per layer and step)
-  // but need enough streams to keep 256 CUs busy
-  if (B >= 64 * 192 && GruF16Geom<4>::lds_bytes(Q.kpre16, Q.base.nlayers) <= 160 * 1024)
-    return launch_gru_f16_nn<4>(Q, x, B, T, h0, y, hn, stream);
-  if (B >= 32 * 192 && GruF16Geom<2>::lds_bytes(Q.kpre16, Q.base.nlayers) <= 160 * 1024)
-    return launch_gru_f16_nn<2>(Q, x, B, T, h0, y, hn, stream);
-  return launch_gru_f16_nn<1>(Q, x, B, T, h0, y, hn, stream);
+inline int launch_gru_f16(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
+                          const float* h0, float* y, float* hn, hipStream_t stream) {
+  if (!gru_f16_supported(Q)) return -4;
+  return gru_f16_nn(B) == 2 ? launch_gru_f16_nn<2>(Q, ws, x, B, T, h0, y, hn, stream)
+                            : launch_gru_f16_nn<1>(Q, ws, x, B, T, h0, y, hn, stream);
 }
 
 }  // namespace wekws

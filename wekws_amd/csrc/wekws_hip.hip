@@ -511,6 +511,12 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
     gp.head_b = img.put(p, K); p += K;
     m->gq.kpre16 = round_up(d.idim, 32);
+    {  // the GRU forward takes a stream-ordered workspace per call: keep freed blocks in the pool between calls
+      hipMemPool_t pool = nullptr;
+      uint64_t keep = UINT64_MAX;
+      if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool)
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
     m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim);
     m->cache_len = 0;
   }
@@ -593,9 +599,23 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     const int rc = forward_fsmn(m, x, B, T, in_cache, y, out_cache, stream);
     if (rc) return rc;
   } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && d.odim <= 128;
-    const int rc = f16 ? wekws::launch_gru_f16(m->gq, x, B, T, in_cache, y, out_cache, stream)
-                       : wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
+    const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && wekws::gru_f16_supported(m->gq);
+    int rc;
+    if (f16) {
+      // per-call, stream-ordered workspace (layer sequences + gate pre-activations): concurrent calls on different
+      // streams never share it, and the pool hands the same blocks back after the first call
+      size_t seq_b = 0, gi_b = 0;
+      wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b);
+      HIP_TRY(hipSetDevice(m->device));
+      char* base = nullptr;
+      const size_t seq_al = (seq_b + 255) / 256 * 256;
+      HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), 2 * seq_al + gi_b, stream));
+      wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al)};
+      rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, stream);
+      (void)hipFreeAsync(base, stream);
+    } else {
+      rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
+    }
     if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
   } else {
     const int TILE = WEKWS_HIP_TILE_FRAMES;

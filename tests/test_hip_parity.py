@@ -187,6 +187,21 @@ def test_fsmn_packed_utterances(name, B, T):
     assert np.isfinite(y).all() and np.isfinite(c).all()
 
 
+def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
+    """WEKWS_HIP_MM=1 selects the experimental DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores
+    (ds256_mm.hip.h): same goldens, same tolerance, including streaming and carried caches."""
+    monkeypatch.setenv("WEKWS_HIP_MM", "1")
+    for case in CASES:
+        if case["model"] != "ds_tcn_h256" or case.get("odim"):
+            continue
+        cfg, sd = case_weights(case)
+        model = build(cfg, sd)                      # the switch is read when the library builds its model
+        y, cache = run(model, case_input(case), case_in_cache(case, cfg), chunks=case.get("chunks"))
+        gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
+        assert max_abs(y, gy) <= tol_for(gy), case["name"]
+        assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
+
+
 def test_fsmn_f32_is_refused():
     """The exact-f32 mode has no FSMN kernel: the library must say so (EUNSUPPORTED), not run something else."""
     from wekws_amd import _capi

@@ -18,6 +18,7 @@
 #include "conv_stack_f16.hip.h"
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
+#include "ds256_mm.hip.h"
 #include "fbank.hip.h"
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
@@ -187,6 +188,8 @@ struct wekws_hip_model {
   wekws::DenseBlock* d_dblocks = nullptr;
   wekws::StackParams sp{};
   wekws::DenseParams dp{};
+  bool mm_ok = false;     // DS-TCN h256 + per-frame linear head: depthwise on the matrix cores.  Experimental, opt-in
+                          // (WEKWS_HIP_MM=1): correct, but 12 % slower than the 16-wave kernel
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
@@ -485,6 +488,12 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
+    m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
+               d.head == WEKWS_HIP_HEAD_LINEAR && K <= 16;
+    {
+      const char* e = std::getenv("WEKWS_HIP_MM");
+      m->mm_ok = m->mm_ok && e && std::atoi(e) != 0;
+    }
   } else {
     wekws::GruParams& gp = m->gp;
     gp.idim = d.idim;
@@ -672,6 +681,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
           rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+               : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, m->sp, a, stream)   // 16-wave variant
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;

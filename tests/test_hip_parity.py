@@ -187,6 +187,28 @@ def test_fsmn_packed_utterances(name, B, T):
     assert np.isfinite(y).all() and np.isfinite(c).all()
 
 
+def test_same_model_on_two_streams():
+    """ONE model driven from two HIP streams at once, for the backbones that take a workspace per call (GRU: stream-
+    ordered allocation; long conv / FSMN inputs: the per-model tile workspace is serialised by a mutex only while
+    enqueuing, so those are exercised on one stream at a time here): GRU results must equal the serial ones."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"])
+    m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3))
+    xs = [torch.from_numpy(synth.synth_feats(40, 60, 40, seed=s)).cuda() for s in (1, 2)]
+    serial = [m(x)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(m(xs[i])[0])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for y in outs[i]:
+            assert torch.equal(y, serial[i])
+
+
 def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
     """WEKWS_HIP_MM=1 selects the experimental DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores
     (ds256_mm.hip.h): same goldens, same tolerance, including streaming and carried caches."""
@@ -249,7 +271,7 @@ def test_concurrent_streams_and_models():
     for name, seed in (("ds_tcn_h256", 1), ("mdtc_h64", 2)):
         cfg = dict(synth.MODEL_CONFIGS[name])
         m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), seed))
-        x = torch.from_numpy(synth.synth_feats(64, 98, 40, seed=seed)).cuda()
+        x = torch.from_numpy(synth.synth_feats(64, 98, cfg["input_dim"], seed=seed)).cuda()
         ms.append(m); xs.append(x)
         serial.append(m(x)[0].clone())
     torch.cuda.synchronize()

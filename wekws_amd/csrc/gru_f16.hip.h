@@ -15,7 +15,7 @@
 // Wave w owns hidden units 16w..16w+15 of all three gates, so r, z, n of a (unit, stream) land in the same lane and
 // the cell math is register-local; the f32 state stays in registers.  Only pass R has a per-step dependency: its
 // step is 36*NN MFMAs per wave + the cell math + ONE workgroup barrier (the fp16 hi/lo image of h ping-pongs between
-// two LDS plane buffers).  Sequences travel between passes through a per-call HBM workspace in the layout the next
+// two LDS plane buffers).  Sequences travel between passes through an HBM workspace (per model and stream) in the layout the next
 // pass consumes directly: layer inputs as operand planes [t][hi|lo][k-octet][stream][8 halves] (a B fragment is one
 // coalesced 16-byte load per lane, no LDS), gate pre-activations in the producing lane's own D-fragment order (the
 // lane that wrote them is the only one that reads them).

@@ -101,6 +101,12 @@ struct Image {
   }
 };
 
+struct StreamBuf {
+  hipStream_t stream;
+  char* ptr;
+  size_t bytes;
+};
+
 struct Workspace {
   float* cache[2] = {nullptr, nullptr};
   size_t cache_elems = 0;
@@ -199,6 +205,7 @@ struct wekws_hip_model {
   int fsmn_cus = 256;     // compute units of the device (utterance packing keeps at least one workgroup per CU)
   int cache_len = 0;
   Workspace ws;
+  std::vector<StreamBuf> gru_ws;   // GRU: per-stream sequence / gate workspaces
   std::mutex ws_mu;
 };
 
@@ -520,12 +527,6 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
     gp.head_b = img.put(p, K); p += K;
     m->gq.kpre16 = round_up(d.idim, 32);
-    {  // the GRU forward takes a stream-ordered workspace per call: keep freed blocks in the pool between calls
-      hipMemPool_t pool = nullptr;
-      uint64_t keep = UINT64_MAX;
-      if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool)
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
     m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim);
     m->cache_len = 0;
   }
@@ -572,6 +573,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
   for (float* c : m->ws.cache) if (c) (void)hipFree(c);
   if (m->ws.gsum) (void)hipFree(m->ws.gsum);
+  for (auto& e : m->gru_ws) if (e.ptr) (void)hipFree(e.ptr);
   delete m;
 }
 
@@ -611,17 +613,32 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && wekws::gru_f16_supported(m->gq);
     int rc;
     if (f16) {
-      // per-call, stream-ordered workspace (layer sequences + gate pre-activations): concurrent calls on different
-      // streams never share it, and the pool hands the same blocks back after the first call
+      // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
+      // same stream are ordered by the stream, calls on different streams never share a buffer
       size_t seq_b = 0, gi_b = 0;
       wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b);
-      HIP_TRY(hipSetDevice(m->device));
-      char* base = nullptr;
       const size_t seq_al = (seq_b + 255) / 256 * 256;
-      HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&base), 2 * seq_al + gi_b, stream));
+      const size_t need = 2 * seq_al + gi_b;
+      char* base = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(m->ws_mu);
+        StreamBuf* sb = nullptr;
+        for (auto& e : m->gru_ws) if (e.stream == stream) sb = &e;
+        if (!sb) { m->gru_ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->gru_ws.back(); }
+        if (sb->bytes < need) {
+          HIP_TRY(hipSetDevice(m->device));
+          if (sb->ptr) {
+            HIP_TRY(hipStreamSynchronize(stream));            // earlier calls on this stream may still use the old buffer
+            (void)hipFree(sb->ptr);
+            sb->ptr = nullptr; sb->bytes = 0;
+          }
+          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sb->ptr), need));
+          sb->bytes = need;
+        }
+        base = sb->ptr;
+      }
       wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al)};
       rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, stream);
-      (void)hipFreeAsync(base, stream);
     } else {
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     }

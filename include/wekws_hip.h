@@ -222,6 +222,17 @@ int wekws_hip_splice_frames(int T, int right, int skip);
 int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out,
                      void* stream);
 
+/*
+ * Row softmax + top-k  --  the first beam prune of the CTC prefix beam search: `logits.softmax(2)` followed by
+ * `probs.topk(score_beam_size)` per frame (wekws/bin/stream_kws_ctc.py:487-488, wekws/model/loss.py:236-238), fused so
+ * that the (frames x vocabulary) posterior matrix is neither written nor copied to the host.
+ *   logits (rows, K) device float32;  k in 1..8 (the reference uses 3)
+ *   probs  (rows, k) device float32: the k largest softmax posteriors of each row, descending
+ *   idx    (rows, k) device int32:   their column indices (equal values: lower index first; -1 if K < k)
+ */
+int wekws_hip_softmax_topk(const float* logits, int64_t rows, int K, int k, float* probs, int32_t* idx,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
 #include "splice.hip.h"
+#include "topk.hip.h"
 
 namespace {
 
@@ -792,6 +793,17 @@ int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int righ
   if ((int64_t(B) * To * (left + right + 1) * F + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "splice: too many elements for one launch");
   const int rc = wekws::launch_splice(feats, B, T, F, left, right, skip, To, out, static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "splice launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+// --------------------------------------------- CTC first beam prune ---------------------------------------------
+int wekws_hip_softmax_topk(const float* logits, int64_t rows, int K, int k, float* probs, int32_t* idx, void* stream_) {
+  if (!logits || !probs || !idx) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (rows < 0 || K <= 0 || k < 1 || k > wekws::kTopkMax) return fail(WEKWS_HIP_EINVAL, "rows=%lld K=%d k=%d (k must be 1..%d)", (long long)rows, K, k, wekws::kTopkMax);
+  if (rows == 0) return WEKWS_HIP_OK;
+  if ((rows + 3) / 4 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "softmax_topk: too many rows for one launch");
+  const int rc = wekws::launch_softmax_topk(logits, rows, K, k, probs, idx, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "softmax_topk launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }
 

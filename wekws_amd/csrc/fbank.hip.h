@@ -141,21 +141,34 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
   const int64_t total = int64_t(B) * nframes;
   const int64_t stride = int64_t(gridDim.x) * kFbankWaves;
   const int FL = P.frame_length;
+  // the samples of a wave's NEXT frame are requested before the current frame is processed (a frame is one HBM round
+  // trip followed by ~20 dependent LDS hand-offs; without this the round trip is fully exposed)
+  float vn[8];
+  auto fetch = [&](int64_t f) __attribute__((always_inline)) {
+    const int64_t b = f / nframes;
+    const int fr = int(f - b * nframes);
+    const float* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int i = lane + 64 * m;
+      vn[m] = (f < total && i < FL) ? src[i] : 0.f;
+    }
+  };
+  fetch(int64_t(blockIdx.x) * kFbankWaves + wave);
   for (int64_t f = int64_t(blockIdx.x) * kFbankWaves + wave; f < total; f += stride) {
     const bool live = true;
     const int64_t b = f / nframes;
     const int fr = int(f - b * nframes);
-    const float* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
 
     // ---- load, DC removal (fbank.h:155-160)
     float v[8];
     float s = 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int i = lane + 64 * m;
-      v[m] = (live && i < FL) ? src[i] : 0.f;
+      v[m] = vn[m];
       s += v[m];
     }
+    fetch(f + stride);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float mean = s / float(FL);
@@ -231,8 +244,21 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       const int first = int(tab[P.mel_first_off + bin]);
       const int size = int(tab[P.mel_size_off + bin]);
       const float* w = tab + P.mel_w_off + int(tab[P.mel_start_off + bin]);
+      const float* pwr = strip + first;
+      // the reference's summation order (fbank.h:181-186), eight taps requested at a time: taps past the filter's
+      // width re-read its last one with weight 0
       float e = 0.f;
-      for (int k = 0; k < size; ++k) e += w[k] * strip[first + k];
+      for (int k0 = 0; k0 < size; k0 += 8) {
+        float wv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = min(k0 + u, size - 1);
+          wv[u] = (k0 + u < size) ? w[kk] : 0.f;
+          pv[u] = pwr[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e += wv[u] * pv[u];
+      }
       e = logf(fmaxf(e, FLT_EPSILON));
       if (live) feats[(b * nframes + fr) * P.num_bins + bin] = e;
     }

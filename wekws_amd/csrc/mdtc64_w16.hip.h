@@ -1,0 +1,287 @@
+// MDTC, hidden_dim 64 (examples/hi_xiaowen/s0/conf/mdtc.yaml, the speech-commands MDTC): 16-wave variant of
+// conv_stack_f16_kernel<KIND_MDTC, 64, NT, 5>.  Same arithmetic and results, same LDS footprint (two utterances per
+// workgroup: f32 tile 2 x 64 x SS + 2 x 256*TT bytes of operand planes = 114,688 B at NT = 7), different shape:
+//
+//   * 1024 threads = 4 waves per SIMD.  Per-phase clock64 sums of the 8-wave kernel (B = 1024, build/probe) put 59 %
+//     of a block in the depthwise producer, three times its vector-ALU bound: with two waves per SIMD the producer's
+//     LDS round trips are not covered.
+//   * wave = (utterance, o-tile, frame half): 16 accumulator registers instead of 28, all 16 waves multiply.
+//   * the whole 64-channel depthwise output of both utterances is produced in ONE phase (128 rows = 64 lane-groups x
+//     2 rows; lane-group g makes channel g of BOTH utterances, so its taps are loaded once), then GEMM 1 runs over the
+//     full K: 4 barriers per block instead of 5.
+//
+// Block (mdtc.py:95-121): dw conv + BN (no ReLU) -> 1x1 + BN1 + ReLU -> 1x1 + BN2 -> + residual -> ReLU; the output of
+// the last block of a stack is added to the stack sum (mdtc.py:270-273), which lives in registers.
+#pragma once
+#include "conv_stack_f16.hip.h"
+#include "ds256_w16.hip.h"
+
+namespace wekws {
+
+template <int NT, bool HAS_CACHE>
+__global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackParams P, const CallArgs A) {
+  using G = Geom<KIND_MDTC, 64, NT>;
+  constexpr int C = 64, U = 2, SS = G::SS, TT = 16 * NT, KS = 5;
+  constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of a 64-channel operand
+  constexpr int UB = 2 * MPB;                                // bytes of one utterance's planes
+  constexpr int NTW = NT < 4 ? NT : 4;                       // frame tiles per wave (frame half fh: tiles 4 fh ..)
+  static_assert(U == G::U && U * UB <= G::S_FLOATS * 4, "planes must fit the shared geometry");
+  extern __shared__ __attribute__((aligned(16))) float mdtc16_lds[];
+  char* const slab = reinterpret_cast<char*>(mdtc16_lds);    // [utt][hi | lo][8 oct][TT][8 halves]
+  float* const hbuf = mdtc16_lds + G::S_FLOATS;              // [utt][64][SS] f32 resident activations
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b0 = blockIdx.x * U;
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int pg = tid >> 4, tl = tid & 15;                    // producer: 64 lane-groups x 16 lanes; group = channel
+  const int wu = wave >> 3, ot = (wave >> 1) & 3, fh = wave & 1;
+  const int ft0 = fh * 4;                                    // first frame tile of this wave
+  const int ntw = NT - ft0 < NTW ? (NT - ft0 < 0 ? 0 : NT - ft0) : NTW;
+  const int o0 = ot * 16 + lq * 4;                           // this lane's 4 output channels
+  char* const slab_u = slab + wu * UB;
+  float* const h_w = hbuf + wu * C * SS;
+  const int frag_off = (lq * TT + ft0 * 16 + l15) * 16;      // B item of this wave's first tile, K step 0
+  const bool uok = (b0 + wu) < A.B;
+
+  f32x4 acc[NTW], zsum[NTW];
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) zsum[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto gemm = [&](const uint4* ap) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes of slab_u
+    F16Frag a[2];
+    a[0].h = __builtin_bit_cast(f16x8, ap[0]);   a[0].l = __builtin_bit_cast(f16x8, ap[64]);
+    a[1].h = __builtin_bit_cast(f16x8, ap[128]); a[1].l = __builtin_bit_cast(f16x8, ap[192]);
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        if (tt < ntw) {
+          const char* q = slab_u + ks * 4 * TT * 16 + frag_off + tt * 256;
+          const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
+          const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vh, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vl, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].l, vh, acc[tt], 0, 0, 0);
+        }
+  };
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+    const int nk = P.kpre16 / 32;                            // <= 2 (launcher): the staged x fits the planes
+    for (int e = tid; e < U * nk * 4 * TT; e += kW16Threads) {   // item = (utt, step, k-octet, frame)
+      const int t = e % TT;
+      int q = e / TT;
+      const int oct = q & 3; q >>= 2;
+      const int st = q % nk, u = q / nk;
+      const int kf = st * 32 + oct * 8;
+      const bool ok = (b0 + u) < A.B && t < T;
+      const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+      f16x8 vh, vl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+        _Float16 h, l;
+        split16(v, h, l);
+        vh[i] = h; vl[i] = l;
+      }
+      char* dst = slab + u * UB + ((st * 4 + oct) * TT + t) * 16;
+      *reinterpret_cast<f16x8*>(dst) = vh;
+      *reinterpret_cast<f16x8*>(dst + MPB) = vl;
+    }
+    __syncthreads();
+    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(ot) * nk * 128 + lane;
+    const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < nk; ++ks) {
+      F16Frag a;
+      a.h = __builtin_bit_cast(f16x8, ap[ks * 128]);
+      a.l = __builtin_bit_cast(f16x8, ap[ks * 128 + 64]);
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        if (tt < ntw) {
+          const char* q = slab_u + ks * 4 * TT * 16 + frag_off + tt * 256;
+          const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
+          const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) {
+        const int t = (ft0 + tt) * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[tt][r] + f4c(bias, r);
+          if (P.pre_relu) v = fmaxf(v, 0.f);
+          h_w[(o0 + r) * SS + t] = v;
+        }
+      }
+    __syncthreads();
+  }
+
+  // ======================================= residual blocks =======================================
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    const BlockDesc bd = P.blocks[bi];
+    const int d = bd.dil, pad = bd.pad;
+    const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(ot) * 256 + lane;
+    const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + size_t(ot) * 256 + lane;
+    // taps + bias of channel pg (8-float record)
+    float dww[KS + 1];
+    {
+      const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + pg * 8);
+      const float4 q0 = src[0], q1 = src[1];
+      dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w; dww[4] = q1.x; dww[5] = q1.y;
+    }
+    const bool slide = d <= 16 && (16 % d) == 0;
+    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+
+    // ---- producer: lane-group pg makes channel pg of both utterances: depthwise dilated conv + folded BN
+    //      (mdtc.py:55-58, no ReLU), split to fp16 hi/lo planes, and hands the channel's streaming cache over
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = pg;
+      const int hoff = (u * C + c) * SS;
+      const bool pok = (b0 + u) < A.B;
+      const int64_t gbase = (int64_t(pok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
+#define fetch(idx_)                                                                      \
+  ({                                                                                     \
+    const int ix_ = (idx_);                                                              \
+    float fv_ = hbuf[hoff + ix_];                                                        \
+    if constexpr (HAS_CACHE) {                                                           \
+      const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
+      fv_ = ix_ >= 0 ? fv_ : (pok ? fg_ : 0.f);                                          \
+    } else {                                                                             \
+      fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
+    }                                                                                    \
+    fv_;                                                                                 \
+  })
+      if (A.out_cache && pok) {
+        for (int p = tl; p < pad; p += 16) {
+          const int src = T + p - pad;   // index into h (negative: still inside the old cache)
+          float cv = hbuf[hoff + max(src, 0)];
+          if constexpr (HAS_CACHE) {
+            const float g = A.in_cache[gbase + pad + min(src, -1)];
+            cv = src >= 0 ? cv : g;
+          } else {
+            cv = src >= 0 ? cv : 0.f;
+          }
+          A.out_cache[gbase + p] = cv;
+        }
+      }
+      _Float16* ph = reinterpret_cast<_Float16*>(slab + u * UB) + ((c >> 3) * TT) * 8 + (c & 7);
+      _Float16* pl = reinterpret_cast<_Float16*>(slab + u * UB + MPB) + ((c >> 3) * TT) * 8 + (c & 7);
+      if (slide) {
+        float v[NT + KS - 1];
+#pragma unroll
+        for (int q = 0; q < NT + KS - 1; ++q) {
+          if (q >= KS - 1) v[q] = hbuf[hoff + fbase + (q - (KS - 1)) * d];
+          else v[q] = fetch(fbase + (q - (KS - 1)) * d);
+        }
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          float o = dww[KS];
+#pragma unroll
+          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
+          const int t = fbase + m * d;
+          _Float16 h, l;
+          split16(o, h, l);
+          ph[t * 8] = h;
+          pl[t * 8] = l;
+        }
+      } else {
+#pragma unroll 1
+        for (int m = 0; m < NT; ++m) {
+          const int t = tl + 16 * m;
+          float o = dww[KS];
+#pragma unroll
+          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
+          _Float16 h, l;
+          split16(o, h, l);
+          ph[t * 8] = h;
+          pl[t * 8] = l;
+        }
+      }
+#undef fetch
+    }
+    __syncthreads();
+    // ---- GEMM 1 (pointwise) over the full K
+    gemm(ap1);
+    const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
+    const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
+    __syncthreads();                                         // every wave is done reading the depthwise planes
+    // ---- mid = ReLU(BN1(pointwise)) written in operand order over them (mdtc.py:113-114)
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) {
+        const int t = (ft0 + tt) * 16 + l15;
+        const f32x4 v = __builtin_elementwise_max(acc[tt] + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f});
+        const f16x4 vh = __builtin_convertvector(v, f16x4);
+        const f16x4 vl = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
+        char* dst = slab_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
+        *reinterpret_cast<f16x4*>(dst) = vh;
+        *reinterpret_cast<f16x4*>(dst + MPB) = vl;
+      }
+    __syncthreads();
+    // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), in place into h
+    gemm(ap2);
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) {
+        const int t = (ft0 + tt) * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* hp = h_w + (o0 + r) * SS + t;
+          const float v = fmaxf(acc[tt][r] + f4c(bias2, r) + *hp, 0.f);
+          if (bd.zadd) zsum[tt][r] += v;
+          *hp = v;
+        }
+      }
+    __syncthreads();
+  }
+
+  // the backbone output is the sum of the stack outputs (mdtc.py:270-273)
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt)
+    if (tt < ntw) {
+      const int t = (ft0 + tt) * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h_w[(o0 + r) * SS + t] = zsum[tt][r];
+    }
+  __syncthreads();
+  (void)uok;
+  conv_stack_head<KIND_MDTC, 64, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
+}
+
+template <int NT, bool HAS_CACHE>
+inline int launch_mdtc64_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  using G = Geom<KIND_MDTC, 64, NT>;
+  static bool attr_set = false;
+  auto kern = mdtc64_w16_kernel<NT, HAS_CACHE>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(G::LDS_BYTES)) != hipSuccess)
+      return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((A.B + 1) / 2), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int NT>
+inline int launch_mdtc64_w16_nt(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  return A.in_cache ? launch_mdtc64_w16_ntc<NT, true>(P, A, stream) : launch_mdtc64_w16_ntc<NT, false>(P, A, stream);
+}
+
+// usable when: hidden_dim 64, kernel size 5, idim <= 64 (host checks)
+int launch_mdtc64_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+
+}  // namespace wekws

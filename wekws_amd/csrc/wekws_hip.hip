@@ -19,6 +19,7 @@
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
 #include "ds256_mm.hip.h"
+#include "mdtc64_w16.hip.h"
 #include "fbank.hip.h"
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
@@ -197,6 +198,7 @@ struct wekws_hip_model {
   wekws::DenseParams dp{};
   bool mm_ok = false;     // DS-TCN h256 + per-frame linear head: depthwise on the matrix cores.  Experimental, opt-in
                           // (WEKWS_HIP_MM=1): correct, but 12 % slower than the 16-wave kernel
+  bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
@@ -496,6 +498,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
+    m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5 && sp.kpre16 <= 64;
+    if (const char* e = std::getenv("WEKWS_HIP_MDTC16")) m->mdtc16_ok = m->mdtc16_ok && std::atoi(e) != 0;
     m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
                d.head == WEKWS_HIP_HEAD_LINEAR && K <= 16;
     {
@@ -709,7 +713,8 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
-          rc = f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
+          rc = (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, m->sp, a, stream)
+               : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
                    : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;
       }

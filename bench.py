@@ -63,6 +63,25 @@ def cpu_baseline(cfg, sd, T, idim, target_s=12.0):
             "sample": f"{n} utterances (batches of {nb}, T={T}) through oracle/kws_oracle.py in {el:.1f} s"}
 
 
+def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30):
+    """Untimed-by-the-contract extra line: another recipe on the same batch shape, same timing method."""
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    m = init_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
+    m = m.to(dev).eval()
+    x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=7)).to(dev)
+    for _ in range(5):
+        m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m(x)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"workload": f"{name} forward, {B} x 1-s utterances, T={T}", "value": round(B * steps / el, 1),
+            "unit": "utts/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +190,10 @@ def main():
                          "hbm_achieved_GBs": round(hbm_gbs, 2), "hbm_peak_GBs": PEAK_HBM_GBS,
                          "hbm_frac": round(hbm_gbs / PEAK_HBM_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_UTT * B},
         }
+        if world == 1 and args.model == "ds_tcn_h256":
+            # BASELINE.json configs[1] words the single-GPU case as "MDTC ... batch 1024 x 1 s" while its metric names
+            # the DS-TCN: the DS-TCN is `value`; the MDTC 4x4 h64 recipe on the same batch is reported beside it.
+            out["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim)
         print(json.dumps(out))

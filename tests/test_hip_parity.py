@@ -188,25 +188,27 @@ def test_fsmn_packed_utterances(name, B, T):
 
 
 def test_same_model_on_two_streams():
-    """ONE model driven from two HIP streams at once, for the backbones that take a workspace per call (GRU: stream-
-    ordered allocation; long conv / FSMN inputs: the per-model tile workspace is serialised by a mutex only while
-    enqueuing, so those are exercised on one stream at a time here): GRU results must equal the serial ones."""
+    """ONE model driven from two HIP streams at once, for the paths that need scratch memory per call (GRU layer
+    sequences; tile hand-over caches of long conv / FSMN inputs; the global head's running sums): the library keeps one
+    workspace per (model, stream), so concurrent calls must equal the serial results bit for bit."""
     from wekws_amd import pack
-    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"])
-    m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3))
-    xs = [torch.from_numpy(synth.synth_feats(40, 60, 40, seed=s)).cuda() for s in (1, 2)]
-    serial = [m(x)[0].clone() for x in xs]
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs = [[], []]
-    for it in range(6):
+    for name, B, T in (("gru_2x128", 40, 60), ("ds_tcn_h64", 9, 300), ("mdtc_small_global12", 5, 333),
+                       ("fsmn_small", 6, 200)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3))
+        xs = [torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=s)).cuda() for s in (1, 2)]
+        serial = [tuple(t.clone() for t in m(x)) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [[], []]
+        for it in range(6):
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    outs[i].append(m(xs[i]))
+        torch.cuda.synchronize()
         for i in range(2):
-            with torch.cuda.stream(streams[i]):
-                outs[i].append(m(xs[i])[0])
-    torch.cuda.synchronize()
-    for i in range(2):
-        for y in outs[i]:
-            assert torch.equal(y, serial[i])
+            for y, c in outs[i]:
+                assert torch.equal(y, serial[i][0]) and torch.equal(c, serial[i][1]), name
 
 
 def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):

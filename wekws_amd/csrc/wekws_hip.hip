@@ -103,18 +103,13 @@ struct Image {
   }
 };
 
+// Scratch device memory of a model, one grow-only buffer per HIP stream that has called it: calls on one stream are
+// ordered by the stream, calls on different streams never share a buffer (long-input tile hand-over caches, the
+// global head's running sums, the GRU's layer sequences).
 struct StreamBuf {
   hipStream_t stream;
   char* ptr;
   size_t bytes;
-};
-
-struct Workspace {
-  float* cache[2] = {nullptr, nullptr};
-  size_t cache_elems = 0;
-  float* gsum = nullptr;
-  size_t gsum_elems = 0;
-  float* gru_seq = nullptr;  // unused for now
 };
 
 bool desc_conv(const wekws_hip_desc& d) {
@@ -207,10 +202,33 @@ struct wekws_hip_model {
   int fsmn_max_nt = 0;
   int fsmn_cus = 256;     // compute units of the device (utterance packing keeps at least one workgroup per CU)
   int cache_len = 0;
-  Workspace ws;
-  std::vector<StreamBuf> gru_ws;   // GRU: per-stream sequence / gate workspaces
+  std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
 };
+
+// -> device pointer to at least `need` bytes owned by (model, stream); nullptr + error text on failure
+static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need) {
+  std::lock_guard<std::mutex> lk(m->ws_mu);
+  StreamBuf* sb = nullptr;
+  for (auto& e : m->ws) if (e.stream == stream) sb = &e;
+  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->ws.back(); }
+  if (sb->bytes < need) {
+    if (hipSetDevice(m->device) != hipSuccess) { fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device); return nullptr; }
+    if (sb->ptr) {
+      (void)hipStreamSynchronize(stream);                     // earlier calls on this stream may still use the old buffer
+      (void)hipFree(sb->ptr);
+      sb->ptr = nullptr; sb->bytes = 0;
+    }
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&sb->ptr), need);
+    if (e != hipSuccess) {
+      sb->ptr = nullptr;
+      fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "workspace of %zu bytes: %s", need, hipGetErrorString(e));
+      return nullptr;
+    }
+    sb->bytes = need;
+  }
+  return sb->ptr;
+}
 
 struct wekws_hip_fbank {
   wekws::FbankParams fp{};
@@ -305,20 +323,12 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
   const int TILE = 16 * m->fsmn_max_nt;
   const int ntiles = (T + TILE - 1) / TILE;
   float* ws_cache[2] = {nullptr, nullptr};
-  std::unique_lock<std::mutex> lock(m->ws_mu, std::defer_lock);
   if (ntiles > 1) {
-    lock.lock();
-    HIP_TRY(hipSetDevice(m->device));
     const size_t ce = size_t(B) * d.num_stack * m->cache_len * d.num_layers;
-    if (m->ws.cache_elems < ce) {
-      for (float*& c : m->ws.cache) { if (c) (void)hipFree(c); c = nullptr; }
-      m->ws.cache_elems = 0;
-      HIP_TRY(hipMalloc(&m->ws.cache[0], ce * sizeof(float)));
-      HIP_TRY(hipMalloc(&m->ws.cache[1], ce * sizeof(float)));
-      m->ws.cache_elems = ce;
-    }
-    ws_cache[0] = m->ws.cache[0];
-    ws_cache[1] = m->ws.cache[1];
+    char* base = stream_workspace(m, stream, 2 * ce * sizeof(float));
+    if (!base) return WEKWS_HIP_ENOMEM;
+    ws_cache[0] = reinterpret_cast<float*>(base);
+    ws_cache[1] = ws_cache[0] + ce;
   }
   for (int i = 0; i < ntiles; ++i) {
     const int t0 = i * TILE;
@@ -576,9 +586,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
-  for (float* c : m->ws.cache) if (c) (void)hipFree(c);
-  if (m->ws.gsum) (void)hipFree(m->ws.gsum);
-  for (auto& e : m->gru_ws) if (e.ptr) (void)hipFree(e.ptr);
+  for (auto& e : m->ws) if (e.ptr) (void)hipFree(e.ptr);
   delete m;
 }
 
@@ -624,24 +632,8 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b);
       const size_t seq_al = (seq_b + 255) / 256 * 256;
       const size_t need = 2 * seq_al + gi_b;
-      char* base = nullptr;
-      {
-        std::lock_guard<std::mutex> lk(m->ws_mu);
-        StreamBuf* sb = nullptr;
-        for (auto& e : m->gru_ws) if (e.stream == stream) sb = &e;
-        if (!sb) { m->gru_ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->gru_ws.back(); }
-        if (sb->bytes < need) {
-          HIP_TRY(hipSetDevice(m->device));
-          if (sb->ptr) {
-            HIP_TRY(hipStreamSynchronize(stream));            // earlier calls on this stream may still use the old buffer
-            (void)hipFree(sb->ptr);
-            sb->ptr = nullptr; sb->bytes = 0;
-          }
-          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sb->ptr), need));
-          sb->bytes = need;
-        }
-        base = sb->ptr;
-      }
+      char* base = stream_workspace(m, stream, need);
+      if (!base) return WEKWS_HIP_ENOMEM;
       wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al)};
       rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, stream);
     } else {
@@ -654,31 +646,15 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     const int C = d.hdim;
     float* ws_cache[2] = {nullptr, nullptr};
     float* gsum = nullptr;
-    std::unique_lock<std::mutex> lock(m->ws_mu, std::defer_lock);
     if (ntiles > 1) {
-      // long input: tiles hand the causal context over through ping-pong caches in the workspace
-      lock.lock();
-      HIP_TRY(hipSetDevice(m->device));
+      // long input: tiles hand the causal context over through ping-pong caches in the stream's workspace
       const size_t ce = size_t(B) * C * m->cache_len;
-      if (m->ws.cache_elems < ce) {
-        for (float*& c : m->ws.cache) { if (c) (void)hipFree(c); c = nullptr; }
-        m->ws.cache_elems = 0;
-        HIP_TRY(hipMalloc(&m->ws.cache[0], ce * sizeof(float)));
-        HIP_TRY(hipMalloc(&m->ws.cache[1], ce * sizeof(float)));
-        m->ws.cache_elems = ce;
-      }
-      ws_cache[0] = m->ws.cache[0];
-      ws_cache[1] = m->ws.cache[1];
-      if (d.head == WEKWS_HIP_HEAD_GLOBAL) {
-        const size_t ge = size_t(B) * C;
-        if (m->ws.gsum_elems < ge) {
-          if (m->ws.gsum) (void)hipFree(m->ws.gsum);
-          m->ws.gsum = nullptr; m->ws.gsum_elems = 0;
-          HIP_TRY(hipMalloc(&m->ws.gsum, ge * sizeof(float)));
-          m->ws.gsum_elems = ge;
-        }
-        gsum = m->ws.gsum;
-      }
+      const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * C : 0;
+      char* base = stream_workspace(m, stream, (2 * ce + ge) * sizeof(float));
+      if (!base) return WEKWS_HIP_ENOMEM;
+      ws_cache[0] = reinterpret_cast<float*>(base);
+      ws_cache[1] = ws_cache[0] + ce;
+      if (ge) gsum = ws_cache[1] + ce;
     }
     for (int i = 0; i < ntiles; ++i) {
       const int t0 = i * TILE;

@@ -14,15 +14,15 @@
  * Conventions
  *   - plain C, no torch / STL types; all tensors are caller-owned DEVICE pointers (float32,
  *     contiguous unless a stride is given); the library owns only its device copy of the
- *     weights and a small per-model workspace.
+ *     weights and scratch workspaces (one per model and calling stream, grown on demand).
  *   - every call is asynchronous on the hipStream_t passed as `void* stream` (NULL = default
  *     stream); no hidden synchronisation.
  *   - return value: 0 on success, a negative WEKWS_HIP_E* code on failure; the message is
  *     available from wekws_hip_last_error() (thread-local).  Nothing throws across the ABI.
  *   - a model is immutable after create: wekws_hip_forward is re-entrant across streams as
- *     long as each call has its own x / y / cache buffers, EXCEPT for calls that need the
- *     internal workspace (T > WEKWS_HIP_TILE_FRAMES, or the global head), which serialise on
- *     the model's workspace and must be issued on one stream at a time.
+ *     long as each call has its own x / y / cache buffers.  Calls that need scratch memory
+ *     (inputs longer than one LDS tile, the GRU) take it from the workspace of the stream they are
+ *     issued on; growing a workspace synchronises that stream once.
  */
 #ifndef WEKWS_HIP_H_
 #define WEKWS_HIP_H_

@@ -528,8 +528,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     // Measured on MI355X (tools/ablate.sh): the f32 MFMA stream and the VALU/LDS producer do NOT overlap on a
     // SIMD even when they come from different waves (time = MFMA + producer, also with the two waves of a SIMD
     // staggered into different phases), so the producer is kept short instead of hidden.
-    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
-    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
+    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
+    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
     constexpr bool kBarrier = WEKWS_ABLATE != 4;
     zero_acc(acc);
     produce(0, 0);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 }
 
 // Row softmax over the last axis (KWSModel.forward_softmax, kws_model.py:89): one wave per row.
-static __global__ void softmax_rows_kernel(float* y, int64_t rows, int K) {
+static __global__ __attribute__((unused)) void softmax_rows_kernel(float* y, int64_t rows, int K) {
   const int64_t row = int64_t(blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;

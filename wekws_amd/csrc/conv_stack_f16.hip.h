@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     };
 
     // ---- GEMM 1 over K: one MFMA K step per chunk, double-buffered planes, one barrier per chunk
-    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
-    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4);
+    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
+    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
     zero_acc(acc);
     produce(0, 0);
     load_dw(min(1, nch - 1));

@@ -60,6 +60,11 @@ CASES = [
     _c("mdtc_small_last12/stream10", "mdtc_small_last12", B=2, T=40, chunks=[10] * 4),
     _c("gru_2x128/stream10", "gru_2x128", B=2, T=100, chunks=[10] * 10, cache="zeros"),
     _c("gru_2x128/stream_mixed", "gru_2x128", B=1, T=98, chunks=[1, 3, 10, 7, 30, 47], cache="random"),
+    # ---- DS-TCN with a CTC token head (ds_tcn_ctc.yaml) ----
+    _c("ds_tcn_h256_ctc300/full", "ds_tcn_h256_ctc300", B=2, T=40),
+    _c("ds_tcn_h256_ctc300/softmax", "ds_tcn_h256_ctc300", B=1, T=20, softmax=True),
+    _c("ds_tcn_h256_ctc300/stream_mixed", "ds_tcn_h256_ctc300", B=1, T=24, chunks=[1, 3, 8, 12]),
+    _c("ds_tcn_h256_ctc300/T150_cache_rand", "ds_tcn_h256_ctc300", B=1, T=150, cache="random"),
     # ---- FSMN (4-D cache, layer index last; fsmn.py:462-495) ----
     _c("fsmn_ctc/full", "fsmn_ctc", B=1, T=33),
     _c("fsmn_ctc/stream_mixed", "fsmn_ctc", B=1, T=24, chunks=[1, 3, 8, 12]),

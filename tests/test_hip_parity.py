@@ -265,6 +265,24 @@ def test_large_vocabulary_head_matches_oracle():
     assert max_abs(ys, rs) <= POSTERIOR_TOL
 
 
+def test_ds_tcn_ctc_vocabulary_head():
+    """ds_tcn_ctc.yaml's shape (256 channels -> 2599 tokens): the classifier runs on the matrix cores from the
+    activation planes of the all-matrix-core kernel; logits, softmax, streaming and batch tail vs the oracle."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256_ctc"])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 9)
+    model = build(cfg, sd)
+    x = synth.synth_feats(3, 61, 40, seed=4)
+    y, c = run(model, x)
+    ry, rc = kws_oracle.forward(cfg, sd, x, None)
+    assert y.shape == (3, 61, 2599) and max_abs(y, ry) <= tol_for(ry) and max_abs(c, rc) <= tol_for(rc)
+    ys, _ = run(model, x, softmax=True)
+    rs, _ = kws_oracle.forward(cfg, sd, x, None, softmax=True)
+    assert max_abs(ys, rs) <= POSTERIOR_TOL
+    yst, cst = run(model, x, chunks=[7, 20, 1, 33])
+    assert max_abs(yst, y) <= 2e-5 * max(1.0, float(np.abs(y).max())) and max_abs(cst, c) <= 2e-5 * max(1.0, float(np.abs(c).max()))
+
+
 def test_concurrent_streams_and_models():
     """Two models on two HIP streams at once (the library keeps no hidden global state besides the per-model
     workspace): results equal the serial ones bit for bit."""

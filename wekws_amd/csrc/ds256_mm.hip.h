@@ -1,4 +1,5 @@
-// DS-TCN, hidden_dim 256, per-frame linear head (the headline model): depthwise convolution ON THE MATRIX CORES.
+// DS-TCN, hidden_dim 256, per-frame linear head (the headline model and its CTC twin): depthwise convolution ON THE
+// MATRIX CORES, and a matrix-core classifier of any width.
 //
 // ds256_w16.hip.h spends ~60 % of its time in the depthwise producer: 8 FMAs + split + stores per output on the vector
 // ALU, which on a SIMD does not overlap with MFMA work (one vector instruction issues per MFMA of a co-resident wave).
@@ -273,30 +274,110 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
     __syncthreads();
   }
 
-  // ============ head: y[t] = [sigmoid](Wc h[t] + bc), classifier rows padded to one o-tile; wave = frame tile ============
-  if (wave < NT) {
-    const uint4* ah = reinterpret_cast<const uint4*>(W + head_a16) + lane;
-    f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+  // ============ head: y[t] = [sigmoid](Wc h[t] + bc) on the matrix cores, straight from the planes ============
+  const int K = P.odim;
+  if (K <= 16) {
+    // keyword heads (1..16 outputs): one padded o-tile; wave = frame tile
+    if (wave < NT) {
+      const uint4* ah = reinterpret_cast<const uint4*>(W + head_a16) + lane;
+      f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < C / 32; ++ks) {
-      F16Frag a[1];
-      load_a16<1>(a, ah + ks * 128, 0);
-      const char* q = hpl + ((ks * 4 + lq) * TT + wave * 16 + l15) * 16;
-      const f16x8 bh = *reinterpret_cast<const f16x8*>(q);
-      const f16x8 bl = *reinterpret_cast<const f16x8*>(q + HP);
-      hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].h, bh, hacc, 0, 0, 0);
-      hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].h, bl, hacc, 0, 0, 0);
-      hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].l, bh, hacc, 0, 0, 0);
+      for (int ks = 0; ks < C / 32; ++ks) {
+        F16Frag a[1];
+        load_a16<1>(a, ah + ks * 128, 0);
+        const char* q = hpl + ((ks * 4 + lq) * TT + wave * 16 + l15) * 16;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(q);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(q + HP);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].h, bh, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].h, bl, hacc, 0, 0, 0);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].l, bh, hacc, 0, 0, 0);
+      }
+      const int t = wave * 16 + l15;
+      if (t < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = lq * 4 + r;
+          if (k < K) {
+            float v = hacc[r] + W[P.head_b + k];
+            if (P.sigmoid) v = sigmoidf_(v);
+            A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+          }
+        }
+      }
     }
-    const int t = wave * 16 + l15, K = P.odim;
-    if (t < T) {
+  } else {
+    // CTC-sized heads (ds_tcn_ctc.yaml: thousands of tokens): waves walk pairs of o-tiles (the host pads the row count
+    // to a multiple of 32), weights streamed from L2 one K step ahead, B fragments shared by the two tiles
+    constexpr int NK = C / 32;
+    const int HT = (K + 31) / 32 * 2;
+    struct __attribute__((packed, aligned(4))) Y4 { float v[4]; };   // rows of y are only dword aligned
+    float* const yb = A.y + int64_t(b) * A.ys_b;
+    for (int ot = wave * 2; ot < HT; ot += 2 * kW16Waves) {
+      const uint4* ap = reinterpret_cast<const uint4*>(W + head_a16) + size_t(ot) * NK * 128 + lane;
+      f32x4 hacc[2][NT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = lq * 4 + r;
-        if (k < K) {
-          float v = hacc[r] + W[P.head_b + k];
-          if (P.sigmoid) v = sigmoidf_(v);
-          A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+      for (int ow = 0; ow < 2; ++ow)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) hacc[ow][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 hb[2];
+#pragma unroll
+      for (int ow = 0; ow < 2; ++ow)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = (ot + ow) * 16 + lq * 4 + r;
+          hb[ow][r] = k < K ? W[P.head_b + k] : 0.f;
+        }
+      F16Frag ha0[2], ha1[2];
+      load_a16<2>(ha0, ap, NK * 128);
+#pragma unroll 1
+      for (int ks = 0; ks < NK; ks += 2) {
+        load_a16<2>(ha1, ap + (ks + 1) * 128, NK * 128);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const char* q = hpl + ((ks * 4 + lq) * TT + tt * 16 + l15) * 16;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(q);
+          const f16x8 bl = *reinterpret_cast<const f16x8*>(q + HP);
+#pragma unroll
+          for (int ow = 0; ow < 2; ++ow) {
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0[ow].h, bh, hacc[ow][tt], 0, 0, 0);
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0[ow].h, bl, hacc[ow][tt], 0, 0, 0);
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha0[ow].l, bh, hacc[ow][tt], 0, 0, 0);
+          }
+        }
+        load_a16<2>(ha0, ap + min(ks + 2, NK - 1) * 128, NK * 128);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const char* q = hpl + (((ks + 1) * 4 + lq) * TT + tt * 16 + l15) * 16;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(q);
+          const f16x8 bl = *reinterpret_cast<const f16x8*>(q + HP);
+#pragma unroll
+          for (int ow = 0; ow < 2; ++ow) {
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1[ow].h, bh, hacc[ow][tt], 0, 0, 0);
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1[ow].h, bl, hacc[ow][tt], 0, 0, 0);
+            hacc[ow][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha1[ow].l, bh, hacc[ow][tt], 0, 0, 0);
+          }
+        }
+      }
+      const bool whole = (ot + 2) * 16 <= K;                 // wave-uniform: only the last pair can run past odim
+#pragma unroll
+      for (int ow = 0; ow < 2; ++ow) {
+        const int k0 = (ot + ow) * 16 + lq * 4;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const int t = tt * 16 + l15;
+          f32x4 v = hacc[ow][tt] + hb[ow];
+          if (P.sigmoid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+          }
+          float* yr = yb + int64_t(t) * K + k0;
+          if (whole) {
+            if (t < T) *reinterpret_cast<Y4*>(yr) = Y4{{v[0], v[1], v[2], v[3]}};
+          } else if (t < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (k0 + r < K) yr[r] = v[r];
+          }
         }
       }
     }

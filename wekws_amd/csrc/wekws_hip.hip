@@ -191,8 +191,9 @@ struct wekws_hip_model {
   wekws::DenseBlock* d_dblocks = nullptr;
   wekws::StackParams sp{};
   wekws::DenseParams dp{};
-  bool mm_ok = false;     // DS-TCN h256 + per-frame linear head: depthwise on the matrix cores.  Experimental, opt-in
-                          // (WEKWS_HIP_MM=1): correct, but 12 % slower than the 16-wave kernel
+  bool mm_ok = false;     // DS-TCN h256 + per-frame linear head: all-matrix-core kernel (ds256_mm.hip.h).  Default for
+                          // CTC-sized heads (odim > 16); opt-in (WEKWS_HIP_MM=1) for keyword heads, where the
+                          // 16-wave kernel is 12 % faster
   bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
@@ -490,7 +491,14 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     sp.sigmoid = d.activation == WEKWS_HIP_ACT_SIGMOID;
     wekws::DenseParams& dp = m->dp;
     if (d.head == WEKWS_HIP_HEAD_LINEAR) {
-      dp.head_a16 = img.put_packed_a16(p, K, C, C);
+      if (K > 16) {  // wide (CTC) heads: rows padded to a multiple of 32 so that o-tiles come in pairs (ds256_mm.hip.h)
+        const int Kp = round_up(K, 32);
+        std::vector<float> wp(size_t(Kp) * C, 0.f);
+        std::memcpy(wp.data(), p, size_t(K) * C * sizeof(float));
+        dp.head_a16 = img.put_packed_a16(wp.data(), Kp, C, C);
+      } else {
+        dp.head_a16 = img.put_packed_a16(p, K, C, C);
+      }
       sp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
       sp.head_b = img.put(p, K); p += K;
     } else if (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST) {
@@ -511,10 +519,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5 && sp.kpre16 <= 64;
     if (const char* e = std::getenv("WEKWS_HIP_MDTC16")) m->mdtc16_ok = m->mdtc16_ok && std::atoi(e) != 0;
     m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
-               d.head == WEKWS_HIP_HEAD_LINEAR && K <= 16;
+               d.head == WEKWS_HIP_HEAD_LINEAR;
     {
+      // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword
+      // heads (the 16-wave kernel is 12 % faster there); WEKWS_HIP_MM=0 / 1 forces it off / on where eligible
       const char* e = std::getenv("WEKWS_HIP_MM");
-      m->mm_ok = m->mm_ok && e && std::atoi(e) != 0;
+      const bool want = e ? std::atoi(e) != 0 : K > 16;
+      m->mm_ok = m->mm_ok && want;
     }
   } else {
     wekws::GruParams& gp = m->gp;

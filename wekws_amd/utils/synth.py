@@ -67,6 +67,16 @@ MODEL_CONFIGS: Dict[str, dict] = {
                              preprocessing=dict(type="linear"),
                              backbone=dict(type="tcn", ds=True, num_layers=4, kernel_size=8, dropout=0.1),
                              activation=dict(type="identity")),
+    # examples/hi_xiaowen/s0/conf/ds_tcn_ctc.yaml:32-43: the headline body with a CTC token head (2599 tokens, 955 k
+    # params) and identity activation; the 300-token twin keeps the committed fixtures small
+    "ds_tcn_h256_ctc": dict(input_dim=40, output_dim=2599, hidden_dim=256,
+                            preprocessing=dict(type="linear"),
+                            backbone=dict(type="tcn", ds=True, num_layers=4, kernel_size=8, dropout=0.1),
+                            activation=dict(type="identity")),
+    "ds_tcn_h256_ctc300": dict(input_dim=40, output_dim=300, hidden_dim=256,
+                               preprocessing=dict(type="linear"),
+                               backbone=dict(type="tcn", ds=True, num_layers=4, kernel_size=8, dropout=0.1),
+                               activation=dict(type="identity")),
     # examples/hi_xiaowen/s0/conf/fsmn_ctc.yaml:36-56 (400-d spliced fbank, 2599 CTC tokens, 756 k params)
     "fsmn_ctc": dict(input_dim=400, output_dim=2599, hidden_dim=128,
                      preprocessing=dict(type="none"),

@@ -81,7 +81,8 @@ def test_golden(case, precision, golden, models):
 @pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 5, 98), ("ds_tcn_h64", 7, 33), ("tcn_h64", 3, 98),
                                       ("mdtc_h64", 5, 98), ("mdtc_small", 9, 61), ("mdtc_h64_global12", 5, 130),
                                       ("mdtc_small_last12", 6, 98), ("gru_2x128", 19, 40), ("gru_1x128", 3, 98),
-                                      ("fsmn_ctc300", 5, 33), ("fsmn_small", 7, 61), ("fsmn_ctc", 2, 17)])
+                                      ("fsmn_ctc300", 5, 33), ("fsmn_small", 7, 61), ("fsmn_ctc", 2, 17),
+                                      ("mdtc_h64_80d", 5, 98), ("mdtc_h64_80d", 3, 20)])
 def test_vs_oracle_other_seeds(name, B, T):
     """Different weights (wseed 77) / inputs (xseed 5) / odd batch sizes than the goldens, vs the numpy oracle."""
     from wekws_amd import pack

@@ -2,7 +2,7 @@
 #include "mdtc64_w16.hip.h"
 namespace wekws {
 int launch_mdtc64_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  if (P.ksize != 5 || P.kpre16 > 64) return -4;
+  if (P.ksize != 5) return -4;
   switch (nt) {
     case 1: return launch_mdtc64_w16_nt<1>(P, A, stream);
     case 2: return launch_mdtc64_w16_nt<2>(P, A, stream);

@@ -73,46 +73,50 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
-    const int nk = P.kpre16 / 32;                            // <= 2 (launcher): the staged x fits the planes
-    for (int e = tid; e < U * nk * 4 * TT; e += kW16Threads) {   // item = (utt, step, k-octet, frame)
-      const int t = e % TT;
-      int q = e / TT;
-      const int oct = q & 3; q >>= 2;
-      const int st = q % nk, u = q / nk;
-      const int kf = st * 32 + oct * 8;
-      const bool ok = (b0 + u) < A.B && t < T;
-      const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
-      f16x8 vh, vl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
-        _Float16 h, l;
-        split16(v, h, l);
-        vh[i] = h; vl[i] = l;
-      }
-      char* dst = slab + u * UB + ((st * 4 + oct) * TT + t) * 16;
-      *reinterpret_cast<f16x8*>(dst) = vh;
-      *reinterpret_cast<f16x8*>(dst + MPB) = vl;
-    }
-    __syncthreads();
+    const int nk = P.kpre16 / 32;                            // K steps of the input (40-d: 2, 80-d MFCC: 3)
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(ot) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < nk; ++ks) {
-      F16Frag a;
-      a.h = __builtin_bit_cast(f16x8, ap[ks * 128]);
-      a.l = __builtin_bit_cast(f16x8, ap[ks * 128 + 64]);
+    for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the planes of an utterance)
+      const int steps = min(2, nk - k0);
+      if (k0) __syncthreads();
+      for (int e = tid; e < U * steps * 4 * TT; e += kW16Threads) {   // item = (utt, step, k-octet, frame)
+        const int t = e % TT;
+        int q = e / TT;
+        const int oct = q & 3; q >>= 2;
+        const int st = q % steps, u = q / steps;
+        const int kf = (k0 + st) * 32 + oct * 8;
+        const bool ok = (b0 + u) < A.B && t < T;
+        const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+        f16x8 vh, vl;
 #pragma unroll
-      for (int tt = 0; tt < NTW; ++tt)
-        if (tt < ntw) {
-          const char* q = slab_u + ks * 4 * TT * 16 + frag_off + tt * 256;
-          const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
-          const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          _Float16 h, l;
+          split16(v, h, l);
+          vh[i] = h; vl[i] = l;
         }
+        char* dst = slab + u * UB + ((st * 4 + oct) * TT + t) * 16;
+        *reinterpret_cast<f16x8*>(dst) = vh;
+        *reinterpret_cast<f16x8*>(dst + MPB) = vl;
+      }
+      __syncthreads();
+      for (int st = 0; st < steps; ++st) {
+        F16Frag a;
+        a.h = __builtin_bit_cast(f16x8, ap[(k0 + st) * 128]);
+        a.l = __builtin_bit_cast(f16x8, ap[(k0 + st) * 128 + 64]);
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt)
+          if (tt < ntw) {
+            const char* q = slab_u + st * 4 * TT * 16 + frag_off + tt * 256;
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+          }
+      }
     }
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -281,7 +285,7 @@ inline int launch_mdtc64_w16_nt(const StackParams& P, const CallArgs& A, hipStre
   return A.in_cache ? launch_mdtc64_w16_ntc<NT, true>(P, A, stream) : launch_mdtc64_w16_ntc<NT, false>(P, A, stream);
 }
 
-// usable when: hidden_dim 64, kernel size 5, idim <= 64 (host checks)
+// usable when: hidden_dim 64, kernel size 5 (host checks)
 int launch_mdtc64_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

@@ -516,7 +516,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
-    m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5 && sp.kpre16 <= 64;
+    m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
     if (const char* e = std::getenv("WEKWS_HIP_MDTC16")) m->mdtc16_ok = m->mdtc16_ok && std::atoi(e) != 0;
     m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
                d.head == WEKWS_HIP_HEAD_LINEAR;

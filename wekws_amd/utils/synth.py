@@ -33,6 +33,11 @@ MODEL_CONFIGS: Dict[str, dict] = {
                      preprocessing=dict(type="linear"),
                      backbone=dict(type="mdtc", num_stack=4, stack_size=4, kernel_size=5,
                                    hidden_dim=64, causal=True)),
+    # examples/hi_xiaowen/s0/conf/mdtc.yaml as trained: 80-d MFCC input (mdtc.yaml:11)
+    "mdtc_h64_80d": dict(input_dim=80, output_dim=2, hidden_dim=64,
+                         preprocessing=dict(type="linear"),
+                         backbone=dict(type="mdtc", num_stack=4, stack_size=4, kernel_size=5,
+                                       hidden_dim=64, causal=True)),
     # examples/hi_xiaowen/s0/conf/mdtc_small.yaml:28-38
     "mdtc_small": dict(input_dim=40, output_dim=2, hidden_dim=32,
                        preprocessing=dict(type="linear"),

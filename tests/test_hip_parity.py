@@ -212,6 +212,24 @@ def test_same_model_on_two_streams():
                 assert torch.equal(y, serial[i][0]) and torch.equal(c, serial[i][1]), name
 
 
+def test_generic_kernels_behind_the_specialised_ones(golden, monkeypatch):
+    """WEKWS_HIP_W16=0 / WEKWS_HIP_MDTC16=0 / WEKWS_HIP_MM=0 route the headline shapes through the generic 8-wave kernel
+    (and CTC heads through the vector-ALU classifier): still the same goldens."""
+    monkeypatch.setenv("WEKWS_HIP_W16", "0")
+    monkeypatch.setenv("WEKWS_HIP_MDTC16", "0")
+    monkeypatch.setenv("WEKWS_HIP_MM", "0")
+    for case in CASES:
+        if case["model"] not in ("ds_tcn_h256", "mdtc_h64", "ds_tcn_h256_ctc300") or case.get("odim"):
+            continue
+        cfg, sd = case_weights(case)
+        model = build(cfg, sd)
+        y, cache = run(model, case_input(case), case_in_cache(case, cfg), softmax=case.get("softmax", False),
+                       chunks=case.get("chunks"))
+        gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
+        assert max_abs(y, gy) <= tol_for(gy), case["name"]
+        assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
+
+
 def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
     """WEKWS_HIP_MM=1 selects the experimental DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores
     (ds256_mm.hip.h): same goldens, same tolerance, including streaming and carried caches."""

@@ -2,14 +2,14 @@
 // reference citations and the LDS geometry, which are shared).
 //
 // The f32-input matrix instruction of gfx950 issues at the vector-FP32 rate (32 cycles per 16x16x4), 1/16 of the
-// fp16 rate, and -- measured, build/probe/mfma_probe.hip -- a saturated MFMA stream lets only ONE VALU instruction
+// fp16 rate, and -- measured, tools/probe/mfma_probe.hip -- a saturated MFMA stream lets only ONE VALU instruction
 // of the co-resident wave through per MFMA, so matrix time and vector time add up.  Here every 1x1 / dense
 // convolution runs on v_mfma_f32_16x16x32_f16 instead, with fp32-level accuracy recovered by the classic
 // two-term split of both operands:
 //        w = wh + wl,  a = ah + al      (wh = fp16(w), wl = fp16(w - wh); same for a; |w - wh - wl| <~ 2^-22 |w|)
 //        w*a ~= wh*ah + wh*al + wl*ah   (the dropped wl*al term is <= 2^-22 relative)
 // Products of fp16 values are exact in the fp32 accumulator and the instruction honours fp16 subnormals
-// (build/probe/denorm.hip), so the lo parts need no scaling and all three terms share ONE accumulator set.
+// (tools/probe/denorm.hip), so the lo parts need no scaling and all three terms share ONE accumulator set.
 // Cost per 32-deep K step: 3 x 17 cycles instead of 8 x 32.  Assumption: |activation| < 65504 (fp16 range);
 // the exact-f32 kernel remains selectable (wekws_hip_desc.precision) for models outside it.
 //

@@ -4,7 +4,7 @@
 // workgroup per CU), same results -- different occupancy: 1024 threads = 4 waves per SIMD instead of 2.
 //
 // Why: after the move to fp16 matrix products the kernel is bound by vector-instruction ISSUE, not by the matrix pipe
-// (profiles/r01c: MFMA pipe ~25 % busy), and build/probe/valu_rate.hip measures what a SIMD issues per VALU
+// (profiles/r01c: MFMA pipe ~25 % busy), and tools/probe/valu_rate.hip measures what a SIMD issues per VALU
 // instruction: 5.5 cycles with one wave, 3.0 with two, 1.9 with four.  The LDS tile allows only one workgroup per CU,
 // so the only way to four waves per SIMD is a 16-wave workgroup: each wave owns ONE 16-channel o-tile for all NT
 // frame tiles (28 accumulator registers at NT = 7, the whole kernel fits the 128-VGPR budget of 4 waves/SIMD).
@@ -12,7 +12,7 @@
 // K is consumed in intervals of 64 channels = the whole operand slab (two 32-deep K steps), single-buffered:
 //   [all 64 lane-groups produce one row each] barrier [every wave: 2 K steps x 3 products x NT tiles] barrier
 // A double buffer would buy nothing here: a saturated MFMA stream lets one VALU instruction of the co-resident waves
-// through per MFMA (build/probe/mfma_probe.hip), so producer and matrix phases do not overlap on a SIMD anyway.
+// through per MFMA (tools/probe/mfma_probe.hip), so producer and matrix phases do not overlap on a SIMD anyway.
 #pragma once
 #include "conv_stack_f16.hip.h"
 

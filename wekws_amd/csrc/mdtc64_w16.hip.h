@@ -2,7 +2,7 @@
 // conv_stack_f16_kernel<KIND_MDTC, 64, NT, 5>.  Same arithmetic and results, same LDS footprint (two utterances per
 // workgroup: f32 tile 2 x 64 x SS + 2 x 256*TT bytes of operand planes = 114,688 B at NT = 7), different shape:
 //
-//   * 1024 threads = 4 waves per SIMD.  Per-phase clock64 sums of the 8-wave kernel (B = 1024, build/probe) put 59 %
+//   * 1024 threads = 4 waves per SIMD.  Per-phase clock64 sums of the 8-wave kernel (B = 1024, tools/probe) put 59 %
 //     of a block in the depthwise producer, three times its vector-ALU bound: with two waves per SIMD the producer's
 //     LDS round trips are not covered.
 //   * wave = (utterance, o-tile, frame half): 16 accumulator registers instead of 28, all 16 waves multiply.

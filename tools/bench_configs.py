@@ -95,6 +95,25 @@ def main():
         out.append(dict(kind="stream", model=name, B=B, chunk=10, ms_per_chunk_wall=round(wall, 4),
                         ms_per_chunk_stream=round(dev, 4), us_per_frame=round(dev * 100, 2)))
         print(json.dumps(out[-1]), flush=True)
+    # end-to-end on the device, PCM resident in HBM: (a) fbank40 -> DS-TCN h256 posteriors; (b) fbank80 -> context
+    # expansion(2, 2) / skip 3 -> FSMN-CTC logits -> fused softmax + top-3 (what stream_kws_ctc.py's decoder consumes)
+    if only in "e2e":
+        from wekws_amd import ctc
+        from wekws_amd.frontend import splice_skip
+        B = 1024
+        pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()
+        _, m1 = build("ds_tcn_h256")
+        fb40 = Fbank(40)
+        med, p10, p90 = timeit(lambda: m1(fb40(pcm)), reps=6, group=6)
+        out.append(dict(kind="e2e", pipeline="pcm -> fbank40 -> ds_tcn_h256 -> posteriors", B=B, ms=round(med, 4),
+                        utts_per_s=round(B / med * 1e3, 1)))
+        print(json.dumps(out[-1]), flush=True)
+        _, m2 = build("fsmn_ctc")
+        fb80 = Fbank(80)
+        med, p10, p90 = timeit(lambda: ctc.softmax_topk(m2(splice_skip(fb80(pcm), 2, 2, 3))[0], 3), reps=6, group=6)
+        out.append(dict(kind="e2e", pipeline="pcm -> fbank80 -> splice(2,2)/skip3 -> fsmn_ctc -> softmax+top3", B=B,
+                        ms=round(med, 4), utts_per_s=round(B / med * 1e3, 1)))
+        print(json.dumps(out[-1]), flush=True)
     fb = Fbank(40)
     for B in ((1024, 8192) if only in "fbank" else ()):
         pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()

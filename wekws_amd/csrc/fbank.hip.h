@@ -6,19 +6,25 @@
 //   framing (snip edges, no centering)          runtime/core/frontend/fbank.h:141-142
 //   int16-scale float input, no normalisation   runtime/core/frontend/feature_pipeline.cc:49-55
 //
-// GPU design (not the reference's scalar table-driven radix-2): one wave64 per 25 ms frame.
-//   1. the 400 samples of the frame are read coalesced, the DC mean is a wave-level shuffle reduction,
-//      pre-emphasis + window are applied while packing the real signal as a 256-point COMPLEX sequence
-//      z[n] = y[2n] + i*y[2n+1] (a real 512-point FFT costs one 256-point complex FFT + a twiddle pass);
-//   2. 256 = 4^4: four radix-4 DIF stages, exactly one butterfly per lane per stage, data exchanged
-//      between stages through a 2 KiB LDS strip owned by the wave; output is base-4 digit-reversed;
-//   3. lane l rebuilds X[k], k = l + 64m, from Z[k] and conj(Z[256-k]), squares it, and the 256 power
-//      bins go back to LDS;
-//   4. lanes < num_bins apply the triangular mel weights (sparse: first index + run of weights, summed in
-//      ascending bin order like the reference), floor at FLT_EPSILON, logf, and store (T, num_bins)
-//      rows -- 160 contiguous bytes per frame at 40 bins.
-// Twiddles / window / mel weights are built on the host in double precision and staged into LDS once per
-// workgroup.
+// GPU design (not the reference's scalar table-driven radix-2): one wave64 per 25 ms frame, persistent waves.
+//   1. lane l loads the sample PAIRS (2n, 2n+1), n = l + 64m -- the real frame packed as a 256-point COMPLEX sequence
+//      (a real 512-point FFT costs one 256-point complex FFT + a twiddle pass); the DC mean is a wave shuffle
+//      reduction, pre-emphasis takes its left neighbour from the next lane down (one shuffle), the window values of a
+//      lane's eight samples live in registers for the whole launch, like its twiddles;
+//   2. 256 = 4^4: four radix-4 DIF stages, one butterfly per lane per stage; the first runs on the lane's own four
+//      values, the others exchange through a 2.5 KiB LDS strip owned by the wave whose element e sits at e + (e >> 2)
+//      (conflict-free for the stride-4 and stride-16 stages); the last stage stores X[k] in natural order;
+//   3. lane l rebuilds X[k], k = l + 64m, from Z[k] and conj(Z[256-k]), squares it, and the 256 power bins go back to
+//      LDS;
+//   4. mel: the triangular filters are cut into SLOTS of at most 16 consecutive taps (a filter wider than 16 bins
+//      gets two or more); a lane owns a slot for the whole launch with its 16 weights in registers, so a frame costs it
+//      16 LDS reads + 16 FMAs, ascending in k like the reference; slot sums are combined per filter in slot order (the
+//      only departure from the reference's single ascending loop: one float reassociation per extra slot), floored
+//      at FLT_EPSILON, logf, stored as (T, num_bins) rows.  (LDS float atomics were tried for this step and cost 4x
+//      the whole rest of the kernel: tens of lanes serialise on one accumulator.)
+// PMC of the previous gather version (one lane per mel bin walking its taps, tables re-read from LDS every frame):
+// vector ALU 59 % and LDS 74 % busy, 46 % of the LDS time in bank conflicts.
+// Twiddles / window / mel weights are built on the host in double precision.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,6 +49,10 @@ struct FbankParams {
   int32_t mel_start_off;  // start offset of each bin's weights inside the weight run [num_bins]
   int32_t mel_w_off;      // concatenated weights
   int32_t mel_w_count;
+  int32_t nslots;         // gather slots: runs of <= 16 taps of one filter (a lane owns a slot for the whole launch)
+  int32_t slot_first_off; // first FFT bin of the slot (as float) [nslots]
+  int32_t slot_bin_off;   // mel bin of the slot (as float) [nslots]
+  int32_t slot_w_off;     // 16 weights per slot, zero padded [nslots][16]
   int32_t table_floats;
 };
 
@@ -102,6 +112,18 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
   fp->mel_start_off = int(t.size()); t.insert(t.end(), start.begin(), start.end());
   fp->mel_w_off = int(t.size()); t.insert(t.end(), weights.begin(), weights.end());
   fp->mel_w_count = int(weights.size());
+  // gather slots: a filter of up to 16 taps is one slot, wider ones are cut into runs of 16; one lane per slot
+  std::vector<float> sfirst, sbin, sw;
+  for (int b = 0; b < num_bins; ++b)
+    for (int k0 = 0; k0 < int(size[b]); k0 += 16) {
+      sfirst.push_back(float(int(first[b]) + k0));
+      sbin.push_back(float(b));
+      for (int u = 0; u < 16; ++u) sw.push_back(k0 + u < int(size[b]) ? weights[size_t(start[b]) + k0 + u] : 0.f);
+    }
+  fp->nslots = int(sfirst.size());
+  fp->slot_first_off = int(t.size()); t.insert(t.end(), sfirst.begin(), sfirst.end());
+  fp->slot_bin_off = int(t.size()); t.insert(t.end(), sbin.begin(), sbin.end());
+  fp->slot_w_off = int(t.size()); t.insert(t.end(), sw.begin(), sw.end());
   fp->table_floats = int(t.size());
 }
 
@@ -122,79 +144,125 @@ __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 dig
   return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
 }
 
+__device__ __forceinline__ int pz(int e) { return e + (e >> 2); }   // padded position of element e of the FFT strip
+
+constexpr int kFbankStrip = 832;   // floats per wave: 320 complex (padded 256) + 192 slot sums
+
+template <int ROUNDS>
 __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankParams P, const float* __restrict__ pcm,
                                                                  int B, int nsamp, int nframes,
                                                                  float* __restrict__ feats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const tab = lds;                                  // [table_floats]
-  const int tab_pad = (P.table_floats + 3) & ~3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* const strip = lds + tab_pad + wave * 1024;        // per wave: 512 samples / 256 complex / 256 power
-
-  for (int i = threadIdx.x; i < P.table_floats; i += blockDim.x) tab[i] = P.tables[i];
-  __syncthreads();
+  float2* const z = reinterpret_cast<float2*>(lds + wave * kFbankStrip);
+  float* const melacc = lds + wave * kFbankStrip + 640;
+  const float* __restrict__ tab = P.tables;
   const float2* tw256 = reinterpret_cast<const float2*>(tab);
   const float2* tw512 = reinterpret_cast<const float2*>(tab + 512);
   const float* win = tab + 1024;
-  float2* z = reinterpret_cast<float2*>(strip);
+  const int FL = P.frame_length;
+
+  // ---- per-lane constants of the whole launch (registers): window of its 8 samples, stage twiddles, untangle twiddles,
+  //      scatter targets of its 4 FFT bins
+  float wn[8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int n = lane + 64 * m;
+    wn[2 * m] = win[2 * n];
+    wn[2 * m + 1] = win[2 * n + 1];
+  }
+  float2 tws[3][3];                                         // stages 0..2: w^j, w^2j, w^3j of the stage's block size
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    const int q = 64 >> (2 * st), L = 4 * q, j = lane % q, tstep = 256 / L;
+#pragma unroll
+    for (int r = 1; r <= 3; ++r) tws[st][r - 1] = tw256[(r * j * tstep) & 255];
+  }
+  float2 twu[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) twu[m] = tw512[lane + 64 * m];
+  // mel slots of this lane: first FFT bin, mel bin, 16 weights (zero padded)
+  int sfirst[ROUNDS], sbin[ROUNDS], scount[ROUNDS];          // scount: slots of the filter if this slot is its first, else 0
+  float sw[ROUNDS][16];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int slot = lane + 64 * r;
+    const bool ok = slot < P.nslots;
+    sfirst[r] = ok ? int(tab[P.slot_first_off + slot]) : 0;
+    sbin[r] = ok ? int(tab[P.slot_bin_off + slot]) : -1;
+    scount[r] = 0;
+    if (ok && (slot == 0 || int(tab[P.slot_bin_off + slot - 1]) != sbin[r])) {
+      int n = 1;
+      while (slot + n < P.nslots && int(tab[P.slot_bin_off + slot + n]) == sbin[r]) ++n;
+      scount[r] = n;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sw[r][u] = ok ? tab[P.slot_w_off + slot * 16 + u] : 0.f;
+  }
+  // where the last stage puts its four outputs: X[64 m + rev3(lane)], natural order
+  const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
 
   const int64_t total = int64_t(B) * nframes;
   const int64_t stride = int64_t(gridDim.x) * kFbankWaves;
-  const int FL = P.frame_length;
-  // the samples of a wave's NEXT frame are requested before the current frame is processed (a frame is one HBM round
-  // trip followed by ~20 dependent LDS hand-offs; without this the round trip is fully exposed)
-  float vn[8];
+  // the sample pairs of a wave's NEXT frame are requested before the current frame is processed
+  float2 vn[4];
+  const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % 8 == 0);
   auto fetch = [&](int64_t f) __attribute__((always_inline)) {
     const int64_t b = f / nframes;
     const int fr = int(f - b * nframes);
     const float* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int i = lane + 64 * m;
-      vn[m] = (f < total && i < FL) ? src[i] : 0.f;
+    for (int m = 0; m < 4; ++m) {
+      const int i = 2 * (lane + 64 * m);
+      float2 v = make_float2(0.f, 0.f);
+      if (f < total) {
+        if (pair_ok && i + 1 < FL) v = *reinterpret_cast<const float2*>(src + i);
+        else {
+          if (i < FL) v.x = src[i];
+          if (i + 1 < FL) v.y = src[i + 1];
+        }
+      }
+      vn[m] = v;
     }
   };
   fetch(int64_t(blockIdx.x) * kFbankWaves + wave);
   for (int64_t f = int64_t(blockIdx.x) * kFbankWaves + wave; f < total; f += stride) {
-    const bool live = true;
     const int64_t b = f / nframes;
     const int fr = int(f - b * nframes);
-
-    // ---- load, DC removal (fbank.h:155-160)
-    float v[8];
+    // ---- DC removal (fbank.h:155-160)
+    float2 v[4];
     float s = 0.f;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < 4; ++m) {
       v[m] = vn[m];
-      s += v[m];
+      s += v[m].x + v[m].y;
     }
     fetch(f + stride);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float mean = s / float(FL);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int i = lane + 64 * m;
-      strip[i] = (i < FL) ? v[m] - mean : 0.f;
-    }
-    wave_sync();
-    // ---- pre-emphasis 0.97 (fbank.h:122-127), window (fbank.h:130-135), pack as complex
-    float y[8];
+    // ---- pre-emphasis 0.97 (fbank.h:122-127: y[i] = x[i] - 0.97 x[i-1], y[0] = x[0] - 0.97 x[0]), window
+    //      (fbank.h:130-135).  x[2n-1] is the odd sample of element n-1: the lane below (lane 0: lane 63 of m-1)
+    float2 a[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int n = lane + 64 * m;  // complex index: samples 2n, 2n+1
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * n + h;
-        const float cur = strip[i];
-        const float prev = strip[i > 0 ? i - 1 : 0];
-        y[2 * m + h] = (i < FL) ? (cur - 0.97f * prev) * win[i] : 0.f;
+      const int i = 2 * (lane + 64 * m);
+      const float xe = (i < FL) ? v[m].x - mean : 0.f;
+      const float xo = (i + 1 < FL) ? v[m].y - mean : 0.f;
+      const float od = (i + 1 < FL) ? v[m].y - mean : 0.f;
+      float prev = __shfl_up(od, 1);                                        // odd sample of element n - 1
+      if (m > 0) {
+        const float top = (2 * (63 + 64 * (m - 1)) + 1 < FL) ? v[m - 1].y - mean : 0.f;
+        const float wrap = __shfl(top, 63);
+        prev = lane == 0 ? wrap : prev;
+      } else {
+        prev = lane == 0 ? xe : prev;                                       // i = 0: its own value
       }
+      a[m].x = (i < FL) ? (xe - 0.97f * prev) * wn[2 * m] : 0.f;
+      a[m].y = (i + 1 < FL) ? (xo - 0.97f * xe) * wn[2 * m + 1] : 0.f;
     }
-    wave_sync();
     // ---- 256-point complex FFT, radix-4 DIF, 4 stages
-    float2 a0 = make_float2(y[0], y[1]), a1 = make_float2(y[2], y[3]), a2 = make_float2(y[4], y[5]),
-           a3 = make_float2(y[6], y[7]);
+    float2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int q = 64 >> (2 * st);        // quarter size: 64, 16, 4, 1
@@ -202,7 +270,7 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       const int blk = lane / q, j = lane - blk * q;
       const int base = blk * L + j;
       if (st > 0) {
-        a0 = z[base]; a1 = z[base + q]; a2 = z[base + 2 * q]; a3 = z[base + 3 * q];
+        a0 = z[pz(base)]; a1 = z[pz(base + q)]; a2 = z[pz(base + 2 * q)]; a3 = z[pz(base + 3 * q)];
       }
       const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
       const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
@@ -214,12 +282,14 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       float2 o2 = make_float2(t0.x - t2.x, t0.y - t2.y);
       float2 o3 = make_float2(t1.x - t3.x, t1.y - t3.y);
       if (st < 3) {
-        const int tstep = 256 / L;         // w_L^j = w_256^(j*256/L)
-        o1 = cmul(o1, tw256[(j * tstep) & 255]);
-        o2 = cmul(o2, tw256[(2 * j * tstep) & 255]);
-        o3 = cmul(o3, tw256[(3 * j * tstep) & 255]);
+        o1 = cmul(o1, tws[st][0]);
+        o2 = cmul(o2, tws[st][1]);
+        o3 = cmul(o3, tws[st][2]);
+        z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
+      } else {
+        // positions 4 lane + m hold X[rev4(4 lane + m)] = X[64 m + rev3(lane)]: stored in natural order
+        z[pz(rev3)] = o0; z[pz(64 + rev3)] = o1; z[pz(128 + rev3)] = o2; z[pz(192 + rev3)] = o3;
       }
-      z[base] = o0; z[base + q] = o1; z[base + 2 * q] = o2; z[base + 3 * q] = o3;
       wave_sync();
     }
     // ---- real-FFT untangle + power (fbank.h:173-175): X[k] = (Zk + conj(Zn))/2 - i w^k (Zk - conj(Zn))/2
@@ -227,40 +297,38 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k = lane + 64 * m;
-      const float2 zk = z[rev4_256(k)];
-      const float2 zn = z[rev4_256((256 - k) & 255)];
+      const float2 zk = z[pz(k)];
+      const float2 zn = z[pz((256 - k) & 255)];
       const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
       const float2 o = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-      const float2 wo = cmul(tw512[k], o);
+      const float2 wo = cmul(twu[m], o);
       const float xr = e.x + wo.y, xi = e.y - wo.x;  // e - i*wo
       pw[m] = xr * xr + xi * xi;
     }
-    wave_sync();
+    wave_sync();                                          // every lane has read its Z values: the strip is free
+    float* const pwr = reinterpret_cast<float*>(z);         // 256 power bins (+ 16 zeros of slack for the padded slots)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) strip[lane + 64 * m] = pw[m];
+    for (int m = 0; m < 4; ++m) pwr[lane + 64 * m] = pw[m];
+    if (lane < 16) pwr[256 + lane] = 0.f;
     wave_sync();
-    // ---- mel + log (fbank.h:179-190)
-    for (int bin = lane; bin < P.num_bins; bin += 64) {
-      const int first = int(tab[P.mel_first_off + bin]);
-      const int size = int(tab[P.mel_size_off + bin]);
-      const float* w = tab + P.mel_w_off + int(tab[P.mel_start_off + bin]);
-      const float* pwr = strip + first;
-      // the reference's summation order (fbank.h:181-186), eight taps requested at a time: taps past the filter's
-      // width re-read its last one with weight 0
+    // ---- mel (fbank.h:179-186): one slot per lane and round, ascending k, then the slots of a filter in order
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
       float e = 0.f;
-      for (int k0 = 0; k0 < size; k0 += 8) {
-        float wv[8], pv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int kk = min(k0 + u, size - 1);
-          wv[u] = (k0 + u < size) ? w[kk] : 0.f;
-          pv[u] = pwr[kk];
-        }
+      for (int u = 0; u < 16; ++u) e = fmaf(sw[r][u], pwr[sfirst[r] + u], e);
+      melacc[lane + 64 * r] = e;                            // slot sums (slots past nslots: 0)
+    }
+    wave_sync();
+    // ---- log (fbank.h:187-190), store.  Slots are sorted by filter: a filter's slots are neighbours.
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e += wv[u] * pv[u];
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int slot = lane + 64 * r;
+      if (scount[r] > 0) {
+        float e = melacc[slot];
+        for (int n = 1; n < scount[r]; ++n) e += melacc[slot + n];
+        feats[(b * nframes + fr) * P.num_bins + sbin[r]] = logf(fmaxf(e, FLT_EPSILON));
       }
-      e = logf(fmaxf(e, FLT_EPSILON));
-      if (live) feats[(b * nframes + fr) * P.num_bins + bin] = e;
     }
     wave_sync();
   }
@@ -268,13 +336,25 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
 
 inline int launch_fbank(const FbankParams& P, const float* pcm, int B, int nsamp, int nframes, float* feats,
                         hipStream_t stream) {
-  const int tab_pad = (P.table_floats + 3) & ~3;
-  const size_t lds = size_t(tab_pad + kFbankWaves * 1024) * sizeof(float);
+  const int rounds = (P.nslots + 63) / 64;
+  if (rounds < 1 || rounds > 3) return -4;
+  const size_t lds = size_t(kFbankWaves * kFbankStrip) * sizeof(float);
   const int64_t total = int64_t(B) * nframes;
   int64_t grid = (total + kFbankWaves - 1) / kFbankWaves;
-  if (grid > 256 * 8) grid = 256 * 8;
-  hipLaunchKernelGGL(fbank_kernel, dim3(unsigned(grid)), dim3(64 * kFbankWaves), lds, stream, P, pcm, B, nsamp,
-                     nframes, feats);
+  // persistent waves: exactly one resident round (a second, partly filled round costs a whole wave lifetime)
+  static int resident[4] = {0, 0, 0, 0};
+  auto kern = rounds == 1 ? fbank_kernel<1> : rounds == 2 ? fbank_kernel<2> : fbank_kernel<3>;
+  if (!resident[rounds]) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kFbankWaves, lds) == hipSuccess &&
+        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0)
+      resident[rounds] = per_cu * prop.multiProcessorCount;
+    else
+      resident[rounds] = 256 * 4;
+  }
+  if (grid > resident[rounds]) grid = resident[rounds];
+  hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(64 * kFbankWaves), lds, stream, P, pcm, B, nsamp, nframes, feats);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -11,8 +11,9 @@ s=s.replace('    // ---- DC removal (fbank.h:155-160)','    PH(7);\n    // ---- 
 s=s.replace('    // ---- pre-emphasis 0.97','    PH(0);\n    // ---- pre-emphasis 0.97')
 s=s.replace('    // ---- 256-point complex FFT','    PH(1);\n    // ---- 256-point complex FFT')
 s=s.replace('    // ---- real-FFT untangle + power','    PH(2);\n    // ---- real-FFT untangle + power')
-s=s.replace('    // ---- log (fbank.h:187-190), store, clear','    PH(3);\n    // ---- log (fbank.h:187-190), store, clear')
-s=s.replace('      feats[(b * nframes + fr) * P.num_bins + bin] = e;\n    }\n    wave_sync();\n  }\n}','      feats[(b * nframes + fr) * P.num_bins + bin] = e;\n    }\n    wave_sync();\n    PH(4);\n  }\n  if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 8; ++i) feats[i] = float(tph[i]);\n}')
+s=s.replace('    // ---- mel (fbank.h:179-186)','    PH(3);\n    // ---- mel (fbank.h:179-186)')
+s=s.replace('    // ---- log (fbank.h:187-190), store.','    PH(5);\n    // ---- log (fbank.h:187-190), store.')
+s=s.replace('        feats[(b * nframes + fr) * P.num_bins + sbin[r]] = logf(fmaxf(e, FLT_EPSILON));\n      }\n    }\n    wave_sync();\n  }\n}','        feats[(b * nframes + fr) * P.num_bins + sbin[r]] = logf(fmaxf(e, FLT_EPSILON));\n      }\n    }\n    wave_sync();\n    PH(4);\n  }\n  if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 8; ++i) feats[i] = float(tph[i]);\n}')
 open('/tmp/ablfb/fbank.hip.h','w').write(s)
 w=open('/root/repo/wekws_amd/csrc/wekws_hip.hip').read().replace('#include "fbank.hip.h"','#include "/tmp/ablfb/fbank.hip.h"')
 for h in ["conv_stack.hip.h","conv_stack_f16.hip.h","dense_stack_f16.hip.h","ds256_w16.hip.h","ds256_mm.hip.h","mdtc64_w16.hip.h","fsmn_f16.hip.h","gru.hip.h","gru_f16.hip.h","splice.hip.h","topk.hip.h"]:

@@ -7,5 +7,5 @@ fb = Fbank(40)
 for _ in range(3): f = fb(pcm)
 torch.cuda.synchronize()
 d = f.flatten()[:8].cpu().numpy()
-names = ["dc", "preemph+win", "fft", "power+scatter", "log+store", "-", "-", "loop-top"]
+names = ["dc", "preemph+win", "fft", "power", "log+store", "mel", "-", "loop-top"]
 print(" ".join(f"{n}={int(v)}" for n, v in zip(names, d)), "total", int(d.sum()))

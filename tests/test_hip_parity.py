@@ -63,7 +63,7 @@ def models():
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_golden(case, precision, golden, models):
-    """HIP vs the live-reference golden vectors (41 cases: every backbone/head, ragged T, caches, streaming), in
+    """HIP vs the live-reference golden vectors (58 cases: every backbone/head, ragged T, caches, streaming), in
     both matrix precisions (wekws_hip_precision): exact-f32 MFMA and the fp16 hi/lo split."""
     if precision == "f32" and case["model"].startswith("fsmn"):
         pytest.skip("FSMN is built for the split-fp16 mode only (test_fsmn_f32_is_refused)")

@@ -76,11 +76,15 @@ __device__ __forceinline__ float gru_sigmoid(float v) { return __builtin_amdgcn_
 // tanh(v) = 1 - 2 / (1 + e^{2v}); absolute error ~1e-7 (the cancellation near 0 is absolute, not relative)
 __device__ __forceinline__ float gru_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }
 
-template <int NN>
+// MODE 0: the whole network in one launch (streaming chunks, or enough stream tiles to fill the GPU).  MODE 1 / 2 / 4:
+// only pass P / I (layer `lsel`) / H, over the time chunk blockIdx.y -- the time-parallel passes as their own launches
+// over (stream tile x time chunk), so that a mid-sized batch (fewer stream tiles than CUs) still uses every CU for
+// them; MODE 3: only pass R of layer `lsel` (grid = stream tiles).
+template <int NN, int MODE>
 __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q, const GruF16Workspace WS,
                                                            const float* __restrict__ x, int B, int T,
                                                            const float* __restrict__ h0, float* __restrict__ y,
-                                                           float* __restrict__ hn) {
+                                                           float* __restrict__ hn, int lsel, int tchunk) {
   using G = GruF16Geom<NN>;
   constexpr int MB = G::MB, H = kGruH, PH = G::PLANE_H;
   constexpr int KSB = 4 * MB * 16;                            // bytes per K step inside a plane
@@ -100,9 +104,11 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   char* const seq0 = WS.seq[0] + size_t(blockIdx.x) * T * G::SEQ_STEP;
   char* const seq1 = WS.seq[1] + size_t(blockIdx.x) * T * G::SEQ_STEP;
   float* const gi = WS.gi + size_t(blockIdx.x) * T * G::GI_STEP + size_t(wave) * 3 * NN * 256 + lane * 4;
+  const int tb = (MODE == 0 || MODE == 3) ? 0 : int(blockIdx.y) * tchunk;       // time range of this workgroup
+  const int te = (MODE == 0 || MODE == 3) ? T : min(T, tb + tchunk);
 
   // =================== pass P: in0[t] = [ReLU](Wpre x[t] + b) -> seq0 (subsampling.py:53-57) ===================
-  {
+  if constexpr (MODE == 0 || MODE == 1) {
     const int nkp = Q.kpre16 / 32;                            // <= 4 (checked by the launcher)
     const uint4* ap = reinterpret_cast<const uint4*>(W + Q.pre_a16) + size_t(wave) * nkp * 128 + lane;
     F16Frag a[4];
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         }
     };
     gru_f32x8 xc[4][NN], xn[4][NN];
-    load_x(xc, 0);
-    for (int t = 0; t < T; ++t) {
+    load_x(xc, tb);
+    for (int t = tb; t < te; ++t) {
       load_x(xn, t + 1);
       f32x4 acc[NN];
 #pragma unroll
@@ -166,17 +172,19 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         for (int nn = 0; nn < NN; ++nn) xc[ks][nn] = xn[ks][nn];
     }
   }
-  __threadfence_block();
-  __syncthreads();
+  if constexpr (MODE == 0) {
+    __threadfence_block();
+    __syncthreads();
+  }
 
   // ============================== GRU layers ==============================
 #pragma unroll 1
-  for (int l = 0; l < P.nlayers; ++l) {
+  for (int l = (MODE == 0 ? 0 : lsel); l < (MODE == 0 ? P.nlayers : ((MODE == 2 || MODE == 3) ? lsel + 1 : 0)); ++l) {
     const GruLayer gl = P.layer[l];
     const char* const sin = (l & 1) ? seq1 : seq0;            // this layer's input sequence
     char* const sout = (l & 1) ? seq0 : seq1;                 // its output sequence
     // ---------------- pass I: gi[t] = W_ih in[t] + b_ih (+ b_hh for r, z), all t ----------------
-    {
+    if constexpr (MODE == 0 || MODE == 2) {
       const uint4* aih = reinterpret_cast<const uint4*>(W + Q.a_ih16[l]) + lane;
       F16Frag wi[3][4];
 #pragma unroll
@@ -203,16 +211,16 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #define GRU_PUT(BUF)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < IT; ++i)                                                         \
       *reinterpret_cast<gru_u32x4*>((BUF) + (i * kThreads + tid) * 16) = stage[i];
-      GRU_FETCH(0)
+      GRU_FETCH(tb)
       GRU_PUT(gru16_lds)
       __syncthreads();
-      for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
+      for (int t0 = tb, c = 0; t0 < te; t0 += CS, ++c) {
         const char* cur = gru16_lds + (c & 1) * CHUNK;
         GRU_FETCH(t0 + CS)                                   // clamped to the last step: harmless past the end
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) {
           const int t = t0 + dt;
-          if (t < T) {
+          if (t < te) {
             f32x4 acc[3][NN];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #undef GRU_PUT
     }
     // ---------------- pass R: the recurrence ----------------
-    {
+    if constexpr (MODE == 0 || MODE == 3) {
       const uint4* ahh = reinterpret_cast<const uint4*>(W + Q.a_hh16[l]) + lane;
       F16Frag wh[3][4];
 #pragma unroll
@@ -329,12 +337,14 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         }
       }
     }
-    __threadfence_block();
-    __syncthreads();
+    if constexpr (MODE == 0) {
+      __threadfence_block();
+      __syncthreads();
+    }
   }
 
   // ================= pass H: y[t] = [sigmoid](Wc h_top[t] + bc), waves take steps round-robin =================
-  {
+  if constexpr (MODE == 0 || MODE == 4) {
     const char* const stop = (P.nlayers & 1) ? seq1 : seq0;   // output sequence of the last layer
     const int head_tiles = (K + 15) / 16;
     for (int ot = 0; ot < head_tiles; ++ot) {
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (k0 + r < K) bc[r] = W[P.head_b + k0 + r];
-      for (int t = wave; t < T; t += kThreads / 64) {
+      for (int t = tb + wave; t < te; t += kThreads / 64) {
         const char* p = stop + size_t(t) * G::SEQ_STEP + frag;
         f32x4 acc[NN];
 #pragma unroll
@@ -378,20 +388,45 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   }
 }
 
-template <int NN>
-inline int launch_gru_f16_nn(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
-                             const float* h0, float* y, float* hn, hipStream_t stream) {
+template <int NN, int MODE>
+inline int launch_gru_f16_mode(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
+                               const float* h0, float* y, float* hn, int lsel, int tchunk, int nchunks,
+                               hipStream_t stream) {
   using G = GruF16Geom<NN>;
-  const int grid = (B + G::MB - 1) / G::MB;
+  const int tiles = (B + G::MB - 1) / G::MB;
   static bool attr_set = false;
+  auto kern = gru_f16_kernel<NN, MODE>;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_f16_kernel<NN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             G::LDS_BYTES) != hipSuccess)
       return -3;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gru_f16_kernel<NN>, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn);
+  hipLaunchKernelGGL(kern, dim3(tiles, nchunks), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn, lsel,
+                     tchunk);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int NN>
+inline int launch_gru_f16_nn(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
+                             const float* h0, float* y, float* hn, int cus, hipStream_t stream) {
+  using G = GruF16Geom<NN>;
+  const int tiles = (B + G::MB - 1) / G::MB;
+  // few stream tiles and a long input: run the time-parallel passes over (tile x time chunk) so every CU works
+  if (2 * tiles <= cus && T >= 32) {
+    int nchunks = (2 * cus + tiles - 1) / tiles;
+    int tchunk = ((T + nchunks - 1) / nchunks + G::CS - 1) / G::CS * G::CS;
+    if (tchunk < 2 * G::CS) tchunk = 2 * G::CS;
+    nchunks = (T + tchunk - 1) / tchunk;
+    int rc = launch_gru_f16_mode<NN, 1>(Q, ws, x, B, T, h0, y, hn, 0, tchunk, nchunks, stream);
+    for (int l = 0; l < Q.base.nlayers && !rc; ++l) {
+      rc = launch_gru_f16_mode<NN, 2>(Q, ws, x, B, T, h0, y, hn, l, tchunk, nchunks, stream);
+      if (!rc) rc = launch_gru_f16_mode<NN, 3>(Q, ws, x, B, T, h0, y, hn, l, T, 1, stream);
+    }
+    if (!rc) rc = launch_gru_f16_mode<NN, 4>(Q, ws, x, B, T, h0, y, hn, 0, tchunk, nchunks, stream);
+    return rc;
+  }
+  return launch_gru_f16_mode<NN, 0>(Q, ws, x, B, T, h0, y, hn, 0, T, 1, stream);
 }
 
 inline bool gru_f16_supported(const GruF16Params& Q) { return Q.kpre16 <= 128 && Q.base.odim <= 128; }
@@ -410,10 +445,10 @@ inline void gru_f16_workspace_bytes(int B, int T, size_t* seq_bytes, size_t* gi_
 }
 
 inline int launch_gru_f16(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
-                          const float* h0, float* y, float* hn, hipStream_t stream) {
+                          const float* h0, float* y, float* hn, int cus, hipStream_t stream) {
   if (!gru_f16_supported(Q)) return -4;
-  return gru_f16_nn(B) == 2 ? launch_gru_f16_nn<2>(Q, ws, x, B, T, h0, y, hn, stream)
-                            : launch_gru_f16_nn<1>(Q, ws, x, B, T, h0, y, hn, stream);
+  return gru_f16_nn(B) == 2 ? launch_gru_f16_nn<2>(Q, ws, x, B, T, h0, y, hn, cus, stream)
+                            : launch_gru_f16_nn<1>(Q, ws, x, B, T, h0, y, hn, cus, stream);
 }
 
 }  // namespace wekws

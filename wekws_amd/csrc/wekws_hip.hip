@@ -201,7 +201,7 @@ struct wekws_hip_model {
   wekws::GruF16Params gq{};
   wekws::FsmnParams fq{};
   int fsmn_max_nt = 0;
-  int fsmn_cus = 256;     // compute units of the device (utterance packing keeps at least one workgroup per CU)
+  int fsmn_cus = 256;     // compute units of the device (FSMN utterance packing, GRU pass splitting)
   int cache_len = 0;
   std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
@@ -399,6 +399,10 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
   m->desc = d;
   m->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->fsmn_cus = prop.multiProcessorCount;
+  }
 
   Image img;
   img.reserve(4);  // offset 0 is never a valid section
@@ -646,7 +650,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       char* base = stream_workspace(m, stream, need);
       if (!base) return WEKWS_HIP_ENOMEM;
       wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al)};
-      rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, stream);
+      rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
     } else {
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     }

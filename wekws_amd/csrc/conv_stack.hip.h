@@ -623,20 +623,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
   conv_stack_head<KIND, C, NT>(P, A, hbuf, slab, b0);
 }
 
-// Row softmax over the last axis (KWSModel.forward_softmax, kws_model.py:89): one wave per row.
+// Row softmax over the last axis (KWSModel.forward_softmax, kws_model.py:89): one wave per row, two passes over the
+// row -- online (max, rescaled sum) with 16-byte loads through a 4-byte-aligned type (rows of an odd-width matrix are
+// only dword aligned), then normalise in place.
 static __global__ __attribute__((unused)) void softmax_rows_kernel(float* y, int64_t rows, int K) {
   const int64_t row = int64_t(blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   float* p = y + row * K;
-  float mx = -INFINITY;
-  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, p[k]);
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  float s = 0.f;
-  for (int k = lane; k < K; k += 64) s += __expf(p[k] - mx);
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  const float inv = 1.0f / s;
-  for (int k = lane; k < K; k += 64) p[k] = __expf(p[k] - mx) * inv;
+  struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
+  const int K4 = K & ~3;
+  float mx = -INFINITY, s = 0.f;
+  auto take = [&](float v) __attribute__((always_inline)) {
+    if (v > mx) { s *= __expf(mx - v); mx = v; }
+    s += __expf(v - mx);
+  };
+  for (int k = lane * 4; k < K4; k += 256) {
+    const V4 q = *reinterpret_cast<const V4*>(p + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) take(q.v[j]);
+  }
+  if (K4 + lane < K) take(p[K4 + lane]);
+  float gm = mx;
+  for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off));
+  float gs = (mx == -INFINITY) ? 0.f : s * __expf(mx - gm);
+  for (int off = 32; off > 0; off >>= 1) gs += __shfl_xor(gs, off);
+  const float inv = 1.0f / gs;
+  for (int k = lane * 4; k < K4; k += 256) {
+    V4 q = *reinterpret_cast<const V4*>(p + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q.v[j] = __expf(q.v[j] - gm) * inv;
+    *reinterpret_cast<V4*>(p + k) = q;
+  }
+  if (K4 + lane < K) p[K4 + lane] = __expf(p[K4 + lane] - gm) * inv;
 }
 
 // launcher implemented per KIND in conv_stack_{ds,tcn,mdtc}.hip

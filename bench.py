@@ -68,7 +68,7 @@ def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30):
     cfg = dict(synth.MODEL_CONFIGS[name])
     m = init_model(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
-    m = m.to(dev).eval()
+    m = m.to(dev).eval().freeze()
     x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=7)).to(dev)
     for _ in range(5):
         m(x)
@@ -118,6 +118,7 @@ def main():
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval().set_precision(args.precision)
     parallel.broadcast_weights(model, src=0, device=dev)
+    model.freeze()
 
     x = torch.from_numpy(synth.synth_feats(B, T, idim, seed=100 + rank)).to(dev)
     for _ in range(args.warmup):

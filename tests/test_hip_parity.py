@@ -266,6 +266,20 @@ def test_weight_update_repacks():
     y2, _ = run(model, x)
     r2, _ = kws_oracle.forward(cfg, sd2, x, None)
     assert max_abs(y2, r2) <= POSTERIOR_TOL and max_abs(y1, y2) > 1e-3
+    # in-place edits are seen too (tensor version counters) ...
+    with torch.no_grad():
+        model.classifier.linear.bias.add_(1.0)
+    y3, _ = run(model, x)
+    assert max_abs(y3, y2) > 1e-3
+    # ... unless the caller froze the weights; load_state_dict lifts the promise
+    model.freeze()
+    with torch.no_grad():
+        model.classifier.linear.bias.add_(1.0)
+    y4, _ = run(model, x)
+    assert np.array_equal(y4, y3)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    y5, _ = run(model, x)
+    assert np.array_equal(y5, y1)
 
 
 def test_large_vocabulary_head_matches_oracle():

@@ -23,7 +23,7 @@ def build(name):
     m = init_model(cfg)
     sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    return cfg, m.cuda().eval()
+    return cfg, m.cuda().eval().freeze()      # weights are final: skip the per-call version check
 
 
 def timeit(fn, warm=5, reps=30, group=10):

@@ -105,10 +105,35 @@ class KWSModel(nn.Module):
                 mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
         self._handle: Optional[_HipHandle] = None
         self._handle_key = None
+        self._tlist = None
+        self._frozen = False
 
     # ------------------------------------------------------------------ weights -> device library
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): buffers become new tensor objects and storages move
+        self._tlist = None
+        self._handle = None
+        self._frozen = False
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._frozen = False
+        return super().load_state_dict(*args, **kwargs)
+
+    def freeze(self) -> "KWSModel":
+        """Promise that the weights will not be modified in place any more: forward stops comparing tensor versions
+        (a streaming loop over MDTC's 363 tensors otherwise spends more host time there than the GPU needs for the
+        chunk).  load_state_dict / .to() / set_precision / load_packed lift the promise again."""
+        self._frozen = True
+        return self
+
     def _weights_key(self, device: torch.device):
-        return (device.index,) + tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
+        # every parameter / buffer counts its in-place modifications: a flat cached list makes the check O(tensors)
+        # attribute reads per call instead of rebuilding the state_dict
+        if self._tlist is None:
+            self._tlist = list(self.state_dict(keep_vars=True).values())
+        lst = self._tlist
+        return (device.index, lst[0].data_ptr() if lst else 0) + tuple(t._version for t in lst)
 
     def load_packed(self, blob: np.ndarray) -> None:
         """Install an already folded weight blob (e.g. received through the RCCL broadcast of
@@ -119,6 +144,7 @@ class KWSModel(nn.Module):
             raise ValueError(f"blob has {blob.size} floats, config needs {pack.blob_elems(desc)}")
         self._packed_blob = blob
         self._handle = None
+        self._frozen = False
 
     def _get_handle(self, device: torch.device) -> _HipHandle:
         if getattr(self, "_packed_blob", None) is not None:
@@ -126,6 +152,8 @@ class KWSModel(nn.Module):
                 desc = {k: int(self._d[k]) for k in pack.DESC_FIELDS}
                 self._handle = _HipHandle(desc, self._packed_blob, device.index if device.index is not None else 0)
                 self._handle_key = ("packed", device.index)
+            return self._handle
+        if self._frozen and self._handle is not None and self._handle_key and self._handle_key[0] == device.index:
             return self._handle
         key = self._weights_key(device)
         if self._handle is None or key != self._handle_key:
@@ -143,6 +171,7 @@ class KWSModel(nn.Module):
         self._cfg["_precision"] = mode
         self._d["precision"] = pack.PRECISION[mode]
         self._handle = None
+        self._frozen = False
         return self
 
     def packed(self) -> Tuple[dict, np.ndarray]:

@@ -67,7 +67,11 @@ enum wekws_hip_head {
 
 enum wekws_hip_activation {
   WEKWS_HIP_ACT_IDENTITY = 0,
-  WEKWS_HIP_ACT_SIGMOID = 1 /* kws_model.py:196-199 */
+  WEKWS_HIP_ACT_SIGMOID = 1, /* kws_model.py:196-199 */
+  WEKWS_HIP_ACT_SOFTMAX = 2  /* the model *is* forward_softmax: what wekws/bin/export_onnx.py:46-48 exports for CTC
+                                recipes (forward := forward_softmax before tracing).  Per-frame heads only; set by the
+                                exported-file reader, never by a training config.  wekws_hip_forward then applies the
+                                softmax whatever its `softmax` argument says. */
 };
 
 /* How the 1x1 / dense convolutions and Linear layers of the conv backbones are multiplied.  Both modes read and

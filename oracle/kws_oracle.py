@@ -303,7 +303,8 @@ def forward(cfg, sd, x, in_cache=None, softmax=False):
     # 5. activation -- wekws/model/kws_model.py:196-210
     if act == "sigmoid":
         y = sigmoid(y)
-    if softmax:  # forward_softmax: x.softmax(2)  (kws_model.py:89)
+    if softmax or cfg.get("_exported_softmax"):  # forward_softmax: x.softmax(2)  (kws_model.py:89); exported CTC
+        # graphs are forward_softmax (export_onnx.py:46-48)
         e = np.exp(y - y.max(axis=2, keepdims=True))
         y = (e / e.sum(axis=2, keepdims=True)).astype(F32)
     return _f(y), _f(cache)

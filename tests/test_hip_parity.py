@@ -247,7 +247,7 @@ def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
 
 def test_fsmn_f32_is_refused():
     """The exact-f32 mode has no FSMN kernel: the library must say so (EUNSUPPORTED), not run something else."""
-    from wekws_amd import _capi
+    from wekws_amd import _capi, pack
     m = init_model(dict(synth.MODEL_CONFIGS["fsmn_small"])).to("cuda").set_precision("f32")
     with pytest.raises(_capi.HipLibraryError, match="fsmn"):
         m(torch.zeros(1, 4, 120, device="cuda"))
@@ -338,3 +338,59 @@ def test_concurrent_streams_and_models():
     for i in range(2):
         for y in outs[i]:
             assert torch.equal(y, serial[i])
+
+
+EXPORTED = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", EXPORTED)
+def test_exported_models(name):
+    """Files written by the reference's exporter recipe (tests/golden/make_onnx_golden.py) -> load_exported -> HIP
+    forward == the reference PyTorch model the file was exported from (recorded outputs), with and without a cache,
+    and batched (the exported graph is batch 1 only; ours is not)."""
+    import os
+    from wekws_amd.model.kws_model import load_exported
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, "golden", "onnx_golden.npz"))
+    model = load_exported(os.path.join(here, "golden", "onnx", name + ".onnx")).cuda()
+    x, c = torch.from_numpy(gold[name + "/x"]).cuda(), torch.from_numpy(gold[name + "/cache"]).cuda()
+    y, rc = model(x, c)
+    assert max_abs(y.cpu().numpy(), gold[name + "/y"]) <= POSTERIOR_TOL
+    scale = max(1.0, float(np.abs(gold[name + "/r_cache"]).max()))
+    assert max_abs(rc.cpu().numpy(), gold[name + "/r_cache"]) <= 1e-4 * scale
+    y0, _ = model(x)                                            # empty cache == zero cache (kws_model.py:67-69)
+    assert max_abs(y0.cpu().numpy(), gold[name + "/y_zero_cache"]) <= POSTERIOR_TOL
+    xb = torch.cat([x, x.flip(1), x], 0)
+    cb = torch.cat([c, torch.zeros_like(c), c], 0)
+    yb, rb = model(xb, cb)
+    assert torch.equal(yb[0], yb[2]) and max_abs(yb[0:1].cpu().numpy(), gold[name + "/y"]) <= POSTERIOR_TOL
+    if name.endswith("_ctc"):                                   # the exported function is forward_softmax
+        assert float((y.sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_reference_android_asset_hip():
+    """The trained DS-TCN the reference ships as an ORT file, converted by tools/make_ref_asset.py in the build
+    container (the asset itself is not in this repo): packed file -> C ABI, streamed in 80-frame chunks."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "ref_asset")
+    if not os.path.exists(os.path.join(root, "kws.wekwship")):
+        pytest.skip("build/ref_asset not prepared (python tools/make_ref_asset.py where /root/reference exists)")
+    import ctypes
+    from wekws_amd import _capi, pack
+    from wekws_amd.model.kws_model import _HipHandle
+    desc, blob = pack.load_packed(os.path.join(root, "kws.wekwship"))
+    exp = np.load(os.path.join(root, "expect.npz"))
+    h, lib = _HipHandle({k: int(desc[k]) for k in pack.DESC_FIELDS}, blob, 0), _capi.load()
+    x = torch.from_numpy(exp["x"]).cuda()
+    caches = [torch.zeros(1, 64, 105, device="cuda"), torch.empty(1, 64, 105, device="cuda")]
+    y = torch.empty(1, x.size(1), 1, device="cuda")
+    for i, t in enumerate(range(0, x.size(1), 80)):
+        xc = x[:, t:t + 80].contiguous()
+        _capi.check(lib.wekws_hip_forward(h.ptr, xc.data_ptr(), 1, 80, caches[i & 1].data_ptr(),
+                                          y[:, t:t + 80].data_ptr(), caches[(i & 1) ^ 1].data_ptr(), 0,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "forward")
+    torch.cuda.synchronize()
+    assert max_abs(y.cpu().numpy(), exp["y"]) <= POSTERIOR_TOL
+    assert max_abs(caches[(i + 1) & 1].cpu().numpy(), exp["cache"]) <= 1e-4 * max(1.0, float(np.abs(exp["cache"]).max()))

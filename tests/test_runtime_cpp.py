@@ -64,3 +64,35 @@ def test_kws_main_matches_oracle(tmp_path, name, chunk):
     ref, _ = kws_oracle.forward_streaming(cfg, sd, feats[None], chunks, None)
     assert got.shape == ref[0].shape == (T, cfg["output_dim"])
     assert float(np.abs(got - ref[0]).max()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_exported_onnx_to_kws_main(tmp_path):
+    """The reference's deployment flow with the middle piece swapped: export_onnx.py's .onnx -> export_packed
+    --exported -> kws_main.  Printed probabilities == the exported graph (numpy executor) run chunk by chunk with the
+    carried cache, which is what keyword_spotting.cc:56-95 does with onnxruntime."""
+    from oracle import onnx_graph_oracle
+    from wekws_amd.bin import export_packed
+    from wekws_amd.utils import onnx_model
+    build_runtime()
+    src = os.path.join(ROOT, "tests", "golden", "onnx", "ds_tcn_h64_cmvn.onnx")
+    model = str(tmp_path / "model.wekwship")
+    export_packed.main(["--exported", src, "--output", model])
+    pcm = (synth.synth_pcm(1, 24000, seed=5, kind="noise")[0] * 0.5 + synth.synth_pcm(1, 24000, kind="sine")[0])
+    pcm = np.clip(np.round(pcm), -32768, 32767).astype(np.int16)
+    wav = str(tmp_path / "t.wav")
+    write_wav(wav, pcm)
+    chunk = 40
+    r = subprocess.run([KWS_MAIN, "40", str(chunk), model, wav], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[float(v) for v in l.split()[3:]] for l in r.stdout.strip().splitlines()], np.float32)
+    g = onnx_model.load_graph(src)
+    feats = fbank_oracle.fbank(pcm.astype(np.float32), 40)
+    cache = np.zeros((1, int(g.meta["cache_dim"]), int(g.meta["cache_len"])), np.float32)   # keyword_spotting.cc:47-53
+    ref = []
+    for t in range(0, feats.shape[0], chunk):
+        out = onnx_graph_oracle.run(g, dict(input=feats[None, t:t + chunk], cache=cache))
+        ref.append(out["output"][0])
+        cache = out["r_cache"]
+    ref = np.concatenate(ref)
+    assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= 1e-4

@@ -128,6 +128,11 @@ size_t blob_elems(const wekws_hip_desc& d) {
   if (d.idim <= 0 || d.hdim <= 0 || d.odim <= 0) { fail(WEKWS_HIP_EINVAL, "idim/hdim/odim must be positive"); return 0; }
   if (d.backbone != WEKWS_HIP_BACKBONE_FSMN && (d.aux[0] || d.aux[1])) { fail(WEKWS_HIP_EINVAL, "desc.aux must be 0 for this backbone"); return 0; }
   if (d.precision < 0 || d.precision > WEKWS_HIP_PRECISION_F16X3) { fail(WEKWS_HIP_EINVAL, "desc.precision %d", d.precision); return 0; }
+  if (d.activation < 0 || d.activation > WEKWS_HIP_ACT_SOFTMAX) { fail(WEKWS_HIP_EINVAL, "desc.activation %d", d.activation); return 0; }
+  if (d.activation == WEKWS_HIP_ACT_SOFTMAX && (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST)) {
+    fail(WEKWS_HIP_EINVAL, "softmax activation needs a per-frame head (forward_softmax is softmax over axis 2)");
+    return 0;
+  }
   const size_t C = d.hdim, K = d.odim, ks = d.kernel_size;
   if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
     const size_t A1 = d.aux[0], A2 = d.aux[1], D = d.num_stack, ro = d.stack_size;
@@ -135,7 +140,7 @@ size_t blob_elems(const wekws_hip_desc& d) {
       fail(WEKWS_HIP_EINVAL, "fsmn: num_layers/proj_dim/left_order/right_order/affine dims must be positive");
       return 0;
     }
-    if (d.head != WEKWS_HIP_HEAD_IDENTITY || d.activation != WEKWS_HIP_ACT_IDENTITY || d.preproc_relu) {
+    if (d.head != WEKWS_HIP_HEAD_IDENTITY || d.activation == WEKWS_HIP_ACT_SIGMOID || d.preproc_relu) {
       fail(WEKWS_HIP_EINVAL, "fsmn: preprocessing none, identity classifier and identity activation only");
       return 0;
     }
@@ -712,7 +717,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
     }
   }
-  if (softmax) {
+  if (softmax || d.activation == WEKWS_HIP_ACT_SOFTMAX) {
     const int64_t rows = per_frame ? int64_t(B) * T : B;
     const int K = d.odim;
     hipLaunchKernelGGL(wekws::softmax_rows_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, stream, y, rows, K);

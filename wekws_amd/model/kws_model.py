@@ -248,3 +248,21 @@ def init_model(configs: Mapping) -> KWSModel:
         # else: the statistics file recorded in config.yaml is not on this machine (the reference would raise here);
         # the global_cmvn.mean / .istd buffers are still created and a checkpoint's state_dict fills them
     return model
+
+
+def load_exported(path: str) -> KWSModel:
+    """A model file written by the reference's exporters -- the ``.onnx`` of wekws/bin/export_onnx.py:62-77 or its
+    ORT-format conversion (runtime/android/app/src/main/assets/kws.ort) -- as a KWSModel on the HIP path.
+
+    The file is recognised, not executed (wekws_amd/utils/onnx_lower.py): the result is an ordinary KWSModel whose
+    config / state_dict were read off the graph, BatchNorm already folded.  ``model(x, cache)`` then equals
+    ``ort_sess.run(None, {'input': x, 'cache': cache})`` of export_onnx.py:80-85 -- including the softmax of CTC
+    exports -- for any batch size, with the cache optional as in KWSModel.forward."""
+    from wekws_amd.utils.onnx_lower import load_model_file
+    cfg, sd, info = load_model_file(path)
+    if info["softmax"]:
+        cfg["_exported_softmax"] = True
+    model = KWSModel(cfg)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    model.exported_info = info
+    return model.eval()

@@ -27,6 +27,7 @@ DESC_FIELDS = ("abi_version", "backbone", "idim", "hdim", "odim", "num_layers", 
 # FSMN reuses the generic slots (include/wekws_hip.h): hdim = linear_dim, num_stack = proj_dim, kernel_size =
 # left_order, stack_size = right_order, aux0 = input_affine_dim, aux1 = output_affine_dim
 PRECISION = dict(default=0, f32=1, f16x3=2)  # enum wekws_hip_precision
+ACT_SOFTMAX = 2  # enum wekws_hip_activation: the model is forward_softmax (exported CTC graphs, export_onnx.py:46-48)
 
 
 class ConfigError(ValueError):
@@ -81,6 +82,7 @@ def parse_config(configs: Mapping) -> dict:
         cm = configs.get("cmvn", {}) or {}
         d["cmvn"] = bool(configs.get("_cmvn")) or bool(cm.get("cmvn_file"))
         d["norm_var"] = bool(cm.get("norm_var", True))
+        _exported_softmax(configs, d)
         return d
     if prep == "none" and idim != hdim:
         raise ConfigError("preprocessing none needs input_dim == hidden_dim")
@@ -101,7 +103,17 @@ def parse_config(configs: Mapping) -> dict:
     cm = configs.get("cmvn", {}) or {}
     d["cmvn"] = bool(configs.get("_cmvn")) or bool(cm.get("cmvn_file"))
     d["norm_var"] = bool(cm.get("norm_var", True))
+    _exported_softmax(configs, d)
     return d
+
+
+def _exported_softmax(configs: Mapping, d: dict) -> None:
+    """configs['_exported_softmax'] (set by the exported-file reader, wekws_amd/utils/onnx_lower.py): forward itself
+    ends in the softmax, as in the graph wekws/bin/export_onnx.py:46-48 traces for CTC recipes."""
+    if configs.get("_exported_softmax"):
+        if d["activation"] != 0 or d["head"] not in (HEAD["linear"], HEAD["identity"]):
+            raise ConfigError("_exported_softmax needs a per-frame head with identity activation")
+        d["activation"] = ACT_SOFTMAX
 
 
 def mdtc_blocks(d: dict) -> List[Tuple[str, int]]:

@@ -90,8 +90,9 @@ def main():
     ap.add_argument("--model", default="ds_tcn_h256")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
-                    help="matrix arithmetic of the conv backbones (enum wekws_hip_precision); default = f16x3")
+    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3", "f16"],
+                    help="matrix arithmetic of the conv backbones (enum wekws_hip_precision); default = f16x3 "
+                         "(meets the 1e-4 bar); f16 = one fp16 product per term, ~1e-3, BASELINE config 5's mode")
     args = ap.parse_args()
 
     import torch
@@ -153,36 +154,39 @@ def main():
         ach_tf = launch_flop / (kern_ms * 1e-3) / 1e12 if flop else None
         hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
         f16x3 = args.precision != "f32"
+        plain = args.precision == "f16"
         kname = "ds256_w16_kernel<NT=7, HAS_CACHE=false>" if f16x3 else "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>"
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
             # the timed process); ignored unless it was taken on the kernel this run dispatches
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             want = "ds256_w16_kernel<7" if f16x3 else "conv_stack_kernel<0, 256, 7"
-            if args.model == "ds_tcn_h256" and B == 1024 and want in pm["kernel"]:
+            if args.model == "ds_tcn_h256" and B == 1024 and want in pm["kernel"] and not plain:
                 traffic, traffic_src = pm["traffic_bytes_per_launch"], pm["profile"]
         except Exception:
             pass
         # Matrix-pipe roofline of the dominant kernel.  f32 mode: exact-f32 MFMA, peak 157.3 TF.  f16x3 mode: every
         # algorithmic MAC costs three fp16 MFMA MACs, so the peak for ALGORITHMIC flops is 2500 / 3 = 833 TF.
-        peak = PEAK_F16_TFLOPS / 3.0 if f16x3 else PEAK_F32_TFLOPS
+        peak = PEAK_F16_TFLOPS if plain else PEAK_F16_TFLOPS / 3.0 if f16x3 else PEAK_F32_TFLOPS
         out = {
             "metric": "1-sec utterances/sec (40-d fbank -> DS-TCN posteriors), whole job",
             "value": round(value, 1), "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 in/out/accumulate; matrix products as 3 x fp16 MFMA on hi/lo-split operands (fp32-level accuracy)"
+            "dtype": "f32 in/out/accumulate; fp16 operands into one MFMA per product (reduced precision, ~1e-3)" if plain
+                     else "f32 in/out/accumulate; matrix products as 3 x fp16 MFMA on hi/lo-split operands (fp32-level accuracy)"
                      if f16x3 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.model} (DS-TCN 4x256, k=8, 287,490 params) forward, {B} x 1-s utterances "
                                    f"per GPU, T=98 frames x 40-d fbank in HBM -> (B,98,2) sigmoid posteriors + "
                                    f"(B,256,105) streaming cache",
-                       "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": "f16x3" if f16x3 else "f32",
+                       "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": "f16" if plain else "f16x3" if f16x3 else "f32",
                        "parallelism": f"utterance-parallel x{world}"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(ach_tf, 3) if ach_tf else None, "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach_tf / peak, 4) if ach_tf else None, "traffic": traffic,
-                         "peak_note": ("algorithmic flops vs dense fp16 MFMA peak 2500 TF / 3 products per MAC; "
+                         "peak_note": "dense fp16 MFMA peak" if plain else
+                                      ("algorithmic flops vs dense fp16 MFMA peak 2500 TF / 3 products per MAC; "
                                        "executed MFMA rate = 3 x achieved") if f16x3 else "exact-f32 MFMA peak",
                          "frac_of_f32_mfma_peak": round(ach_tf / PEAK_F32_TFLOPS, 4) if ach_tf else None,
                          "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)", "traffic_source": traffic_src,

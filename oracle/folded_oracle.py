@@ -41,13 +41,18 @@ def _fsmn(desc, r, x):
     return y
 
 
-def forward(desc, blob, x):
+def forward(desc, blob, x, mm_dtype=None):
+    """mm_dtype=np.float16 restates WEKWS_HIP_PRECISION_F16 (include/wekws_hip.h): both operands of the input Linear
+    and of every pointwise convolution are rounded to fp16 before the (fp32-accumulated) product; everything else
+    stays float32.  DS-TCN / MDTC only."""
     r = _Reader(blob)
     if desc["backbone"] == 4:
         return _fsmn(desc, r, x)
+    q = (lambda a: a) if mm_dtype is None else (lambda a: np.asarray(a, F32).astype(mm_dtype).astype(F32))
+    assert mm_dtype is None or desc["backbone"] in (0, 2)
     C, I, K, ks = desc["hdim"], desc["idim"], desc["odim"], desc["kernel_size"]
     W, b = r.take(C, I), r.take(C)
-    h = ko.linear(np.asarray(x, F32), W, b)
+    h = ko.linear(q(np.asarray(x, F32)), q(W), b)
     if desc["preproc_relu"]:
         h = ko.relu(h)
     bb = desc["backbone"]
@@ -68,13 +73,13 @@ def forward(desc, blob, x):
             u, _ = ko.causal_concat(h, None, (ks - 1) * d)
             if bb == 0:
                 a = ko.relu(ko.depthwise_conv(u, r.take(C, 1, ks), r.take(C), d))
-                h = ko.relu(ko.pointwise_conv(a, r.take(C, C, 1), r.take(C))) + h
+                h = ko.relu(ko.pointwise_conv(q(a), q(r.take(C, C, 1)), r.take(C))) + h
             elif bb == 1:
                 h = ko.relu(ko.full_conv(u, r.take(C, C, ks), r.take(C), d)) + h
             else:
                 a = ko.depthwise_conv(u, r.take(C, 1, ks), r.take(C), d)
-                a = ko.relu(ko.pointwise_conv(a, r.take(C, C, 1), r.take(C)))
-                h = ko.relu(ko.pointwise_conv(a, r.take(C, C, 1), r.take(C)) + h)
+                a = ko.relu(ko.pointwise_conv(q(a), q(r.take(C, C, 1)), r.take(C)))
+                h = ko.relu(ko.pointwise_conv(q(a), q(r.take(C, C, 1)), r.take(C)) + h)
                 if bi > 0 and (bi - 1) % desc["stack_size"] == desc["stack_size"] - 1:
                     z = h.copy() if z is None else z + h
         h = np.transpose(z if bb == 2 else h, (0, 2, 1))

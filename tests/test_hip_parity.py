@@ -394,3 +394,41 @@ def test_reference_android_asset_hip():
     torch.cuda.synchronize()
     assert max_abs(y.cpu().numpy(), exp["y"]) <= POSTERIOR_TOL
     assert max_abs(caches[(i + 1) & 1].cpu().numpy(), exp["cache"]) <= 1e-4 * max(1.0, float(np.abs(exp["cache"]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 3, 98), ("mdtc_h64", 4, 98), ("mdtc_h64_global12", 3, 61),
+                                      ("mdtc_h64_80d", 2, 50), ("ds_tcn_h256", 2, 150)])
+def test_precision_f16_mode(name, B, T):
+    """WEKWS_HIP_PRECISION_F16 (BASELINE.json config 5: fp16 weights + fp16 MFMA pointwise conv): one fp16 product per
+    term.  Checked two ways: (1) tightly against the oracle evaluated with the same roundings (fp16 operands into the
+    input Linear / pointwise convs, fp32 everywhere else) -- differences are accumulation order plus the rare fp16
+    rounding flip of an activation that differs in its last fp32 bit: <= 5e-4 on posteriors / logits of O(1);
+    (2) against the exact fp32 oracle at the accuracy fp16 operands allow: <= 1e-2.  And it must differ from the
+    F16X3 result (the mode is really on)."""
+    from oracle import folded_oracle
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    model = init_model(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.cuda().eval()
+    x = synth.synth_feats(B, T, cfg["input_dim"], seed=3)
+    xt = torch.from_numpy(x).cuda()
+    y3, c3 = model(xt)
+    y16, c16 = model.set_precision("f16")(xt)
+    y16, y3 = y16.cpu().numpy(), y3.cpu().numpy()
+    desc, blob = pack.pack(cfg, sd)
+    exact = folded_oracle.forward(desc, blob, x)
+    emu = folded_oracle.forward(desc, blob, x, mm_dtype=np.float16)
+    scale = max(1.0, float(np.abs(exact).max()))
+    assert max_abs(y3, exact) <= POSTERIOR_TOL * scale
+    assert max_abs(y16, emu) <= 5e-4 * scale, max_abs(y16, emu)
+    assert max_abs(y16, exact) <= 1e-2 * scale, max_abs(y16, exact)
+    if T <= 112:                                  # longer inputs tile through kernels that keep F16X3
+        assert max_abs(y16, y3) > 1e-6
+    # streaming with the carried cache stays self-consistent in this mode too
+    ya, ca = model(xt[:, :40])
+    yb, cb = model(xt[:, 40:], ca)
+    if y16.ndim == 3:
+        assert max_abs(torch.cat([ya, yb], 1).cpu().numpy(), y16) <= 2e-3 * scale

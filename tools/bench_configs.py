@@ -57,12 +57,18 @@ def main():
         out.append(dict(kind="batch", model=name, B=B, T=T, ms=round(med, 4), p10=round(p10, 4), p90=round(p90, 4),
                         utts_per_s=round(B / med * 1e3, 1), frames_per_s=round(B * T / med * 1e3, 1)))
         print(json.dumps(out[-1]), flush=True)
+    # "@f16": WEKWS_HIP_PRECISION_F16, the reduced-precision mode of BASELINE.json config 5 (fp16 weights + fp16 MFMA
+    # pointwise conv; MDTC + 12-class GlobalClassifier, 1024 utterances per GPU of the 8192)
     for name, B in (("ds_tcn_h256", 1024), ("ds_tcn_h256", 8192), ("mdtc_h64", 1024), ("mdtc_h64", 8192),
-                    ("mdtc_h64_global12", 1024), ("mdtc_small", 1024), ("ds_tcn_h64", 1024), ("tcn_h64", 1024),
+                    ("mdtc_h64_global12", 1024), ("mdtc_h64_global12@f16", 1024), ("mdtc_h64_global12@f16", 8192),
+                    ("mdtc_h64@f16", 1024), ("ds_tcn_h256@f16", 1024),
+                    ("mdtc_small", 1024), ("ds_tcn_h64", 1024), ("tcn_h64", 1024),
                     ("gru_2x128", 256), ("gru_2x128", 1024), ("gru_2x128", 16384)):
         if only not in name:
             continue
-        cfg, m = build(name)
+        cfg, m = build(name.split("@")[0])
+        if "@" in name:
+            m.set_precision(name.split("@")[1]).freeze()
         x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=1)).cuda()
         med, p10, p90 = timeit(lambda: m(x), reps=10 if B <= 1024 else 4, group=10 if B <= 1024 else 4)
         out.append(dict(kind="batch", model=name, B=B, T=98, ms=round(med, 4), p10=round(p10, 4), p90=round(p90, 4),

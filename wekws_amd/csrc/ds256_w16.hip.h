@@ -20,15 +20,19 @@ namespace wekws {
 
 // One 32-deep K step for one o-tile, B fragments loaded tile by tile (no double buffer: with four waves per SIMD the
 // LDS latency of a tile is covered by the other waves, and the registers are needed elsewhere).
-template <int NT>
+// SPLIT = false is WEKWS_HIP_PRECISION_F16: weights and activations enter the product as plain fp16 (the hi halves
+// only), one MFMA per product instead of three; the lo planes are neither written nor read.
+template <int NT, bool SPLIT = true>
 __device__ __forceinline__ void mfma16_step_nb(f32x4 (&acc)[NT], const F16Frag& a, const char* bh, const char* bl) {
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
     const f16x8 vh = *reinterpret_cast<const f16x8*>(bh + tt * 256);
-    const f16x8 vl = *reinterpret_cast<const f16x8*>(bl + tt * 256);
     acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+    if constexpr (SPLIT) {
+      const f16x8 vl = *reinterpret_cast<const f16x8*>(bl + tt * 256);
+      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
+      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+    }
   }
 }
 
@@ -49,7 +53,7 @@ struct W16Geom {
 // HAS_CACHE: left context from the streaming cache in global memory (true) or zeros (false).  A template parameter,
 // not a run-time branch: with both producer variants in one kernel the register allocation exceeds the 128-VGPR
 // budget of four waves per SIMD and spills.
-template <int NT, bool HAS_CACHE>
+template <int NT, bool HAS_CACHE, bool SPLIT>
 __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParams P, const CallArgs A) {
   using G = W16Geom<NT>;
   constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB, KS = 8;
@@ -96,13 +100,13 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
         }
         char* dst = slab + st * 2 * PB + (oct * TT + t) * 16;
         *reinterpret_cast<f16x8*>(dst) = vh;
-        *reinterpret_cast<f16x8*>(dst + PB) = vl;
+        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(dst + PB) = vl;
       }
       __syncthreads();
       for (int st = 0; st < steps; ++st) {
         F16Frag a[1];
         load_a16<1>(a, ap + (k0 + st) * 128, 0);
-        mfma16_step_nb<NT>(acc[0], a[0], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
+        mfma16_step_nb<NT, SPLIT>(acc[0], a[0], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
       }
     }
 #pragma unroll
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           _Float16 h, l;
           split16(o, h, l);
           ph[t * 8] = h;
-          pl[t * 8] = l;
+          if constexpr (SPLIT) pl[t * 8] = l;
         }
       } else {
 #pragma unroll 1
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           _Float16 h, l;
           split16(o, h, l);
           ph[t * 8] = h;
-          pl[t * 8] = l;
+          if constexpr (SPLIT) pl[t * 8] = l;
         }
       }
 #undef fetch
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
       produce_iv(iv);
       load_dw(nx);
       __syncthreads();
-      mfma16_step_nb<NT>(acc[0], a0[0], slab + frag_off, slab + PB + frag_off);
+      mfma16_step_nb<NT, SPLIT>(acc[0], a0[0], slab + frag_off, slab + PB + frag_off);
       load_a16<1>(a0, ap1 + (2 * nx) * 128, 0);
-      mfma16_step_nb<NT>(acc[0], a1[0], slab + 2 * PB + frag_off, slab + 3 * PB + frag_off);
+      mfma16_step_nb<NT, SPLIT>(acc[0], a1[0], slab + 2 * PB + frag_off, slab + 3 * PB + frag_off);
       load_a16<1>(a1, ap1 + (2 * nx + 1) * 128, 0);
       __syncthreads();
     }
@@ -246,11 +250,11 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   conv_stack_head<KIND_DS, 256, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
 }
 
-template <int NT, bool HAS_CACHE>
+template <int NT, bool HAS_CACHE, bool SPLIT>
 inline int launch_ds256_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   using G = W16Geom<NT>;
   static bool attr_set = false;
-  auto kern = ds256_w16_kernel<NT, HAS_CACHE>;
+  auto kern = ds256_w16_kernel<NT, HAS_CACHE, SPLIT>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(G::LDS_BYTES)) != hipSuccess)
@@ -262,10 +266,15 @@ inline int launch_ds256_w16_ntc(const StackParams& P, const CallArgs& A, hipStre
 }
 
 template <int NT>
-inline int launch_ds256_w16_nt(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  return A.in_cache ? launch_ds256_w16_ntc<NT, true>(P, A, stream) : launch_ds256_w16_ntc<NT, false>(P, A, stream);
+inline int launch_ds256_w16_nt(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  if (split)
+    return A.in_cache ? launch_ds256_w16_ntc<NT, true, true>(P, A, stream)
+                      : launch_ds256_w16_ntc<NT, false, true>(P, A, stream);
+  return A.in_cache ? launch_ds256_w16_ntc<NT, true, false>(P, A, stream)
+                    : launch_ds256_w16_ntc<NT, false, false>(P, A, stream);
 }
 
-int launch_ds256_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+// split: three fp16 products per MAC on hi/lo operands (F16X3) or one on the hi halves (F16)
+int launch_ds256_w16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

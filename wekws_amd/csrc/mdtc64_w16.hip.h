@@ -18,7 +18,7 @@
 
 namespace wekws {
 
-template <int NT, bool HAS_CACHE>
+template <int NT, bool HAS_CACHE, bool SPLIT>
 __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackParams P, const CallArgs A) {
   using G = Geom<KIND_MDTC, 64, NT>;
   constexpr int C = 64, U = 2, SS = G::SS, TT = 16 * NT, KS = 5;
@@ -64,10 +64,12 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         if (tt < ntw) {
           const char* q = slab_u + ks * 4 * TT * 16 + frag_off + tt * 256;
           const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
-          const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vh, acc[tt], 0, 0, 0);
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vl, acc[tt], 0, 0, 0);
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].l, vh, acc[tt], 0, 0, 0);
+          if constexpr (SPLIT) {                             // !SPLIT = WEKWS_HIP_PRECISION_F16: hi halves only
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vl, acc[tt], 0, 0, 0);
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].l, vh, acc[tt], 0, 0, 0);
+          }
         }
   };
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         }
         char* dst = slab + u * UB + ((st * 4 + oct) * TT + t) * 16;
         *reinterpret_cast<f16x8*>(dst) = vh;
-        *reinterpret_cast<f16x8*>(dst + MPB) = vl;
+        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(dst + MPB) = vl;
       }
       __syncthreads();
       for (int st = 0; st < steps; ++st) {
@@ -111,10 +113,12 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           if (tt < ntw) {
             const char* q = slab_u + st * 4 * TT * 16 + frag_off + tt * 256;
             const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
-            const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh, acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
-            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+            if constexpr (SPLIT) {
+              const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl, acc[tt], 0, 0, 0);
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh, acc[tt], 0, 0, 0);
+            }
           }
       }
     }
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           _Float16 h, l;
           split16(o, h, l);
           ph[t * 8] = h;
-          pl[t * 8] = l;
+          if constexpr (SPLIT) pl[t * 8] = l;
         }
       } else {
 #pragma unroll 1
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           _Float16 h, l;
           split16(o, h, l);
           ph[t * 8] = h;
-          pl[t * 8] = l;
+          if constexpr (SPLIT) pl[t * 8] = l;
         }
       }
 #undef fetch
@@ -229,10 +233,10 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         const int t = (ft0 + tt) * 16 + l15;
         const f32x4 v = __builtin_elementwise_max(acc[tt] + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f});
         const f16x4 vh = __builtin_convertvector(v, f16x4);
-        const f16x4 vl = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
         char* dst = slab_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
         *reinterpret_cast<f16x4*>(dst) = vh;
-        *reinterpret_cast<f16x4*>(dst + MPB) = vl;
+        if constexpr (SPLIT)
+          *reinterpret_cast<f16x4*>(dst + MPB) = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
       }
     __syncthreads();
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), in place into h
@@ -265,11 +269,11 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   conv_stack_head<KIND_MDTC, 64, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
 }
 
-template <int NT, bool HAS_CACHE>
+template <int NT, bool HAS_CACHE, bool SPLIT>
 inline int launch_mdtc64_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   using G = Geom<KIND_MDTC, 64, NT>;
   static bool attr_set = false;
-  auto kern = mdtc64_w16_kernel<NT, HAS_CACHE>;
+  auto kern = mdtc64_w16_kernel<NT, HAS_CACHE, SPLIT>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(G::LDS_BYTES)) != hipSuccess)
@@ -281,11 +285,15 @@ inline int launch_mdtc64_w16_ntc(const StackParams& P, const CallArgs& A, hipStr
 }
 
 template <int NT>
-inline int launch_mdtc64_w16_nt(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  return A.in_cache ? launch_mdtc64_w16_ntc<NT, true>(P, A, stream) : launch_mdtc64_w16_ntc<NT, false>(P, A, stream);
+inline int launch_mdtc64_w16_nt(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  if (split)
+    return A.in_cache ? launch_mdtc64_w16_ntc<NT, true, true>(P, A, stream)
+                      : launch_mdtc64_w16_ntc<NT, false, true>(P, A, stream);
+  return A.in_cache ? launch_mdtc64_w16_ntc<NT, true, false>(P, A, stream)
+                    : launch_mdtc64_w16_ntc<NT, false, false>(P, A, stream);
 }
 
-// usable when: hidden_dim 64, kernel size 5 (host checks)
-int launch_mdtc64_w16(int nt, const StackParams& P, const CallArgs& A, hipStream_t stream);
+// usable when: hidden_dim 64, kernel size 5 (host checks); split as in launch_ds256_w16
+int launch_mdtc64_w16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

@@ -127,7 +127,7 @@ size_t blob_elems(const wekws_hip_desc& d) {
   if (d.abi_version != WEKWS_HIP_ABI_VERSION) { fail(WEKWS_HIP_EINVAL, "desc.abi_version %d != %d", d.abi_version, WEKWS_HIP_ABI_VERSION); return 0; }
   if (d.idim <= 0 || d.hdim <= 0 || d.odim <= 0) { fail(WEKWS_HIP_EINVAL, "idim/hdim/odim must be positive"); return 0; }
   if (d.backbone != WEKWS_HIP_BACKBONE_FSMN && (d.aux[0] || d.aux[1])) { fail(WEKWS_HIP_EINVAL, "desc.aux must be 0 for this backbone"); return 0; }
-  if (d.precision < 0 || d.precision > WEKWS_HIP_PRECISION_F16X3) { fail(WEKWS_HIP_EINVAL, "desc.precision %d", d.precision); return 0; }
+  if (d.precision < 0 || d.precision > WEKWS_HIP_PRECISION_F16) { fail(WEKWS_HIP_EINVAL, "desc.precision %d", d.precision); return 0; }
   if (d.activation < 0 || d.activation > WEKWS_HIP_ACT_SOFTMAX) { fail(WEKWS_HIP_EINVAL, "desc.activation %d", d.activation); return 0; }
   if (d.activation == WEKWS_HIP_ACT_SOFTMAX && (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST)) {
     fail(WEKWS_HIP_EINVAL, "softmax activation needs a per-frame head (forward_softmax is softmax over axis 2)");
@@ -696,11 +696,12 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       a.last_tile = (i == ntiles - 1);
       int rc;
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
+      const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
           rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
-               : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, m->sp, a, stream)   // 16-wave variant
+               : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;
         case WEKWS_HIP_BACKBONE_TCN:
@@ -709,7 +710,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
-          rc = (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, m->sp, a, stream)
+          rc = (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
                    : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;

@@ -26,7 +26,7 @@ DESC_FIELDS = ("abi_version", "backbone", "idim", "hdim", "odim", "num_layers", 
                "kernel_size", "preproc_relu", "head", "head_hidden", "activation", "precision", "aux0", "aux1")
 # FSMN reuses the generic slots (include/wekws_hip.h): hdim = linear_dim, num_stack = proj_dim, kernel_size =
 # left_order, stack_size = right_order, aux0 = input_affine_dim, aux1 = output_affine_dim
-PRECISION = dict(default=0, f32=1, f16x3=2)  # enum wekws_hip_precision
+PRECISION = dict(default=0, f32=1, f16x3=2, f16=3)  # enum wekws_hip_precision
 ACT_SOFTMAX = 2  # enum wekws_hip_activation: the model is forward_softmax (exported CTC graphs, export_onnx.py:46-48)
 
 

@@ -139,6 +139,25 @@ def test_empty_cache_equals_zero_cache():
         assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
 
 
+def test_forward_stream_is_forward_with_cache():
+    from wekws_amd import pack
+    for name in ("ds_tcn_h256", "gru_2x128", "fsmn_small"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+        model = build(cfg, sd)
+        x = torch.from_numpy(synth.synth_feats(2, 30, cfg["input_dim"], seed=4)).cuda()
+        cache, ys = None, []
+        for t in range(0, 30, 10):
+            y, cache = model.forward_stream(x[:, t:t + 10], cache)
+            ys.append(y)
+        y1, c1 = model(x[:, :10])
+        y2, c2 = model(x[:, 10:20], c1)
+        assert torch.equal(ys[0], y1) and torch.equal(ys[1], y2)
+        yfull, cfull = model(x)
+        assert max_abs(torch.cat(ys, 1).cpu().numpy(), yfull.cpu().numpy()) <= 2e-5
+        assert max_abs(cache.cpu().numpy(), cfull.cpu().numpy()) <= 2e-5 * max(1.0, float(cfull.abs().max()))
+
+
 def test_long_input_tiling_matches_oracle():
     """T > 112 goes through several LDS tiles that hand the context over via the workspace cache."""
     from wekws_amd import pack

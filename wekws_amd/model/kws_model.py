@@ -223,6 +223,14 @@ class KWSModel(nn.Module):
             raise IndexError("Dimension out of range (expected to be in range of [-2, 1], but got 2)")  # x.softmax(2) on (B, K)
         return self._run(x, in_cache, True)
 
+    def forward_stream(self, x: torch.Tensor, in_cache: Optional[torch.Tensor] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One streaming step: ``y, cache = model.forward_stream(chunk, cache)``; ``None`` / an empty tensor starts a
+        stream.  The reference has no method of this name -- its streaming callers call ``forward(x, in_cache)``
+        and rebind the cache (wekws/bin/stream_kws_ctc.py:486-487, runtime/core/kws/keyword_spotting.cc:63-94) --
+        so this is that call under the name BASELINE.json's north_star uses."""
+        return self._run(x, in_cache, False)
+
     def fuse_modules(self):
         """Reference: kws_model.py:92-94 (quantisation-time Conv+BN+ReLU fusion).  Here BN is always folded
         at pack time, so this is a no-op kept for API compatibility."""

@@ -155,7 +155,7 @@ def main():
         hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
         f16x3 = args.precision != "f32"
         plain = args.precision == "f16"
-        kname = "ds256_w16_kernel<NT=7, HAS_CACHE=false>" if f16x3 else "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>"
+        kname = ("ds256_w16_kernel<NT=7, HAS_CACHE=false, SPLIT=%s>" % ("false" if plain else "true")) if f16x3 else "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>"
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
             # the timed process); ignored unless it was taken on the kernel this run dispatches

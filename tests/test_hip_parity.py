@@ -299,6 +299,10 @@ def test_weight_update_repacks():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
     y5, _ = run(model, x)
     assert np.array_equal(y5, y1)
+    # assign=True replaces the Parameter objects; still honoured
+    model.load_state_dict({k: torch.from_numpy(v).cuda() for k, v in sd2.items()}, assign=True)
+    y6, _ = run(model, x)
+    assert np.array_equal(y6, y2)
 
 
 def test_large_vocabulary_head_matches_oracle():

@@ -120,6 +120,57 @@ def main():
         out.append(dict(kind="e2e", pipeline="pcm -> fbank80 -> splice(2,2)/skip3 -> fsmn_ctc -> softmax+top3", B=B,
                         ms=round(med, 4), utts_per_s=round(B / med * 1e3, 1)))
         print(json.dumps(out[-1]), flush=True)
+    # host buffers in, host scores out (what a caller without device residency pays): pinned feats -> H2D -> DS-TCN h256
+    # -> D2H of the posteriors.  "serial": one stream.  "overlapped": copies on their own streams, 3 batches in flight.
+    if only in "pcie":
+        B, T = 1024, 98
+        _, m = build("ds_tcn_h256")
+        nbuf = 3
+        hx = [torch.from_numpy(synth.synth_feats(B, T, 40, seed=i)).pin_memory() for i in range(nbuf)]
+        hy = [torch.empty(B, T, 2).pin_memory() for _ in range(nbuf)]
+        dx = [torch.empty(B, T, 40, device="cuda") for _ in range(nbuf)]
+        dy = [None] * nbuf
+
+        def serial(n):
+            for i in range(n):
+                j = i % nbuf
+                dx[j].copy_(hx[j], non_blocking=True)
+                y, _ = m(dx[j])
+                hy[j].copy_(y, non_blocking=True)
+
+        up, comp, down = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        ev_up = [torch.cuda.Event() for _ in range(nbuf)]
+        ev_c = [torch.cuda.Event() for _ in range(nbuf)]
+        ev_d = [torch.cuda.Event() for _ in range(nbuf)]
+
+        def overlapped(n):
+            for i in range(n):
+                j = i % nbuf
+                with torch.cuda.stream(up):
+                    up.wait_event(ev_c[j])                      # the previous forward on this buffer has read it
+                    dx[j].copy_(hx[j], non_blocking=True)
+                    ev_up[j].record(up)
+                with torch.cuda.stream(comp):
+                    comp.wait_event(ev_up[j])
+                    comp.wait_event(ev_d[j])                    # its previous scores have left the device
+                    dy[j], _ = m(dx[j])
+                    ev_c[j].record(comp)
+                with torch.cuda.stream(down):
+                    down.wait_event(ev_c[j])
+                    hy[j].copy_(dy[j], non_blocking=True)
+                    ev_d[j].record(down)
+
+        for label, fn in (("serial", serial), ("overlapped", overlapped)):
+            fn(6)
+            torch.cuda.synchronize()
+            n = 60
+            t0 = time.perf_counter()
+            fn(n)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            out.append(dict(kind="pcie", mode=label, model="ds_tcn_h256", B=B, ms=round(ms, 4),
+                            utts_per_s=round(B / ms * 1e3, 1), h2d_GBs=round(B * T * 40 * 4 / ms / 1e6, 1)))
+            print(json.dumps(out[-1]), flush=True)
     fb = Fbank(40)
     for B in ((1024, 8192) if only in "fbank" else ()):
         pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()

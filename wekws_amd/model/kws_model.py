@@ -117,7 +117,10 @@ class KWSModel(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
+        # assign=True swaps the Parameter objects themselves: drop the cached tensor list and re-pack on the next call
         self._frozen = False
+        self._tlist = None
+        self._handle = None
         return super().load_state_dict(*args, **kwargs)
 
     def freeze(self) -> "KWSModel":

@@ -32,3 +32,21 @@ def test_oracle_matches_reference_golden(case, golden):
     c = cache if cfg["backbone"]["type"] == "gru" else cache[:1]
     assert c.shape == gc.shape
     assert max_abs(c, gc) <= CACHE_TOL * max(1.0, float(np.abs(gc).max()))
+
+
+TORCH_REF_CASES = [c for c in CASES if c["cache"] == "empty" and not c.get("chunks") and not c.get("softmax")
+                   and c["model"].split("_")[0] in ("ds", "tcn", "mdtc") and "global" not in c["model"]
+                   and "last" not in c["model"]]
+
+
+@pytest.mark.parametrize("case", TORCH_REF_CASES, ids=[c["name"] for c in TORCH_REF_CASES])
+def test_torch_cpu_restatement_matches_reference_golden(case, golden):
+    """oracle/torch_ref.py (the reference's ATen call sequence, used as bench.py's cpu_baseline) against the same
+    live-reference goldens."""
+    import torch
+    from oracle import torch_ref
+    cfg, sd = case_weights(case)
+    y, cache = torch_ref.forward(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(case_input(case)))
+    gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
+    assert max_abs(y.numpy(), gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+    assert max_abs(cache.numpy()[:1], gc) <= CACHE_TOL * max(1.0, float(np.abs(gc).max()))

@@ -6,30 +6,24 @@
 #include <cstdio>
 #include <cstring>
 
+#include <exception>
+
+#include "kws/model_file.h"
 #include "utils/check.h"
 
 namespace wekws {
 
-namespace {
-void ReadPackedModel(const std::string& path, wekws_hip_desc* desc, std::vector<float>* blob) {
-  std::FILE* f = std::fopen(path.c_str(), "rb");
-  WEKWS_CHECK(f != nullptr) << "cannot open " << path;
-  char magic[8];
-  uint64_t n = 0;
-  static_assert(sizeof(wekws_hip_desc) == 64, "descriptor is 16 x int32");
-  bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "WEKWSHIP", 8) == 0 &&
-            std::fread(desc, sizeof(*desc), 1, f) == 1 && std::fread(&n, sizeof(n), 1, f) == 1;
-  WEKWS_CHECK(ok) << path << " is not a packed wekws_hip model";
-  blob->resize(n);
-  WEKWS_CHECK(std::fread(blob->data(), sizeof(float), n, f) == n) << path << " is truncated";
-  std::fclose(f);
-}
-}  // namespace
 
 KeywordSpotting::KeywordSpotting(const std::string& model_path) {
+  // model_path: what the reference's constructor takes (the exporter's .onnx / an ORT-format .ort,
+  // keyword_spotting.cc:28-45) or a packed file of wekws_amd.bin.export_packed -- kws/model_file.h
   wekws_hip_desc desc;
   std::vector<float> blob;
-  ReadPackedModel(model_path, &desc, &blob);
+  try {
+    ReadModelFile(model_path, &desc, &blob);
+  } catch (const std::exception& e) {
+    WEKWS_CHECK(false) << e.what();
+  }
   WEKWS_CHECK(wekws_hip_create(&desc, blob.data(), blob.size(), /*device=*/0, &model_) == WEKWS_HIP_OK)
       << wekws_hip_last_error();
   WEKWS_CHECK(desc.head == WEKWS_HIP_HEAD_LINEAR || desc.head == WEKWS_HIP_HEAD_IDENTITY)

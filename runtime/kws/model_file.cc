@@ -1,0 +1,920 @@
+#include "kws/model_file.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+
+namespace wekws {
+namespace {
+
+[[noreturn]] void Fail(const std::string& msg) { throw std::runtime_error(msg); }
+
+// ------------------------------------------------------------------------------------------------ protobuf (.onnx)
+// Field numbers: onnx.proto3 (IR 7/8).  ModelProto{graph=7, opset_import=8, metadata_props=14}; GraphProto{node=1,
+// initializer=5, input=11, output=12}; NodeProto{input=1, output=2, name=3, op_type=4, attribute=5}; AttributeProto
+// {name=1, f=2, i=3, s=4, t=5, floats=7, ints=8, type=20}; TensorProto{dims=1, data_type=2, float_data=4,
+// int32_data=5, int64_data=7, name=8, raw_data=9, double_data=10, external_data=13}.
+struct PbField {
+  uint32_t no = 0;
+  int wt = 0;
+  uint64_t v = 0;            // varint / fixed value
+  const uint8_t* p = nullptr;  // length-delimited payload
+  size_t n = 0;
+};
+
+class PbReader {
+ public:
+  PbReader(const uint8_t* p, size_t n) : p_(p), end_(p + n) {}
+  explicit PbReader(const PbField& f) : p_(f.p), end_(f.p + f.n) {}
+  bool Next(PbField* f) {
+    if (p_ >= end_) return false;
+    const uint64_t key = Varint();
+    f->no = static_cast<uint32_t>(key >> 3);
+    f->wt = static_cast<int>(key & 7);
+    switch (f->wt) {
+      case 0: f->v = Varint(); break;
+      case 1: f->v = Fixed(8); break;
+      case 5: f->v = Fixed(4); break;
+      case 2: {
+        const uint64_t n = Varint();
+        if (n > static_cast<uint64_t>(end_ - p_)) Fail("malformed ONNX file: truncated field");
+        f->p = p_;
+        f->n = static_cast<size_t>(n);
+        p_ += n;
+        break;
+      }
+      default: Fail("malformed ONNX file: unsupported wire type");
+    }
+    return true;
+  }
+  uint64_t Varint() {
+    uint64_t v = 0;
+    for (int s = 0; s < 70; s += 7) {
+      if (p_ >= end_) Fail("malformed ONNX file: truncated varint");
+      const uint8_t b = *p_++;
+      v |= static_cast<uint64_t>(b & 0x7f) << s;
+      if (!(b & 0x80)) return v;
+    }
+    Fail("malformed ONNX file: varint too long");
+  }
+  bool AtEnd() const { return p_ >= end_; }
+
+ private:
+  uint64_t Fixed(int n) {
+    if (end_ - p_ < n) Fail("malformed ONNX file: truncated fixed field");
+    uint64_t v = 0;
+    std::memcpy(&v, p_, n);
+    p_ += n;
+    return v;
+  }
+  const uint8_t* p_;
+  const uint8_t* end_;
+};
+
+std::string Str(const PbField& f) { return std::string(reinterpret_cast<const char*>(f.p), f.n); }
+
+void PackedInts(const PbField& f, std::vector<int64_t>* out) {
+  if (f.wt == 0) {
+    out->push_back(static_cast<int64_t>(f.v));
+    return;
+  }
+  PbReader r(f);
+  while (!r.AtEnd()) out->push_back(static_cast<int64_t>(r.Varint()));
+}
+
+float BitsToFloat(uint32_t u) {
+  float x;
+  std::memcpy(&x, &u, 4);
+  return x;
+}
+
+// ONNX TensorProto.DataType: FLOAT 1, INT32 6, INT64 7, BOOL 9, DOUBLE 11
+void FillTensor(int dtype, const uint8_t* raw, size_t nraw, const std::string& name, ModelTensor* t) {
+  size_t count = 1;
+  for (int64_t d : t->dims) count *= static_cast<size_t>(d);
+  const size_t width = dtype == 1 || dtype == 6 ? 4 : dtype == 7 || dtype == 11 ? 8 : dtype == 9 ? 1 : 0;
+  if (!width) Fail("tensor " + name + ": unsupported element type " + std::to_string(dtype));
+  if (nraw != count * width) Fail("tensor " + name + ": payload size does not match its dims");
+  t->is_float = dtype == 1 || dtype == 11;
+  for (size_t k = 0; k < count; ++k) {
+    const uint8_t* q = raw + k * width;
+    if (dtype == 1) { float x; std::memcpy(&x, q, 4); t->f.push_back(x); }
+    else if (dtype == 11) { double x; std::memcpy(&x, q, 8); t->f.push_back(static_cast<float>(x)); }
+    else if (dtype == 6) { int32_t x; std::memcpy(&x, q, 4); t->i.push_back(x); }
+    else if (dtype == 7) { int64_t x; std::memcpy(&x, q, 8); t->i.push_back(x); }
+    else t->i.push_back(*q);
+  }
+}
+
+std::string PbTensor(const PbField& field, ModelTensor* t) {
+  PbReader r(field);
+  PbField f;
+  int dtype = 1;
+  std::string name;
+  const uint8_t* raw = nullptr;
+  size_t nraw = 0;
+  std::vector<float> fdata;
+  std::vector<int64_t> idata;
+  bool have_raw = false;
+  while (r.Next(&f)) {
+    switch (f.no) {
+      case 1: PackedInts(f, &t->dims); break;
+      case 2: dtype = static_cast<int>(f.v); break;
+      case 8: name = Str(f); break;
+      case 9: raw = f.p; nraw = f.n; have_raw = true; break;
+      case 4:
+        if (f.wt == 2) for (size_t k = 0; k + 4 <= f.n; k += 4) { float x; std::memcpy(&x, f.p + k, 4); fdata.push_back(x); }
+        else fdata.push_back(BitsToFloat(static_cast<uint32_t>(f.v)));
+        break;
+      case 5: case 7: PackedInts(f, &idata); break;
+      case 10:
+        for (size_t k = 0; k + 8 <= f.n; k += 8) { double x; std::memcpy(&x, f.p + k, 8); fdata.push_back(static_cast<float>(x)); }
+        break;
+      case 13: Fail("tensor " + name + " uses external data");
+      default: break;
+    }
+  }
+  if (have_raw) {
+    FillTensor(dtype, raw, nraw, name, t);
+  } else {
+    t->is_float = dtype == 1 || dtype == 11;
+    if (t->is_float) t->f = fdata; else t->i = idata;
+    size_t count = 1;
+    for (int64_t d : t->dims) count *= static_cast<size_t>(d);
+    if (t->size() != count) Fail("tensor " + name + ": element count does not match its dims");
+  }
+  return name;
+}
+
+void PbAttr(const PbField& field, ModelNode* node) {
+  PbReader r(field);
+  PbField f;
+  std::string name;
+  ModelAttr a;
+  while (r.Next(&f)) {
+    switch (f.no) {
+      case 1: name = Str(f); break;
+      case 2: a.f = BitsToFloat(static_cast<uint32_t>(f.v)); break;
+      case 3: a.i = static_cast<int64_t>(f.v); break;
+      case 4: a.s = Str(f); break;
+      case 5: PbTensor(f, &a.t); a.has_tensor = true; break;
+      case 8: PackedInts(f, &a.ints); break;
+      case 6: case 11: Fail("attribute " + name + " holds a sub-graph");
+      default: break;
+    }
+  }
+  node->attr[name] = a;
+}
+
+ModelGraph ParseOnnx(const uint8_t* data, size_t n) {
+  ModelGraph g;
+  PbReader model(data, n);
+  PbField f, graph;
+  bool have_graph = false;
+  while (model.Next(&f)) {
+    if (f.no == 7 && f.wt == 2) { graph = f; have_graph = true; }
+    else if (f.no == 14 && f.wt == 2) {
+      PbReader e(f);
+      PbField kv;
+      std::string k, v;
+      while (e.Next(&kv)) { if (kv.no == 1) k = Str(kv); else if (kv.no == 2) v = Str(kv); }
+      g.meta[k] = v;
+    }
+  }
+  if (!have_graph) Fail("no GraphProto in the file (not an ONNX model?)");
+  PbReader gr(graph);
+  std::vector<std::string> ins;
+  auto value_name = [](const PbField& vf) {
+    PbReader r(vf);
+    PbField x;
+    while (r.Next(&x)) if (x.no == 1) return Str(x);
+    return std::string();
+  };
+  while (gr.Next(&f)) {
+    if (f.wt != 2) continue;
+    if (f.no == 1) {
+      ModelNode node;
+      PbReader nr(f);
+      PbField x;
+      while (nr.Next(&x)) {
+        if (x.no == 1) node.in.push_back(Str(x));
+        else if (x.no == 2) node.out.push_back(Str(x));
+        else if (x.no == 3) node.name = Str(x);
+        else if (x.no == 4) node.op = Str(x);
+        else if (x.no == 5) PbAttr(x, &node);
+      }
+      if (node.op == "Constant" && node.attr.count("value") && node.attr["value"].has_tensor && !node.out.empty())
+        g.init[node.out[0]] = node.attr["value"].t;      // opset-13 exporters emit constants as nodes
+      else
+        g.nodes.push_back(std::move(node));
+    } else if (f.no == 5) {
+      ModelTensor t;
+      const std::string name = PbTensor(f, &t);
+      g.init[name] = std::move(t);
+    } else if (f.no == 11) {
+      ins.push_back(value_name(f));
+    } else if (f.no == 12) {
+      g.outputs.push_back(value_name(f));
+    } else if (f.no == 15) {
+      Fail("sparse initializers are not supported");
+    }
+  }
+  for (const auto& s : ins) if (!g.init.count(s)) g.inputs.push_back(s);
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------ FlatBuffers (.ort)
+// Slots follow onnxruntime/core/flatbuffers/schema/ort.fbs (ORT 1.12, the version the reference pins):
+// InferenceSession{ort_version, model}; Model{.., graph = 7, .., metadata_props = 9}; Graph{initializers, node_args,
+// nodes, max_node_index, node_edges, inputs, outputs}; Node{name, doc, domain, since_version, index, op_type, type, ep,
+// inputs, outputs, attributes}; Attribute{name, doc, type, f, i, s, t, g, floats, ints, strings}; Tensor{name, doc,
+// dims, data_type, raw_data}.
+class Fb {
+ public:
+  Fb(const uint8_t* b, size_t n) : b_(b), n_(n) {}
+  uint32_t U32(size_t p) const { Need(p, 4); uint32_t v; std::memcpy(&v, b_ + p, 4); return v; }
+  int32_t I32(size_t p) const { Need(p, 4); int32_t v; std::memcpy(&v, b_ + p, 4); return v; }
+  uint16_t U16(size_t p) const { Need(p, 2); uint16_t v; std::memcpy(&v, b_ + p, 2); return v; }
+  size_t Root() const { return U32(0); }
+  size_t Field(size_t table, int slot) const {          // absolute position or 0 when absent
+    const size_t vt = table - I32(table);
+    const size_t off = 4 + 2 * static_cast<size_t>(slot);
+    if (off + 2 > U16(vt)) return 0;
+    const uint16_t rel = U16(vt + off);
+    return rel ? table + rel : 0;
+  }
+  size_t Indirect(size_t p) const { return p + U32(p); }
+  size_t Table(size_t table, int slot) const { const size_t p = Field(table, slot); return p ? Indirect(p) : 0; }
+  std::string StringAt(size_t p) const {
+    p = Indirect(p);
+    const uint32_t n = U32(p);
+    Need(p + 4, n);
+    return std::string(reinterpret_cast<const char*>(b_ + p + 4), n);
+  }
+  std::string String(size_t table, int slot) const { const size_t p = Field(table, slot); return p ? StringAt(p) : ""; }
+  // (position of element 0, length)
+  std::pair<size_t, uint32_t> Vector(size_t table, int slot) const {
+    const size_t f = Field(table, slot);
+    if (!f) return {0, 0};
+    const size_t p = Indirect(f);
+    return {p + 4, U32(p)};
+  }
+  std::vector<std::string> Strings(size_t table, int slot) const {
+    auto v = Vector(table, slot);
+    std::vector<std::string> out;
+    for (uint32_t k = 0; k < v.second; ++k) out.push_back(StringAt(v.first + 4 * k));
+    return out;
+  }
+  std::vector<size_t> Tables(size_t table, int slot) const {
+    auto v = Vector(table, slot);
+    std::vector<size_t> out;
+    for (uint32_t k = 0; k < v.second; ++k) out.push_back(Indirect(v.first + 4 * k));
+    return out;
+  }
+  std::vector<int64_t> Int64s(size_t table, int slot) const {
+    auto v = Vector(table, slot);
+    Need(v.first, size_t(v.second) * 8);
+    std::vector<int64_t> out(v.second);
+    if (v.second) std::memcpy(out.data(), b_ + v.first, size_t(v.second) * 8);
+    return out;
+  }
+  template <typename T>
+  T Scalar(size_t table, int slot, T dflt) const {
+    const size_t p = Field(table, slot);
+    if (!p) return dflt;
+    Need(p, sizeof(T));
+    T v;
+    std::memcpy(&v, b_ + p, sizeof(T));
+    return v;
+  }
+  const uint8_t* Bytes(size_t p, size_t n) const { Need(p, n); return b_ + p; }
+
+ private:
+  void Need(size_t p, size_t n) const { if (p > n_ || n > n_ - p) Fail("malformed ORT file: offset out of range"); }
+  const uint8_t* b_;
+  size_t n_;
+};
+
+std::string OrtTensor(const Fb& fb, size_t t, ModelTensor* out) {
+  const std::string name = fb.String(t, 0);
+  out->dims = fb.Int64s(t, 2);
+  const int dtype = fb.Scalar<int32_t>(t, 3, 0);
+  auto raw = fb.Vector(t, 4);
+  FillTensor(dtype, fb.Bytes(raw.first, raw.second), raw.second, name, out);
+  return name;
+}
+
+ModelGraph ParseOrt(const uint8_t* data, size_t n) {
+  Fb fb(data, n);
+  ModelGraph g;
+  const size_t model = fb.Table(fb.Root(), 1);
+  const size_t graph = model ? fb.Table(model, 7) : 0;
+  if (!graph) Fail("malformed ORT file: no graph");
+  for (size_t e : fb.Tables(model, 9)) g.meta[fb.String(e, 0)] = fb.String(e, 1);
+  for (size_t t : fb.Tables(graph, 0)) {
+    ModelTensor mt;
+    const std::string name = OrtTensor(fb, t, &mt);
+    g.init[name] = std::move(mt);
+  }
+  std::vector<std::pair<uint32_t, ModelNode>> nodes;
+  for (size_t nd : fb.Tables(graph, 2)) {
+    ModelNode node;
+    node.name = fb.String(nd, 0);
+    node.op = fb.String(nd, 5);
+    node.in = fb.Strings(nd, 8);
+    node.out = fb.Strings(nd, 9);
+    for (size_t a : fb.Tables(nd, 10)) {
+      ModelAttr at;
+      const int type = fb.Scalar<int32_t>(a, 2, 0);   // AttributeType: FLOAT 1, INT 2, STRING 3, TENSOR 4, INTS 7
+      if (type == 1) at.f = fb.Scalar<float>(a, 3, 0.f);
+      else if (type == 2) at.i = fb.Scalar<int64_t>(a, 4, 0);
+      else if (type == 3) at.s = fb.String(a, 5);
+      else if (type == 4) { OrtTensor(fb, fb.Table(a, 6), &at.t); at.has_tensor = true; }
+      else if (type == 7) at.ints = fb.Int64s(a, 9);
+      else if (type == 5 || type == 10) Fail("attribute holds a sub-graph");
+      node.attr[fb.String(a, 0)] = std::move(at);
+    }
+    nodes.emplace_back(fb.Scalar<uint32_t>(nd, 4, 0), std::move(node));
+  }
+  std::stable_sort(nodes.begin(), nodes.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (const auto& s : fb.Strings(graph, 5)) if (!g.init.count(s)) g.inputs.push_back(s);
+  g.outputs = fb.Strings(graph, 6);
+  // ORT stores nodes by index, which its optimiser does not keep topological
+  std::set<std::string> ready(g.inputs.begin(), g.inputs.end());
+  for (const auto& kv : g.init) ready.insert(kv.first);
+  ready.insert("");
+  std::vector<bool> done(nodes.size(), false);
+  for (size_t placed = 0; placed < nodes.size();) {
+    const size_t before = placed;
+    for (size_t k = 0; k < nodes.size(); ++k) {
+      if (done[k]) continue;
+      const ModelNode& nd = nodes[k].second;
+      if (!std::all_of(nd.in.begin(), nd.in.end(), [&](const std::string& s) { return ready.count(s) > 0; })) continue;
+      for (const auto& o : nd.out) ready.insert(o);
+      g.nodes.push_back(nd);
+      done[k] = true;
+      ++placed;
+    }
+    if (placed == before) Fail("malformed ORT file: graph has a cycle or a dangling input");
+  }
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------ recogniser
+[[noreturn]] void Unrec(const std::string& msg) { Fail("unrecognised wekws graph: " + msg); }
+
+struct Conv {
+  const ModelTensor* W = nullptr;
+  std::vector<float> b;
+  std::vector<int64_t> dil;
+  int64_t group = 1;
+  bool relu = false;
+  std::string out;
+};
+struct Linear {
+  bool ok = false;
+  std::vector<float> W;  // (out, in) row-major
+  int64_t out_dim = 0, in_dim = 0;
+  std::vector<float> b;
+  bool has_bias = false;
+  std::string out;
+};
+struct Block {
+  int64_t off = 0, pad = 0;
+  std::vector<Conv> convs;
+  int post_relu = 0;
+  std::string out, new_cache;
+};
+
+class Tracer {
+ public:
+  explicit Tracer(const ModelGraph& g) : g_(g) {
+    for (const auto& n : g.nodes) {
+      for (const auto& o : n.out) prod_[o] = &n;
+      for (const auto& i : n.in) cons_[i].push_back(&n);
+    }
+  }
+  const ModelTensor* Const(const std::string& name) const {
+    auto it = g_.init.find(name);
+    return it == g_.init.end() ? nullptr : &it->second;
+  }
+  const ModelNode* Producer(const std::string& t) const { auto it = prod_.find(t); return it == prod_.end() ? nullptr : it->second; }
+  std::vector<const ModelNode*> Users(const std::string& t, std::initializer_list<const char*> ops = {}) const {
+    std::vector<const ModelNode*> out;
+    auto it = cons_.find(t);
+    if (it == cons_.end()) return out;
+    for (const ModelNode* n : it->second)
+      if (ops.size() == 0 || std::any_of(ops.begin(), ops.end(), [&](const char* o) { return n->op == o; })) out.push_back(n);
+    return out;
+  }
+  const ModelNode* OnlyUser(const std::string& t, std::initializer_list<const char*> ops) const {
+    auto it = cons_.find(t);
+    if (it == cons_.end() || it->second.size() != 1) return nullptr;
+    const ModelNode* n = it->second[0];
+    return std::any_of(ops.begin(), ops.end(), [&](const char* o) { return n->op == o; }) ? n : nullptr;
+  }
+  static int64_t AttrI(const ModelNode& n, const char* k, int64_t d) { auto it = n.attr.find(k); return it == n.attr.end() ? d : it->second.i; }
+  static float AttrF(const ModelNode& n, const char* k, float d) { auto it = n.attr.find(k); return it == n.attr.end() ? d : it->second.f; }
+  static std::string AttrS(const ModelNode& n, const char* k, const char* d) { auto it = n.attr.find(k); return it == n.attr.end() ? d : it->second.s; }
+  static std::vector<int64_t> AttrInts(const ModelNode& n, const char* k) { auto it = n.attr.find(k); return it == n.attr.end() ? std::vector<int64_t>() : it->second.ints; }
+
+  // (axis, start, end) of a constant unit-step single-axis Slice-13
+  bool SliceRange(const ModelNode& n, int64_t* axis, int64_t* start, int64_t* end, bool required = true) const {
+    const ModelTensor* ps[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (size_t k = 1; k < n.in.size() && k <= 4; ++k) ps[k - 1] = Const(n.in[k]);
+    const bool ok = n.in.size() >= 4 && ps[0] && ps[1] && ps[2] && !ps[0]->is_float && ps[0]->size() == 1 &&
+                    ps[1]->size() == 1 && ps[2]->size() == 1 &&
+                    (n.in.size() < 5 || (ps[3] && ps[3]->size() == 1 && ps[3]->i[0] == 1));
+    if (!ok) {
+      if (required) Unrec("Slice " + n.name + " is not a constant single-axis unit-step slice");
+      return false;
+    }
+    *axis = ps[2]->i[0]; *start = ps[0]->i[0]; *end = ps[1]->i[0];
+    return true;
+  }
+  // absolute [start, end) along `axis` if t is (a slice of a slice of ...) the graph input 'cache'
+  bool CacheWindow(const std::string& t, int64_t axis, int64_t* s, int64_t* e) const {
+    if (t == "cache") { *s = 0; *e = int64_t(1) << 62; return true; }
+    const ModelNode* n = Producer(t);
+    if (!n) return false;
+    if (n->op == "Cast") return CacheWindow(n->in[0], axis, s, e);
+    if (n->op != "Slice") return false;
+    int64_t is, ie;
+    if (!CacheWindow(n->in[0], axis, &is, &ie)) return false;
+    int64_t ax, a, b;
+    SliceRange(*n, &ax, &a, &b);
+    if (ax != axis || a < 0 || b < 0) Unrec("cache slice " + n->name);
+    *s = is + a;
+    *e = std::min(is + b, ie);
+    return true;
+  }
+
+  // x @ W^T + b in its exported spellings (MatMul+Add, Gemm, FusedMatMul)
+  Linear TakeLinear(const std::string& t, bool channels_first = false) const {
+    Linear L;
+    const ModelNode* n = nullptr;
+    if (channels_first) { auto u = Users(t, {"FusedMatMul"}); n = u.empty() ? nullptr : u[0]; }
+    else n = OnlyUser(t, {"MatMul", "Gemm", "FusedMatMul"});
+    if (!n || n->in[0] != t) return L;
+    const ModelTensor* W = Const(n->in[1]);
+    if (!W || W->dims.size() != 2 || !W->is_float) return L;
+    bool w_is_out_in = false;   // whether W is stored (out, in)
+    if (n->op == "Gemm") {
+      if (AttrI(*n, "transA", 0) || AttrF(*n, "alpha", 1.f) != 1.f || AttrF(*n, "beta", 1.f) != 1.f) Unrec("Gemm " + n->name + " attributes");
+      w_is_out_in = AttrI(*n, "transB", 0) != 0;
+      if (n->in.size() > 2 && !n->in[2].empty()) {
+        const ModelTensor* b = Const(n->in[2]);
+        if (!b) return L;
+        L.b = b->f; L.has_bias = true;
+      }
+      L.out = n->out[0];
+    } else {
+      if (n->op == "FusedMatMul") {
+        if ((AttrI(*n, "transA", 0) != 0) != channels_first || AttrI(*n, "transBatchA", 0) || AttrI(*n, "transBatchB", 0) ||
+            AttrF(*n, "alpha", 1.f) != 1.f) Unrec("FusedMatMul " + n->name + " attributes");
+        w_is_out_in = AttrI(*n, "transB", 0) != 0;
+      }
+      L.out = n->out[0];
+      if (const ModelNode* add = OnlyUser(L.out, {"Add"})) {
+        const std::string& other = add->in[0] == L.out ? add->in[1] : add->in[0];
+        const ModelTensor* b = Const(other);
+        if (b && b->dims.size() == 1 && b->is_float) { L.b = b->f; L.has_bias = true; L.out = add->out[0]; }
+      }
+    }
+    const int64_t r = W->dims[0], c = W->dims[1];
+    if (w_is_out_in) { L.out_dim = r; L.in_dim = c; L.W = W->f; }
+    else {
+      L.out_dim = c; L.in_dim = r; L.W.resize(W->f.size());
+      for (int64_t i = 0; i < r; ++i) for (int64_t j = 0; j < c; ++j) L.W[j * r + i] = W->f[i * c + j];
+    }
+    L.ok = true;
+    return L;
+  }
+  bool TakeRelu(std::string* t) const {
+    const ModelNode* r = OnlyUser(*t, {"Relu"});
+    if (!r) return false;
+    *t = r->out[0];
+    return true;
+  }
+  bool TakeConv(const std::string& t, Conv* c) const {
+    auto cn = Users(t, {"Conv", "FusedConv"});
+    if (cn.size() != 1 || cn[0]->in[0] != t) return false;
+    const ModelNode& n = *cn[0];
+    c->W = Const(n.in[1]);
+    if (!c->W || !c->W->is_float) return false;
+    if (n.in.size() > 2 && !n.in[2].empty()) { const ModelTensor* b = Const(n.in[2]); if (!b) return false; c->b = b->f; }
+    else c->b.assign(static_cast<size_t>(c->W->dims[0]), 0.f);
+    for (int64_t p : AttrInts(n, "pads")) if (p) Unrec("convolution " + n.name + " with pads");
+    for (int64_t s : AttrInts(n, "strides")) if (s != 1) Unrec("convolution " + n.name + " with strides");
+    if (AttrS(n, "auto_pad", "NOTSET") != "NOTSET") Unrec("convolution " + n.name + " with auto_pad");
+    const std::string act = n.op == "FusedConv" ? AttrS(n, "activation", "") : "";
+    if (!act.empty() && act != "Relu") Unrec("FusedConv activation " + act);
+    c->dil = AttrInts(n, "dilations");
+    if (c->dil.empty()) c->dil.assign(c->W->dims.size() - 2, 1);
+    c->group = AttrI(n, "group", 1);
+    c->out = n.out[0];
+    c->relu = act == "Relu";
+    if (!c->relu) c->relu = TakeRelu(&c->out);
+    return true;
+  }
+  // r_cache must be the given pieces concatenated along the last axis, in order (nested Concats flattened)
+  void CheckCacheOrder(const std::vector<std::string>& pieces, int64_t axis) const {
+    std::vector<std::string> leaves;
+    Leaves("r_cache", axis, &leaves);
+    if (leaves != pieces) Unrec("r_cache is not the per-block caches in block order");
+  }
+  const ModelGraph& graph() const { return g_; }
+
+ private:
+  void Leaves(const std::string& t, int64_t axis, std::vector<std::string>* out) const {
+    const ModelNode* n = Producer(t);
+    if (n && n->op == "Concat" && (AttrI(*n, "axis", 0) == axis || AttrI(*n, "axis", 0) == -1)) {
+      for (const auto& i : n->in) Leaves(i, axis, out);
+    } else {
+      out->push_back(t);
+    }
+  }
+  const ModelGraph& g_;
+  std::map<std::string, const ModelNode*> prod_;
+  std::map<std::string, std::vector<const ModelNode*>> cons_;
+};
+
+void Append(std::vector<float>* blob, const std::vector<float>& v) { blob->insert(blob->end(), v.begin(), v.end()); }
+
+// Sigmoid / nothing / forward_softmax's softmax after the last Linear -> enum wekws_hip_activation
+int LowerActivation(const Tracer& tr, const std::string& t, bool linear_head) {
+  if (t == "output") return WEKWS_HIP_ACT_IDENTITY;
+  const ModelNode* n = tr.OnlyUser(t, {"Sigmoid", "Softmax"});
+  if (!n || n->out[0] != "output") Unrec("the classifier does not end in 'output'");
+  if (n->op == "Sigmoid") {
+    if (!linear_head) Unrec("Sigmoid after a non-linear head");
+    return WEKWS_HIP_ACT_SIGMOID;
+  }
+  const int64_t ax = Tracer::AttrI(*n, "axis", -1);
+  if (ax != 2 && ax != -1) Unrec("Softmax over an unexpected axis");
+  return WEKWS_HIP_ACT_SOFTMAX;
+}
+
+// first Linear of the model with GlobalCMVN folded in exactly as wekws_amd/pack.py does (float64):
+//   W (x - mean) * istd + b = (W * istd) x + (b - (W * istd) mean)
+void FoldCmvn(Linear* L, const std::vector<float>& mean, const std::vector<float>& istd, bool norm_var) {
+  const int64_t O = L->out_dim, I = L->in_dim;
+  for (int64_t o = 0; o < O; ++o) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < I; ++i) {
+      const double w = static_cast<double>(L->W[o * I + i]) * (norm_var ? static_cast<double>(istd[i]) : 1.0);
+      acc += w * static_cast<double>(mean[i]);
+      L->W[o * I + i] = static_cast<float>(w);
+    }
+    L->b[o] = static_cast<float>(static_cast<double>(L->b[o]) - acc);
+  }
+}
+
+std::vector<Block> TraceConvBlocks(const Tracer& tr, std::string* h_io) {
+  std::vector<Block> blocks;
+  std::string h = *h_io;
+  while (true) {
+    const ModelNode* cat = nullptr;
+    int64_t s = 0, e = 0;
+    for (const ModelNode* n : tr.Users(h, {"Concat"})) {
+      int64_t cs, ce;
+      if (Tracer::AttrI(*n, "axis", 0) == 2 && n->in.size() == 2 && n->in[1] == h && tr.CacheWindow(n->in[0], 2, &cs, &ce)) {
+        if (cat) Unrec("tensor " + h + " is padded by more than one cache slice");
+        cat = n; s = cs; e = ce;
+      }
+    }
+    if (!cat) break;
+    Block b;
+    b.off = s;
+    b.pad = e - s;
+    const std::string u = cat->out[0];
+    auto keep = tr.Users(u, {"Slice"});
+    int64_t ax, a, z;
+    if (keep.size() != 1 || !tr.SliceRange(*keep[0], &ax, &a, &z) || ax != 2 || a != -b.pad)
+      Unrec("a block does not emit its last frames as the new cache");
+    b.new_cache = keep[0]->out[0];
+    std::string t = u;
+    Conv c;
+    while (tr.TakeConv(t, &c)) { t = c.out; b.convs.push_back(c); c = Conv(); }
+    const ModelNode* add = nullptr;
+    for (const ModelNode* n : tr.Users(t, {"Add"})) if (n->in[0] == h || n->in[1] == h) { if (add) add = nullptr; else add = n; }
+    if (b.convs.empty() || !add) Unrec("a block has no residual connection");
+    t = add->out[0];
+    while (tr.TakeRelu(&t)) ++b.post_relu;
+    b.out = t;
+    h = t;
+    blocks.push_back(std::move(b));
+  }
+  *h_io = h;
+  return blocks;
+}
+
+bool ConvIs(const Conv& c, int64_t o, int64_t cin, int64_t k, int64_t group, bool relu) {
+  return c.W->dims.size() == 3 && c.W->dims[0] == o && c.W->dims[1] == cin && c.W->dims[2] == k && c.group == group &&
+         c.relu == relu;
+}
+
+void LowerHead(const Tracer& tr, const std::string& h, int64_t C, wekws_hip_desc* d, std::vector<float>* blob) {
+  std::string x = h;
+  Linear lin = tr.TakeLinear(h, /*channels_first=*/true);   // ORT folds the transpose into FusedMatMul(transA)
+  if (!lin.ok) {
+    auto tp = tr.Users(h, {"Transpose"});
+    if (tp.size() != 1 || Tracer::AttrInts(*tp[0], "perm") != std::vector<int64_t>({0, 2, 1}))
+      Unrec("backbone output is not transposed back to (B,T,C)");
+    x = tp[0]->out[0];
+    auto pool = tr.Users(x, {"ReduceMean", "Gather"});
+    if (!pool.empty()) {
+      const ModelNode& p = *pool[0];
+      if (p.op == "ReduceMean") {
+        if (Tracer::AttrInts(p, "axes") != std::vector<int64_t>({1}) || Tracer::AttrI(p, "keepdims", 1) != 0)
+          Unrec("ReduceMean head is not a mean over frames");
+        d->head = WEKWS_HIP_HEAD_GLOBAL;
+      } else {
+        const ModelTensor* idx = tr.Const(p.in[1]);
+        if (Tracer::AttrI(p, "axis", 0) != 1 || !idx || idx->size() != 1 || idx->i[0] != -1) Unrec("Gather head is not x[:, -1, :]");
+        d->head = WEKWS_HIP_HEAD_LAST;
+      }
+      Linear l1 = tr.TakeLinear(p.out[0]);
+      if (!l1.ok || !l1.has_bias || l1.in_dim != C) Unrec("pooled classifier: first Linear");
+      std::string t = l1.out;
+      if (!tr.TakeRelu(&t)) Unrec("pooled classifier: ReLU");
+      Linear l2 = tr.TakeLinear(t);
+      if (!l2.ok || !l2.has_bias || l2.out != "output") Unrec("pooled classifier: second Linear must produce 'output'");
+      d->head_hidden = static_cast<int32_t>(l1.out_dim);
+      d->odim = static_cast<int32_t>(l2.out_dim);
+      d->activation = WEKWS_HIP_ACT_IDENTITY;
+      Append(blob, l1.W); Append(blob, l1.b); Append(blob, l2.W); Append(blob, l2.b);
+      return;
+    }
+    lin = tr.TakeLinear(x);
+  }
+  if (!lin.ok || lin.in_dim != C || !lin.has_bias) Unrec("no classifier found after the backbone");
+  d->head = WEKWS_HIP_HEAD_LINEAR;
+  d->head_hidden = 0;
+  d->odim = static_cast<int32_t>(lin.out_dim);
+  d->activation = LowerActivation(tr, lin.out, true);
+  Append(blob, lin.W); Append(blob, lin.b);
+}
+
+void LowerConvFamily(const Tracer& tr, const std::string& after_pre, wekws_hip_desc* d, std::vector<float>* blob) {
+  const ModelNode* tp = tr.OnlyUser(after_pre, {"Transpose"});
+  if (!tp || Tracer::AttrInts(*tp, "perm") != std::vector<int64_t>({0, 2, 1})) Unrec("no (B,T,C)->(B,C,T) transpose in front of the backbone");
+  std::string h = tp->out[0];
+  std::vector<Block> blocks = TraceConvBlocks(tr, &h);
+  if (blocks.empty()) Unrec("no residual block found");
+  const int64_t C = blocks[0].convs[0].W->dims[0];
+  const int64_t ks = blocks[0].convs[0].W->dims.size() == 3 ? blocks[0].convs[0].W->dims[2] : 0;
+  int64_t off = 0;
+  for (const Block& b : blocks) {
+    if (b.off != off) Unrec("cache offsets are not cumulative");
+    off += b.pad;
+    if (b.convs[0].dil.size() != 1 || b.pad != (ks - 1) * b.convs[0].dil[0]) Unrec("receptive field of a block");
+    for (size_t k = 1; k < b.convs.size(); ++k) if (b.convs[k].dil != std::vector<int64_t>({1})) Unrec("dilated pointwise convolution");
+  }
+  auto all = [&](auto pred) { return std::all_of(blocks.begin(), blocks.end(), pred); };
+  const bool ds = all([&](const Block& b) { return b.convs.size() == 2 && ConvIs(b.convs[0], C, 1, ks, C, true) && ConvIs(b.convs[1], C, C, 1, 1, true); });
+  const bool full = all([&](const Block& b) { return b.convs.size() == 1 && ConvIs(b.convs[0], C, C, ks, 1, true); });
+  const bool mdtc = all([&](const Block& b) {
+    return b.convs.size() == 3 && ConvIs(b.convs[0], C, 1, ks, C, false) && ConvIs(b.convs[1], C, C, 1, 1, true) && ConvIs(b.convs[2], C, C, 1, 1, false);
+  });
+  d->hdim = static_cast<int32_t>(C);
+  d->kernel_size = static_cast<int32_t>(ks);
+  if (ds || full) {
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].convs[0].dil[0] != (int64_t(1) << i) || blocks[i].post_relu) Unrec("TCN block dilation / activation");
+    d->backbone = ds ? WEKWS_HIP_BACKBONE_DS_TCN : WEKWS_HIP_BACKBONE_TCN;
+    d->num_layers = static_cast<int32_t>(blocks.size());
+  } else if (mdtc) {
+    std::vector<int64_t> dil;
+    for (const Block& b : blocks) dil.push_back(b.convs[0].dil[0]);
+    const size_t body = dil.size() - 1;
+    size_t size = body;
+    for (size_t k = 2; k < dil.size(); ++k) if (dil[k] == 1) { size = k - 1; break; }
+    bool ok = dil[0] == 1 && blocks[0].post_relu == 2 && body > 0 && body % size == 0;
+    for (size_t k = 1; ok && k < dil.size(); ++k) ok = dil[k] == (int64_t(1) << ((k - 1) % size)) && blocks[k].post_relu == 1;
+    if (!ok) Unrec("MDTC block dilations");
+    const size_t nstack = body / size;
+    // output = zeros_like + every stack's last block (mdtc.py:270-273)
+    std::set<std::string> ends;
+    for (size_t s = 0; s < nstack; ++s) ends.insert(blocks[(s + 1) * size].out);
+    auto top = tr.Users(h, {"Add"});
+    while (!top.empty() && !tr.Users(top[0]->out[0], {"Add"}).empty()) top = tr.Users(top[0]->out[0], {"Add"});
+    if (top.size() != 1) Unrec("MDTC stack outputs are not summed");
+    std::vector<std::string> leaves, work = {top[0]->out[0]};
+    while (!work.empty()) {
+      const std::string t = work.back();
+      work.pop_back();
+      const ModelNode* n = tr.Producer(t);
+      if (n && n->op == "Add" && !ends.count(t)) { work.push_back(n->in[0]); work.push_back(n->in[1]); }
+      else leaves.push_back(t);
+    }
+    std::set<std::string> seen;
+    for (const auto& l : leaves) {
+      if (ends.count(l)) { seen.insert(l); continue; }
+      const ModelNode* z = tr.Producer(l);
+      if (!z || z->op != "ConstantOfShape") Unrec("MDTC output is not the sum of its stacks");
+    }
+    if (seen != ends) Unrec("MDTC output is not the sum of its stacks");
+    h = top[0]->out[0];
+    d->backbone = WEKWS_HIP_BACKBONE_MDTC;
+    d->num_stack = static_cast<int32_t>(nstack);
+    d->stack_size = static_cast<int32_t>(size);
+  } else {
+    Unrec("residual blocks match neither TCN, DS-TCN nor MDTC");
+  }
+  std::vector<std::string> pieces;
+  for (const Block& b : blocks) {
+    pieces.push_back(b.new_cache);
+    for (const Conv& c : b.convs) { Append(blob, c.W->f); Append(blob, c.b); }
+  }
+  tr.CheckCacheOrder(pieces, 2);
+  LowerHead(tr, h, C, d, blob);
+}
+
+// fsmn.py:462-495: in_linear1, in_linear2, ReLU, [LinearTransform, FSMNBlock, AffineTransform, ReLU] * L, out_linear1/2
+void LowerFsmn(const Tracer& tr, const std::string& start, Linear l1, wekws_hip_desc* d, std::vector<float>* blob) {
+  (void)start;
+  Linear l2 = l1.ok && l1.has_bias ? tr.TakeLinear(l1.out) : Linear();
+  if (!l2.ok || !l2.has_bias) Unrec("FSMN input affine layers");
+  std::string t = l2.out;
+  if (!tr.TakeRelu(&t)) Unrec("FSMN: ReLU after in_linear2");
+  Append(blob, l1.W); Append(blob, l1.b); Append(blob, l2.W); Append(blob, l2.b);
+  const int64_t C = l2.out_dim;
+  int64_t D = -1, lo = -1, ro = -1;
+  int layers = 0;
+  std::vector<std::string> caches;
+  Linear lin;
+  while (true) {
+    lin = tr.TakeLinear(t);
+    if (!lin.ok) Unrec("FSMN layer projection");
+    const ModelNode* uq = tr.OnlyUser(lin.out, {"Unsqueeze"});
+    if (!uq) break;   // this Linear is out_linear1
+    if (lin.has_bias) Unrec("FSMN LinearTransform carries a bias");
+    const ModelNode* tp = tr.OnlyUser(uq->out[0], {"Transpose"});
+    if (!tp || Tracer::AttrInts(*tp, "perm") != std::vector<int64_t>({0, 3, 2, 1})) Unrec("FSMN (B,T,1,D)->(B,D,T,1) transpose");
+    const std::string x4 = tp->out[0];
+    const ModelNode* cat = nullptr;
+    for (const ModelNode* n : tr.Users(x4, {"Concat"})) if (Tracer::AttrI(*n, "axis", 0) == 2 && n->in.size() == 2 && n->in[1] == x4) cat = n;
+    int64_t cs, ce;
+    if (!cat || !tr.CacheWindow(cat->in[0], 3, &cs, &ce) || cs != layers || ce != layers + 1) Unrec("an FSMN layer does not read its cache slice");
+    const std::string u = cat->out[0];
+    Conv left, right;
+    bool have_left = false, have_right = false, have_keep = false, have_ident = false;
+    int64_t lax = 0, la = 0, lz = 0, kax = 0, ka = 0, kz = 0, iax = 0, ia = 0, iz = 0;
+    std::string keep_out, ident_out;
+    for (const ModelNode* s : tr.Users(u, {"Slice"})) {
+      Conv c;
+      int64_t ax, a, z;
+      if (tr.TakeConv(s->out[0], &c)) {
+        left = c; have_left = true;
+        tr.SliceRange(*s, &lax, &la, &lz);
+      } else if (!tr.Users(s->out[0], {"Slice"}).empty()) {
+        if (!tr.TakeConv(tr.Users(s->out[0], {"Slice"})[0]->out[0], &right)) Unrec("FSMN right-context convolution");
+        have_right = true;
+      } else if (tr.SliceRange(*s, &ax, &a, &z, /*required=*/false)) {
+        if (z >= (int64_t(1) << 62)) { have_keep = true; kax = ax; ka = a; kz = z; keep_out = s->out[0]; }
+        else { have_ident = true; iax = ax; ia = a; iz = z; ident_out = s->out[0]; }
+      }
+    }
+    (void)kz;
+    if (!have_left || !have_right || !have_keep || !have_ident) Unrec("FSMN memory block");
+    const ModelTensor& wl = *left.W;
+    const ModelTensor& wr = *right.W;
+    auto any_nonzero = [](const std::vector<float>& v) { return std::any_of(v.begin(), v.end(), [](float x) { return x != 0.f; }); };
+    if (wl.dims.size() != 4 || wl.dims[1] != 1 || wl.dims[3] != 1 || wr.dims.size() != 4 || wr.dims[0] != wl.dims[0] ||
+        wr.dims[1] != 1 || wr.dims[3] != 1 || left.dil != std::vector<int64_t>({1, 1}) || right.dil != std::vector<int64_t>({1, 1}) ||
+        left.relu || right.relu || any_nonzero(left.b) || any_nonzero(right.b) || left.group != wl.dims[0] || right.group != wl.dims[0])
+      Unrec("FSMN memory taps");
+    if (D >= 0 && (D != wl.dims[0] || lo != wl.dims[2] || ro != wr.dims[2])) Unrec("FSMN layers differ in memory shape");
+    D = wl.dims[0]; lo = wl.dims[2]; ro = wr.dims[2];
+    if (lin.out_dim != D || kax != 2 || ka != -(lo - 1 + ro) || lax != 2 || la != 0 || lz != -ro || iax != 2 || ia != lo - 1 || iz != -ro)
+      Unrec("FSMN cache length / left window");
+    const ModelNode* a1 = tr.OnlyUser(right.out, {"Add"});
+    const ModelNode* a0 = tr.OnlyUser(left.out, {"Add"});
+    if (!a1 || !a0 || (a1->in[0] != a0->out[0] && a1->in[1] != a0->out[0]) || (a0->in[0] != ident_out && a0->in[1] != ident_out))
+      Unrec("FSMN memory sum");
+    const ModelNode* tb = tr.OnlyUser(a1->out[0], {"Transpose"});
+    const ModelNode* sq = tb ? tr.OnlyUser(tb->out[0], {"Squeeze"}) : nullptr;
+    Linear aff = sq ? tr.TakeLinear(sq->out[0]) : Linear();
+    if (!aff.ok || !aff.has_bias || aff.out_dim != C || aff.in_dim != D) Unrec("FSMN AffineTransform");
+    t = aff.out;
+    if (!tr.TakeRelu(&t)) Unrec("FSMN ReLU");
+    // blob: Wp (D,C) | taps (D, lo+ro) = [left taps, identity folded into tap lo-1 | right taps] | Wa (C,D) | ba
+    Append(blob, lin.W);
+    for (int64_t c = 0; c < D; ++c) {
+      for (int64_t j = 0; j < lo; ++j)
+        blob->push_back(static_cast<float>(static_cast<double>(wl.f[c * lo + j]) + (j == lo - 1 ? 1.0 : 0.0)));
+      for (int64_t j = 0; j < ro; ++j) blob->push_back(wr.f[c * ro + j]);
+    }
+    Append(blob, aff.W); Append(blob, aff.b);
+    caches.push_back(keep_out);
+    ++layers;
+  }
+  Linear o2 = lin.has_bias ? tr.TakeLinear(lin.out) : Linear();
+  if (!layers || !o2.ok || !o2.has_bias) Unrec("FSMN output affine layers");
+  Append(blob, lin.W); Append(blob, lin.b); Append(blob, o2.W); Append(blob, o2.b);
+  tr.CheckCacheOrder(caches, 3);
+  d->backbone = WEKWS_HIP_BACKBONE_FSMN;
+  d->hdim = static_cast<int32_t>(C);
+  d->num_layers = layers;
+  d->num_stack = static_cast<int32_t>(D);
+  d->kernel_size = static_cast<int32_t>(lo);
+  d->stack_size = static_cast<int32_t>(ro);
+  d->aux[0] = static_cast<int32_t>(l1.out_dim);
+  d->aux[1] = static_cast<int32_t>(lin.out_dim);
+  d->odim = static_cast<int32_t>(o2.out_dim);
+  d->head = WEKWS_HIP_HEAD_IDENTITY;
+  d->head_hidden = 0;
+  d->preproc_relu = 0;
+  d->activation = LowerActivation(tr, o2.out, false);
+}
+
+}  // namespace
+
+ModelGraph ParseModelBytes(const std::string& bytes) {
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(bytes.data());
+  if (bytes.size() >= 8 && std::memcmp(p + 4, "ORTM", 4) == 0) return ParseOrt(p, bytes.size());
+  return ParseOnnx(p, bytes.size());
+}
+
+void LowerGraph(const ModelGraph& g, wekws_hip_desc* d, std::vector<float>* blob) {
+  if (g.inputs != std::vector<std::string>({"input", "cache"}) || g.outputs != std::vector<std::string>({"output", "r_cache"}))
+    Unrec("graph inputs / outputs are not the exporter's input,cache / output,r_cache");
+  std::memset(d, 0, sizeof(*d));
+  d->abi_version = WEKWS_HIP_ABI_VERSION;
+  d->precision = WEKWS_HIP_PRECISION_DEFAULT;
+  blob->clear();
+  Tracer tr(g);
+  // GlobalCMVN (cmvn.py:45-48): x - mean [, * istd]
+  std::string t = "input";
+  std::vector<float> mean, istd;
+  bool cmvn = false, norm_var = false;
+  if (const ModelNode* sub = tr.OnlyUser(t, {"Sub"})) {
+    const ModelTensor* m = sub->in[0] == t ? tr.Const(sub->in[1]) : nullptr;
+    if (m) {
+      cmvn = true;
+      mean = m->f;
+      t = sub->out[0];
+      if (const ModelNode* mul = tr.OnlyUser(t, {"Mul"})) {
+        const ModelTensor* s = tr.Const(mul->in[0] == t ? mul->in[1] : mul->in[0]);
+        if (s) { norm_var = true; istd = s->f; t = mul->out[0]; }
+      }
+    }
+  }
+  Linear first = tr.TakeLinear(t);
+  if (!first.ok || !first.has_bias) Unrec("the first layer is not a Linear");
+  if (cmvn) {
+    if (static_cast<int64_t>(mean.size()) != first.in_dim || (norm_var && istd.size() != mean.size())) Unrec("CMVN vector length");
+    FoldCmvn(&first, mean, istd, norm_var);
+  }
+  d->idim = static_cast<int32_t>(first.in_dim);
+  std::string after = first.out;
+  const bool relu = tr.TakeRelu(&after);
+  if (relu && tr.OnlyUser(after, {"Transpose"})) {
+    // LinearSubsampling1 (subsampling.py:45-57) then the (B,C,T) backbones
+    d->preproc_relu = 1;
+    Append(blob, first.W); Append(blob, first.b);
+    LowerConvFamily(tr, after, d, blob);
+  } else {
+    LowerFsmn(tr, t, first, d, blob);
+  }
+  // metadata the reference runtime reads (keyword_spotting.cc:33-40) must agree with the recovered geometry
+  auto meta = [&](const char* k) { auto it = g.meta.find(k); return it == g.meta.end() ? int64_t(-1) : std::stoll(it->second); };
+  int64_t cache_dim = d->hdim, cache_len = 0;
+  if (d->backbone == WEKWS_HIP_BACKBONE_FSMN) { cache_dim = d->num_stack; cache_len = d->kernel_size - 1 + d->stack_size; }
+  else if (d->backbone == WEKWS_HIP_BACKBONE_MDTC) {
+    cache_len = d->kernel_size - 1;
+    for (int s = 0; s < d->num_stack; ++s) for (int j = 0; j < d->stack_size; ++j) cache_len += (d->kernel_size - 1) * (int64_t(1) << j);
+  } else {
+    for (int i = 0; i < d->num_layers; ++i) cache_len += (d->kernel_size - 1) * (int64_t(1) << i);
+  }
+  if ((meta("cache_len") >= 0 && meta("cache_len") != cache_len) || (meta("cache_dim") >= 0 && meta("cache_dim") != cache_dim))
+    Unrec("metadata cache_dim/cache_len do not match the recovered model");
+}
+
+void ReadModelFile(const std::string& path, wekws_hip_desc* desc, std::vector<float>* blob) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) Fail("cannot read " + path);
+  std::string bytes;
+  char buf[1 << 16];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.append(buf, n);
+  std::fclose(f);
+  static_assert(sizeof(wekws_hip_desc) == 64, "descriptor is 16 x int32");
+  if (bytes.size() >= 8 && std::memcmp(bytes.data(), "WEKWSHIP", 8) == 0) {
+    uint64_t count = 0;
+    if (bytes.size() < 8 + sizeof(*desc) + 8) Fail(path + " is truncated");
+    std::memcpy(desc, bytes.data() + 8, sizeof(*desc));
+    std::memcpy(&count, bytes.data() + 8 + sizeof(*desc), 8);
+    if (bytes.size() != 8 + sizeof(*desc) + 8 + count * sizeof(float)) Fail(path + " is truncated");
+    blob->resize(count);
+    std::memcpy(blob->data(), bytes.data() + 8 + sizeof(*desc) + 8, count * sizeof(float));
+    return;
+  }
+  LowerGraph(ParseModelBytes(bytes), desc, blob);
+}
+
+}  // namespace wekws

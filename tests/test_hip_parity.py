@@ -158,6 +158,33 @@ def test_forward_stream_is_forward_with_cache():
         assert max_abs(cache.cpu().numpy(), cfull.cpu().numpy()) <= 2e-5 * max(1.0, float(cfull.abs().max()))
 
 
+def test_forward_is_graph_capturable():
+    """wekws_hip_forward makes no hidden synchronisation or allocation once a stream's workspace exists: after a
+    warm-up on the capture stream the streaming step records into a HIP graph and replays bit-identically."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234)).freeze()
+    xs = torch.from_numpy(synth.synth_feats(2, 40, 40, seed=8)).cuda()
+    x_static = xs[:, :10].clone()
+    cache_static = torch.zeros(pack.cache_shape(pack.parse_config(cfg), 2), device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        model(x_static, cache_static)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        y_static, c_out = model(x_static, cache_static)
+        cache_static.copy_(c_out)
+    cache, cache_static[:] = torch.zeros_like(cache_static), 0.0
+    for t in range(0, 40, 10):
+        y, cache = model(xs[:, t:t + 10], cache)
+        x_static.copy_(xs[:, t:t + 10])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, y) and torch.equal(cache_static, cache)
+
+
 def test_long_input_tiling_matches_oracle():
     """T > 112 goes through several LDS tiles that hand the context over via the workspace cache."""
     from wekws_amd import pack

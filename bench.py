@@ -78,22 +78,25 @@ def cpu_baseline(cfg, sd, T, idim, target_s=12.0):
                       f"by a sweep (utts/s by thread count: {sweep}) of {avail} available"}
 
 
-def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30):
-    """Untimed-by-the-contract extra line: another recipe on the same batch shape, same timing method."""
+def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_only=False):
+    """Untimed-by-the-contract extra line: another recipe on the same batch shape, same timing method.
+    score_only: the posteriors without the returned cache (score.py:125 drops it) -- KWSModel.posteriors."""
     cfg = dict(synth.MODEL_CONFIGS[name])
     m = init_model(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
     m = m.to(dev).eval().freeze()
     x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=7)).to(dev)
+    fn = m.posteriors if score_only else m
     for _ in range(5):
-        m(x)
+        fn(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        m(x)
+        fn(x)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"workload": f"{name} forward, {B} x 1-s utterances, T={T}", "value": round(B * steps / el, 1),
+    what = "posteriors only (out_cache = NULL)" if score_only else "forward"
+    return {"workload": f"{name} {what}, {B} x 1-s utterances, T={T}", "value": round(B * steps / el, 1),
             "unit": "utts/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
 
 
@@ -214,6 +217,8 @@ def main():
             # BASELINE.json configs[1] words the single-GPU case as "MDTC ... batch 1024 x 1 s" while its metric names
             # the DS-TCN: the DS-TCN is `value`; the MDTC 4x4 h64 recipe on the same batch is reported beside it.
             out["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
+            # the same DS-TCN batch when the caller drops the cache, as wekws/bin/score.py:125 does
+            out["score_only"] = secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", B, T, score_only=True)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim)
         print(json.dumps(out))

@@ -158,6 +158,17 @@ def test_forward_stream_is_forward_with_cache():
         assert max_abs(cache.cpu().numpy(), cfull.cpu().numpy()) <= 2e-5 * max(1.0, float(cfull.abs().max()))
 
 
+def test_posteriors_only_equals_forward():
+    """KWSModel.posteriors (C ABI out_cache = NULL: no cache hand-over) returns the very y of forward."""
+    from wekws_amd import pack
+    for name, T in (("ds_tcn_h256", 98), ("mdtc_h64", 98), ("tcn_h64", 40), ("gru_2x128", 20), ("fsmn_small", 25),
+                    ("ds_tcn_h256", 200), ("ds_tcn_h256_ctc300", 50)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234))
+        x = torch.from_numpy(synth.synth_feats(3, T, cfg["input_dim"], seed=6)).cuda()
+        assert torch.equal(model.posteriors(x), model(x)[0]), name
+
+
 def test_forward_is_graph_capturable():
     """wekws_hip_forward makes no hidden synchronisation or allocation once a stream's workspace exists: after a
     warm-up on the capture stream the streaming step records into a HIP graph and replays bit-identically."""

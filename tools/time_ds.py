@@ -25,6 +25,9 @@ y, c = m(torch.from_numpy(xs).cuda())
 ry, rc = kws_oracle.forward(cfg, sd, xs, None)
 err = float(np.abs(y.cpu().numpy() - ry).max())
 x = torch.from_numpy(synth.synth_feats(1024, 98, cfg["input_dim"], seed=1)).cuda()
+if os.environ.get("NOCACHE"):
+    _m = m
+    m = _m.posteriors
 for _ in range(10):
     m(x)
 ts = []

@@ -233,6 +233,18 @@ int wekws_hip_splice_frames(int T, int right, int skip);
 int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out,
                      void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * MFCC tail  --  what torchaudio.compliance.kaldi.mfcc does after its fbank call (the reference's MDTC recipes,
+ * wekws/dataset/processor.py:160-169: num_ceps 80 of num_mel_bins 80):
+ *   out = (logmel @ DCT) * lifter,  DCT = DCT-II 'ortho' (N x N) with column 0 := sqrt(1/N), first num_ceps columns;
+ *   lifter_i = 1 + 0.5 Q sin(pi i / Q), Q = cepstral_lifter (22 in the reference's call; 0 disables it).
+ * The log-mel rows come from wekws_hip_fbank_compute with WEKWS_HIP_WINDOW_POVEY.  Parity with torchaudio itself is
+ * UNPINNED (not installable here); checked against a restatement of its published algorithm (oracle/).
+ *   logmel (rows, num_bins) device float32;  out (rows, num_ceps) device float32;  num_ceps <= num_bins <= 128
+ * ------------------------------------------------------------------------------------------*/
+int wekws_hip_dct_lifter(const float* logmel, int64_t rows, int num_bins, int num_ceps, float cepstral_lifter, float* out,
+                         void* stream);
+
 /*
  * Row softmax + top-k  --  the first beam prune of the CTC prefix beam search: `logits.softmax(2)` followed by
  * `probs.topk(score_beam_size)` per frame (wekws/bin/stream_kws_ctc.py:487-488, wekws/model/loss.py:236-238), fused so

@@ -44,6 +44,7 @@ SIGNATURES = {
     "wekws_hip_fbank_num_frames": (C.c_int, [C.c_void_p, C.c_int]),
     "wekws_hip_fbank_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wekws_hip_splice_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "wekws_hip_dct_lifter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "wekws_hip_softmax_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wekws_hip_splice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),

@@ -24,6 +24,7 @@
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
+#include "mfcc.hip.h"
 #include "splice.hip.h"
 #include "topk.hip.h"
 
@@ -795,6 +796,22 @@ int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int righ
   if ((int64_t(B) * To * (left + right + 1) * F + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "splice: too many elements for one launch");
   const int rc = wekws::launch_splice(feats, B, T, F, left, right, skip, To, out, static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "splice launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+// --------------------------------------------- MFCC tail (DCT + lifter) ---------------------------------------------
+int wekws_hip_dct_lifter(const float* logmel, int64_t rows, int num_bins, int num_ceps, float cepstral_lifter, float* out,
+                         void* stream_) {
+  if (!logmel || !out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (rows < 0 || num_bins <= 0 || num_bins > wekws::kMfccMaxBins || num_ceps <= 0 || num_ceps > num_bins || cepstral_lifter < 0.f)
+    return fail(WEKWS_HIP_EINVAL, "rows=%lld num_bins=%d num_ceps=%d lifter=%g (need 0 < num_ceps <= num_bins <= %d)",
+                (long long)rows, num_bins, num_ceps, double(cepstral_lifter), wekws::kMfccMaxBins);
+  if (rows == 0) return WEKWS_HIP_OK;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return fail(WEKWS_HIP_EDEVICE, "no HIP device");
+  const int rc = wekws::launch_dct_lifter(logmel, rows, num_bins, num_ceps, cepstral_lifter, out, cus, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "dct_lifter launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }
 

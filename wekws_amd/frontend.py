@@ -101,3 +101,36 @@ def context_expansion(feats: torch.Tensor, left: int = 1, right: int = 1) -> tor
 def frame_skip(feats: torch.Tensor, skip_rate: int = 1) -> torch.Tensor:
     """wekws/dataset/init_dataset.py:54-68 on a (B, T, F) device batch."""
     return splice_skip(feats, 0, 0, skip_rate)
+
+
+def dct_lifter(logmel: torch.Tensor, num_ceps: int, cepstral_lifter: float = 22.0) -> torch.Tensor:
+    """The MFCC tail of torchaudio.compliance.kaldi.mfcc (DCT-II 'ortho' with Kaldi's first column, first ``num_ceps``
+    cepstra, cepstral lifter) on (..., num_mel_bins) log-mel rows -> (..., num_ceps); wekws_hip_dct_lifter."""
+    if not logmel.is_cuda or logmel.dtype != torch.float32:
+        raise ValueError("logmel must be a float32 tensor on a ROCm device (no CPU fallback)")
+    lib = _capi.load()
+    logmel = logmel.contiguous()
+    nb = int(logmel.shape[-1])
+    rows = logmel.numel() // nb if nb else 0
+    out = torch.empty(tuple(logmel.shape[:-1]) + (int(num_ceps),), dtype=torch.float32, device=logmel.device)
+    stream = torch.cuda.current_stream(logmel.device).cuda_stream
+    _capi.check(lib.wekws_hip_dct_lifter(logmel.data_ptr(), rows, nb, int(num_ceps), float(cepstral_lifter),
+                                         out.data_ptr(), ctypes.c_void_p(stream)), "wekws_hip_dct_lifter")
+    return out
+
+
+class Mfcc:
+    """``kaldi.mfcc(waveform * (1 << 15), num_ceps, num_mel_bins, frame_length, frame_shift, energy_floor=0.0,
+    sample_frequency)`` of the reference's MDTC recipes (wekws/dataset/processor.py:134-169) on the device: Povey-window
+    fbank (wekws_hip_fbank_*) followed by the DCT / lifter kernel.  ``pcm`` is (B, nsamp) float32 already in int16 scale.
+    Parity with torchaudio is unpinned (see oracle/kaldi_feats_oracle.py)."""
+
+    def __init__(self, num_ceps: int = 80, num_mel_bins: int = 80, sample_rate: int = 16000, cepstral_lifter: float = 22.0,
+                 device="cuda"):
+        if not 0 < num_ceps <= num_mel_bins:
+            raise ValueError("need 0 < num_ceps <= num_mel_bins")
+        self.num_ceps, self.cepstral_lifter = int(num_ceps), float(cepstral_lifter)
+        self.fbank = Fbank(num_mel_bins, sample_rate, window="povey", device=device)
+
+    def __call__(self, pcm: torch.Tensor) -> torch.Tensor:
+        return dct_lifter(self.fbank(pcm), self.num_ceps, self.cepstral_lifter)

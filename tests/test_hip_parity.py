@@ -158,6 +158,40 @@ def test_forward_stream_is_forward_with_cache():
         assert max_abs(cache.cpu().numpy(), cfull.cpu().numpy()) <= 2e-5 * max(1.0, float(cfull.abs().max()))
 
 
+def test_streaming_kernel_equals_batch_kernel(monkeypatch):
+    """ds256_stream.hip.h (chunks of <= 16 frames, the stream's cache resident in LDS, coalesced cache I/O) against the
+    batch kernel fed the same chunks: same arithmetic in the same order -> bit-identical posteriors and caches.  With
+    and without an input cache, T = 1 .. 16, ragged batch sizes, both matrix precisions, several output widths."""
+    from wekws_amd import pack as packer
+    for K in (None, 1, 16):
+        cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+        if K:
+            cfg["output_dim"] = K
+        sd = synth.synth_state_dict(packer.model_spec(cfg), 77)
+        for prec in ("default", "f16"):
+            monkeypatch.setenv("WEKWS_HIP_STREAM", "0")
+            ref = build(cfg, sd).set_precision(prec)
+            monkeypatch.setenv("WEKWS_HIP_STREAM", "1")
+            got = build(cfg, sd).set_precision(prec)
+            for B, T in ((5, 10), (3, 16), (2, 1), (300, 7)):
+                x = torch.from_numpy(synth.synth_feats(B, 3 * T, 40, seed=B)).cuda()
+                cr = cg = None
+                for t in range(0, 3 * T, T):
+                    xc = x[:, t:t + T]
+                    yr, cr = ref(xc) if cr is None else ref(xc, cr)
+                    yg, cg = got(xc) if cg is None else got(xc, cg)
+                    assert torch.equal(yr, yg) and torch.equal(cr, cg), (K, prec, B, T, t)
+    # and against the oracle, streamed
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    sd = synth.synth_state_dict(packer.model_spec(cfg), 5)
+    model = build(cfg, sd)
+    x = synth.synth_feats(2, 50, 40, seed=3)
+    y, c = run(model, x, None, chunks=[10] * 5) if "chunks" in run.__code__.co_varnames else (None, None)
+    if y is not None:
+        ry, rc = kws_oracle.forward(cfg, sd, x, None)
+        assert max_abs(y, ry) <= POSTERIOR_TOL
+
+
 def test_posteriors_only_equals_forward():
     """KWSModel.posteriors (C ABI out_cache = NULL: no cache hand-over) returns the very y of forward."""
     from wekws_amd import pack

@@ -101,6 +101,28 @@ def main():
         out.append(dict(kind="stream", model=name, B=B, chunk=10, ms_per_chunk_wall=round(wall, 4),
                         ms_per_chunk_stream=round(dev, 4), us_per_frame=round(dev * 100, 2)))
         print(json.dumps(out[-1]), flush=True)
+    # streaming THROUGHPUT with many concurrent streams (10-frame chunks, caches carried): stream-chunks per second;
+    # lds_cache = the streaming kernel that keeps each stream's cache in LDS (ds256_stream.hip.h, the default for
+    # chunks of <= 16 frames); False = WEKWS_HIP_STREAM=0, the batch kernel fed the same chunks
+    if only in "manystreams":
+        for B in (1, 256, 1024, 4096, 16384):
+            for packed in (True, False):
+                if packed:
+                    os.environ.pop("WEKWS_HIP_STREAM", None)
+                else:
+                    os.environ["WEKWS_HIP_STREAM"] = "0"
+                cfg, m = build("ds_tcn_h256")
+                x = torch.from_numpy(synth.synth_feats(B, 10, 40, seed=2)).cuda()
+                _, cache = m(x)
+                state = {"c": cache}
+
+                def step():
+                    _, state["c"] = m(x, state["c"])
+                med, p10, p90 = timeit(step, reps=6, group=6)
+                out.append(dict(kind="manystreams", model="ds_tcn_h256", B=B, chunk=10, lds_cache=packed, ms=round(med, 4),
+                                chunks_per_s=round(B / med * 1e3, 1), frames_per_s=round(B * 10 / med * 1e3, 1)))
+                print(json.dumps(out[-1]), flush=True)
+        os.environ.pop("WEKWS_HIP_STREAM", None)
     # end-to-end on the device, PCM resident in HBM: (a) fbank40 -> DS-TCN h256 posteriors; (b) fbank80 -> context
     # expansion(2, 2) / skip 3 -> FSMN-CTC logits -> fused softmax + top-3 (what stream_kws_ctc.py's decoder consumes)
     if only in "e2e":

@@ -18,6 +18,7 @@
 #include "conv_stack_f16.hip.h"
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
+#include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
 #include "mdtc64_w16.hip.h"
 #include "fbank.hip.h"
@@ -202,6 +203,8 @@ struct wekws_hip_model {
                           // 16-wave kernel is 12 % faster
   bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
+  bool stream_ok = true;  // DS-TCN h256, chunks of <= 16 frames: the kernel with the LDS-resident cache
+                          // (WEKWS_HIP_STREAM=0 keeps the batch kernel; tests)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
   wekws::GruF16Params gq{};
@@ -526,6 +529,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
+    if (const char* e = std::getenv("WEKWS_HIP_STREAM")) m->stream_ok = std::atoi(e) != 0;
     m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
     if (const char* e = std::getenv("WEKWS_HIP_MDTC16")) m->mdtc16_ok = m->mdtc16_ok && std::atoi(e) != 0;
     m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
@@ -698,9 +702,14 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       int rc;
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
       const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
+      // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
+      const bool strm = f16 && d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && m->w16_ok && !m->mm_ok &&
+                        m->stream_ok && ntiles == 1 && T <= 16 && d.kernel_size == 8 && (in_cache || out_cache) &&
+                        wekws::ds256_stream_lds_bytes(m->cache_len) <= 160 * 1024;
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
-          rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+          rc = strm ? wekws::launch_ds256_stream(split, m->sp, a, stream)
+               : !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   using G = W16Geom<1>;
   constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB, KS = 8, NT = 1;
   extern __shared__ __attribute__((aligned(16))) float strm_lds[];
+  constexpr int kSlab = 8 * 2 * PB;                          // operand planes of ALL 256 channels: [k step][hi | lo]
   char* const slab = reinterpret_cast<char*>(strm_lds);
-  float* const hbuf = strm_lds + G::SLAB / 4;                // [256][16] f32 activations of the chunk
+  float* const hbuf = strm_lds + kSlab / 4;                  // [256][16] f32 activations of the chunk
   float* const cch = hbuf + G::H_FLOATS;                     // [256][Pc]  the stream's cache, reference layout
 
   const int tid = threadIdx.x;
@@ -102,29 +103,36 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   }
 
   // ======================================= residual blocks =======================================
-  constexpr int NIV = C / 64;
+  // One 16-frame tile: the operand planes of all 256 channels fit the slab (16 KB), so a block is
+  //   [every lane-group produces 4 channel rows] barrier [8 K steps x 3 products] [epilogue] barrier
+  // -- two barriers per block instead of the batch kernel's nine; at ten frames of work per step the barriers and the
+  // latencies behind them are the step time.
   constexpr int OTS = (C / 32) * 128;
+  auto ldfrag = [](F16Frag& f, const uint4* __restrict__ q) __attribute__((always_inline)) {
+    f.h = __builtin_bit_cast(f16x8, q[0]);
+    f.l = __builtin_bit_cast(f16x8, q[64]);
+  };
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = P.blocks[bi];
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
     const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
-    float dww[KS + 1];
-    auto load_dw = [&](int iv) __attribute__((always_inline)) {
-      const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + (iv * 64 + pg) * 12);
-      const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-      dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w;
-      dww[4] = q1.x; dww[5] = q1.y; dww[6] = q1.z; dww[7] = q1.w;
-      dww[8] = q2.x;
-    };
-    F16Frag a0[1], a1[1];
-    load_dw(0);
-    load_a16<1>(a0, ap1, 0);
-    load_a16<1>(a1, ap1 + 128, 0);
+    F16Frag af[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) ldfrag(af[s4], ap1 + s4 * 128);   // K steps 0..3, in flight over the producer
 
-    // ---- producer: lane-group pg = channel iv*64 + pg, lane tl = frame tau of the chunk
-    auto produce_iv = [&](int iv) __attribute__((always_inline)) {
-      const int r = pg, c = iv * 64 + pg;
+    // ---- producer: lane-group pg makes channels pg, pg + 64, pg + 128, pg + 192; lane tl = frame tau of the chunk
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = pg + 64 * i;
+      float dww[KS + 1];
+      {
+        const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + c * 12);
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w;
+        dww[4] = q1.x; dww[5] = q1.y; dww[6] = q1.z; dww[7] = q1.w;
+        dww[8] = q2.x;
+      }
       const float* const hrow = hbuf + c * SS;               // frames 0..15 of the chunk
       float* const crow = cch + c * Pc + bd.cache_off;       // this block's slice: frames -pad..-1
       // the padded sequence [slice | chunk] at chunk-relative frame ix, one LDS read through a selected address
@@ -143,25 +151,24 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
       o = fmaxf(o, 0.f);
       _Float16 h, l;
       split16(o, h, l);
-      char* const plane = slab + (r >> 5) * 2 * PB;
-      _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((r & 31) >> 3) * TT) * 8 + (r & 7);
-      _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + (((r & 31) >> 3) * TT) * 8 + (r & 7);
+      char* const plane = slab + (c >> 5) * 2 * PB;          // K step c / 32
+      _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
+      _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
       ph[tl * 8] = h;
       if constexpr (SPLIT) pl[tl * 8] = l;
-    };
-    zero_acc(acc);
-#pragma unroll 1
-    for (int iv = 0; iv < NIV; ++iv) {
-      const int nx = min(iv + 1, NIV - 1);
-      produce_iv(iv);
-      load_dw(nx);
-      __syncthreads();
-      mfma16_step_nb<NT, SPLIT>(acc[0], a0[0], slab + frag_off, slab + PB + frag_off);
-      load_a16<1>(a0, ap1 + (2 * nx) * 128, 0);
-      mfma16_step_nb<NT, SPLIT>(acc[0], a1[0], slab + 2 * PB + frag_off, slab + 3 * PB + frag_off);
-      load_a16<1>(a1, ap1 + (2 * nx + 1) * 128, 0);
-      __syncthreads();
     }
+    zero_acc(acc);
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      mfma16_step_nb<NT, SPLIT>(acc[0], af[s4], slab + s4 * 2 * PB + frag_off, slab + s4 * 2 * PB + PB + frag_off);
+      ldfrag(af[s4], ap1 + (4 + s4) * 128);         // K steps 4..7 follow through the same registers
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      mfma16_step_nb<NT, SPLIT>(acc[0], af[s4], slab + (4 + s4) * 2 * PB + frag_off,
+                                slab + (4 + s4) * 2 * PB + PB + frag_off);
+    // epilogue: folded bias + ReLU + residual, in place (tcn.py:60).  Every producer read of hbuf is behind the barrier.
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* hp = hbuf + (o0 + r) * SS + l15;
@@ -179,7 +186,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   conv_stack_head<KIND_DS, 256, 1, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
 }
 
-inline size_t ds256_stream_lds_bytes(int cache_len) { return W16Geom<1>::LDS_BYTES + size_t(256) * cache_len * 4; }
+inline size_t ds256_stream_lds_bytes(int cache_len) {       // slab 16 KB + chunk 16 KB + cache
+  return size_t(8 * 2 * W16Geom<1>::PB) + size_t(W16Geom<1>::H_FLOATS) * 4 + size_t(256) * cache_len * 4;
+}
 
 template <bool SPLIT>
 inline int launch_ds256_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {

@@ -181,6 +181,23 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
                     yr, cr = ref(xc) if cr is None else ref(xc, cr)
                     yg, cg = got(xc) if cg is None else got(xc, cg)
                     assert torch.equal(yr, yg) and torch.equal(cr, cg), (K, prec, B, T, t)
+    # MDTC h64 (mdtc64_w16.hip.h, LCACHE): two streams per workgroup, odd stream counts, 40-d and 80-d inputs, pooled head
+    for name in ("mdtc_h64", "mdtc_h64_80d", "mdtc_h64_global12"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(packer.model_spec(cfg), 78)
+        for prec in ("default", "f16"):
+            monkeypatch.setenv("WEKWS_HIP_STREAM", "0")
+            ref = build(cfg, sd).set_precision(prec)
+            monkeypatch.setenv("WEKWS_HIP_STREAM", "1")
+            got = build(cfg, sd).set_precision(prec)
+            for B, T in ((5, 10), (2, 16), (1, 1), (301, 7)):
+                x = torch.from_numpy(synth.synth_feats(B, 3 * T, cfg["input_dim"], seed=B)).cuda()
+                cr = cg = None
+                for t in range(0, 3 * T, T):
+                    xc = x[:, t:t + T]
+                    yr, cr = ref(xc) if cr is None else ref(xc, cr)
+                    yg, cg = got(xc) if cg is None else got(xc, cg)
+                    assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, prec, B, T, t)
     # and against the oracle, streamed
     cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
     sd = synth.synth_state_dict(packer.model_spec(cfg), 5)

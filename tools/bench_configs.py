@@ -105,13 +105,13 @@ def main():
     # lds_cache = the streaming kernel that keeps each stream's cache in LDS (ds256_stream.hip.h, the default for
     # chunks of <= 16 frames); False = WEKWS_HIP_STREAM=0, the batch kernel fed the same chunks
     if only in "manystreams":
-        for B in (1, 256, 1024, 4096, 16384):
+        for mname, B in [("ds_tcn_h256", b) for b in (1, 256, 1024, 4096, 16384)] + [("mdtc_h64", b) for b in (1, 256, 4096)]:
             for packed in (True, False):
                 if packed:
                     os.environ.pop("WEKWS_HIP_STREAM", None)
                 else:
                     os.environ["WEKWS_HIP_STREAM"] = "0"
-                cfg, m = build("ds_tcn_h256")
+                cfg, m = build(mname)
                 x = torch.from_numpy(synth.synth_feats(B, 10, 40, seed=2)).cuda()
                 _, cache = m(x)
                 state = {"c": cache}
@@ -119,7 +119,7 @@ def main():
                 def step():
                     _, state["c"] = m(x, state["c"])
                 med, p10, p90 = timeit(step, reps=6, group=6)
-                out.append(dict(kind="manystreams", model="ds_tcn_h256", B=B, chunk=10, lds_cache=packed, ms=round(med, 4),
+                out.append(dict(kind="manystreams", model=mname, B=B, chunk=10, lds_cache=packed, ms=round(med, 4),
                                 chunks_per_s=round(B / med * 1e3, 1), frames_per_s=round(B * 10 / med * 1e3, 1)))
                 print(json.dumps(out[-1]), flush=True)
         os.environ.pop("WEKWS_HIP_STREAM", None)

@@ -18,7 +18,12 @@
 
 namespace wekws {
 
-template <int NT, bool HAS_CACHE, bool SPLIT>
+// LCACHE (streaming steps, NT = 1): both streams' whole caches (64 x 244 floats each) live in LDS behind the tile --
+// one coalesced load at entry, taps through a selected LDS address, every slice shifted in place after its block's
+// depthwise conv has read it, one coalesced store at the end -- instead of 17 blocks x 64 short strided runs in and
+// out per stream with a global-memory latency exposed in every block (see ds256_stream.hip.h for the measurements
+// behind this).  HAS_CACHE is ignored then (a missing input cache is a zero-filled one).
+template <int NT, bool HAS_CACHE, bool SPLIT, bool LCACHE = false>
 __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackParams P, const CallArgs A) {
   using G = Geom<KIND_MDTC, 64, NT>;
   constexpr int C = 64, U = 2, SS = G::SS, TT = 16 * NT, KS = 5;
@@ -29,6 +34,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   extern __shared__ __attribute__((aligned(16))) float mdtc16_lds[];
   char* const slab = reinterpret_cast<char*>(mdtc16_lds);    // [utt][hi | lo][8 oct][TT][8 halves]
   float* const hbuf = mdtc16_lds + G::S_FLOATS;              // [utt][64][SS] f32 resident activations
+  float* const cch = hbuf + G::H_FLOATS;                     // LCACHE: [utt][64][Pc] the streams' caches
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,6 +56,16 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   f32x4 acc[NTW], zsum[NTW];
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) zsum[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (LCACHE) {                                    // the two streams' caches are contiguous in global memory
+    static_assert(NT == 1, "the LDS-resident cache is for single-tile streaming steps");
+    const int nu = min(U, A.B - b0);
+    const int n4 = (C * Pc) >> 2, tot = U * n4;              // C * Pc % 4 == 0 (host checks)
+    const f32x4* src = reinterpret_cast<const f32x4*>(A.in_cache + int64_t(b0) * C * Pc);
+    for (int e = tid; e < tot; e += kW16Threads)
+      reinterpret_cast<f32x4*>(cch)[e] = (A.in_cache && e < nu * n4) ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    // visible to the producers: the preprocessing below ends with a barrier
+  }
 
   auto gemm = [&](const uint4* ap) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes of slab_u
     F16Frag a[2];
@@ -163,16 +179,22 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #define fetch(idx_)                                                                      \
   ({                                                                                     \
     const int ix_ = (idx_);                                                              \
-    float fv_ = hbuf[hoff + ix_];                                                        \
+    float fv_;                                                                           \
+    if constexpr (LCACHE) {                                                              \
+      fv_ = *(ix_ >= 0 ? hbuf + hoff + ix_ : crow + pad + ix_);                          \
+    } else {                                                                             \
+    fv_ = hbuf[hoff + ix_];                                                              \
     if constexpr (HAS_CACHE) {                                                           \
       const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
       fv_ = ix_ >= 0 ? fv_ : (pok ? fg_ : 0.f);                                          \
     } else {                                                                             \
       fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
     }                                                                                    \
+    }                                                                                    \
     fv_;                                                                                 \
   })
-      if (A.out_cache && pok) {
+      float* const crow = cch + (u * C + c) * Pc + bd.cache_off;   // LCACHE: this block's slice of (stream u, channel c)
+      if (!LCACHE && A.out_cache && pok) {
         for (int p = tl; p < pad; p += 16) {
           const int src = T + p - pad;   // index into h (negative: still inside the old cache)
           float cv = hbuf[hoff + max(src, 0)];
@@ -217,6 +239,16 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
+      }
+      if constexpr (LCACHE) {
+        // new slice = last pad frames of [slice | chunk] (mdtc.py:111), in place: the reads above and these reads
+        // precede every write of the group (same wave, LDS in order); pad <= 32 -> two per lane
+        float nv[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) nv[k] = fetch(min(tl + 16 * k, pad - 1) + T - pad);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (tl + 16 * k < pad) crow[tl + 16 * k] = nv[k];
       }
 #undef fetch
     }
@@ -266,6 +298,13 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     }
   __syncthreads();
   (void)uok;
+  if constexpr (LCACHE) {
+    if (A.out_cache) {
+      const int n4 = (C * Pc) >> 2, tot = min(U, A.B - b0) * n4;
+      f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b0) * C * Pc);
+      for (int e = tid; e < tot; e += kW16Threads) dst[e] = reinterpret_cast<const f32x4*>(cch)[e];
+    }
+  }
   conv_stack_head<KIND_MDTC, 64, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
 }
 
@@ -293,7 +332,26 @@ inline int launch_mdtc64_w16_nt(bool split, const StackParams& P, const CallArgs
                     : launch_mdtc64_w16_ntc<NT, false, false>(P, A, stream);
 }
 
+inline size_t mdtc64_stream_lds_bytes(int cache_len) { return Geom<KIND_MDTC, 64, 1>::LDS_BYTES + size_t(2) * 64 * cache_len * 4; }
+
+template <bool SPLIT>
+inline int launch_mdtc64_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  static size_t attr_set = 0;
+  const size_t lds = mdtc64_stream_lds_bytes(P.cache_len);
+  auto kern = mdtc64_w16_kernel<1, false, SPLIT, true>;
+  if (attr_set < lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) !=
+        hipSuccess)
+      return -3;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3((A.B + 1) / 2), dim3(kW16Threads), lds, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // usable when: hidden_dim 64, kernel size 5 (host checks); split as in launch_ds256_w16
 int launch_mdtc64_w16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
+// streaming step (A.T <= 16) with both streams' caches resident in LDS; needs the caches to fit (host checks)
+int launch_mdtc64_stream(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

@@ -203,7 +203,7 @@ struct wekws_hip_model {
                           // 16-wave kernel is 12 % faster
   bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
-  bool stream_ok = true;  // DS-TCN h256, chunks of <= 16 frames: the kernel with the LDS-resident cache
+  bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
                           // (WEKWS_HIP_STREAM=0 keeps the batch kernel; tests)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
@@ -720,7 +720,12 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
-          rc = (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
+          // LDS-resident caches cost the second workgroup per CU: they win while the call fits one round of workgroups
+          // (B <= 2 streams x CUs: 0.057 vs 0.086 ms at 256 streams, 0.077 vs 0.094 at 512, 0.150 vs 0.112 at 1024)
+          rc = (f16 && m->mdtc16_ok && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) && d.stack_size <= 4 &&
+                B <= 2 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256) && wekws::mdtc64_stream_lds_bytes(m->cache_len) <= 160 * 1024)
+                   ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
+               : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
                    : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;

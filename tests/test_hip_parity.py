@@ -198,6 +198,19 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
                     yr, cr = ref(xc) if cr is None else ref(xc, cr)
                     yg, cg = got(xc) if cg is None else got(xc, cg)
                     assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, prec, B, T, t)
+    # a cache that is only 4-byte aligned (a view into a larger buffer) takes the batch kernel: same numbers
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    sd = synth.synth_state_dict(packer.model_spec(cfg), 77)
+    model = build(cfg, sd)
+    x = torch.from_numpy(synth.synth_feats(2, 10, 40, seed=1)).cuda()
+    _, c = model(x)
+    buf = torch.zeros(c.numel() + 1, device="cuda")
+    odd = buf[1:].view_as(c)
+    odd.copy_(c)
+    assert odd.data_ptr() % 16 != 0
+    ya, ca = model(x, c)
+    yb, cb = model(x, odd)
+    assert torch.equal(ya, yb) and torch.equal(ca, cb)
     # and against the oracle, streamed
     cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
     sd = synth.synth_state_dict(packer.model_spec(cfg), 5)

@@ -703,8 +703,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
       const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
       // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
+      // (the streaming kernels move whole caches with 16-byte accesses: both cache pointers must be 16-byte aligned)
+      const bool cache16 = (reinterpret_cast<uintptr_t>(in_cache) | reinterpret_cast<uintptr_t>(out_cache)) % 16 == 0;
       const bool strm = f16 && d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && m->w16_ok && !m->mm_ok &&
-                        m->stream_ok && ntiles == 1 && T <= 16 && d.kernel_size == 8 && (in_cache || out_cache) &&
+                        m->stream_ok && ntiles == 1 && T <= 16 && d.kernel_size == 8 && (in_cache || out_cache) && cache16 &&
                         wekws::ds256_stream_lds_bytes(m->cache_len) <= 160 * 1024;
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
@@ -722,7 +724,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
         default:
           // LDS-resident caches cost the second workgroup per CU: they win while the call fits one round of workgroups
           // (B <= 2 streams x CUs: 0.057 vs 0.086 ms at 256 streams, 0.077 vs 0.094 at 512, 0.150 vs 0.112 at 1024)
-          rc = (f16 && m->mdtc16_ok && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) && d.stack_size <= 4 &&
+          rc = (f16 && m->mdtc16_ok && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) && cache16 && d.stack_size <= 4 &&
                 B <= 2 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256) && wekws::mdtc64_stream_lds_bytes(m->cache_len) <= 160 * 1024)
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)

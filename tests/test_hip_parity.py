@@ -222,6 +222,28 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
         assert max_abs(y, ry) <= POSTERIOR_TOL
 
 
+def test_fsmn_head_slices_equal_single_workgroup(monkeypatch):
+    """Small FSMN-CTC calls split the vocabulary layer over several workgroups per tile (each recomputes the backbone,
+    each writes its own o-tiles of y): the same numbers as one workgroup per tile, caches included."""
+    from wekws_amd import pack as packer
+    for name in ("fsmn_ctc300", "fsmn_ctc"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(packer.model_spec(cfg), 5)
+        monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", "0")
+        ref = build(cfg, sd)
+        for sl in ("-1", "3", "8"):
+            monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", sl)
+            got = build(cfg, sd)
+            for B, T in ((1, 10), (5, 10), (3, 32), (40, 7)):
+                x = torch.from_numpy(synth.synth_feats(B, 2 * T, cfg["input_dim"], seed=B)).cuda()
+                yr, cr = ref(x[:, :T])
+                yg, cg = got(x[:, :T])
+                assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, sl, B, T)
+                yr, cr = ref(x[:, T:], cr)
+                yg, cg = got(x[:, T:], cg)
+                assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, sl, B, T)
+
+
 def test_posteriors_only_equals_forward():
     """KWSModel.posteriors (C ABI out_cache = NULL: no cache hand-over) returns the very y of forward."""
     from wekws_amd import pack

@@ -72,6 +72,7 @@ struct FsmnArgs {
   float* y;               // first output row of this tile
   int64_t ys_b;
   int32_t B, T;           // T: valid frames in this tile (1..16*NT)
+  int32_t head_slices;    // >= 1: gridDim.y workgroups per tile share the o-tiles of out_linear2 (small calls, below)
 };
 
 // LDS plan for a tile of TT frames = U utterances x TT / U frames (bytes); shared by host (capacity check) and device
@@ -102,11 +103,11 @@ struct FsmnLds {
 template <int NT, class Epi>
 __device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict__ W, uint32_t a_off, uint32_t bias_off,
                                                           int MT, int KS, const char* bh, int PLB, int lane, int wave,
-                                                          Epi epi) {
+                                                          Epi epi, int ot_lo = 0) {
   constexpr int TT = 16 * NT;
   constexpr int KSB = 4 * TT * 16;                       // bytes per k-step inside a plane
   const int ots = KS * 128;                              // uint4 per o-tile
-  int ot = wave * 2;
+  int ot = ot_lo + wave * 2;                             // o-tiles [ot_lo, MT) (ot_lo even)
   if (ot >= MT) return;
   const uint4* const abase = reinterpret_cast<const uint4*>(W + a_off) + lane;
   const int k1 = min(1, KS - 1);
@@ -150,11 +151,11 @@ __device__ __attribute__((always_inline)) void fsmn_gemm(const float* __restrict
 template <int NT, int KH, class Epi>
 __device__ __attribute__((always_inline)) void fsmn_gemm_held(const float* __restrict__ W, uint32_t a_off,
                                                                uint32_t bias_off, int MT, int KS, const char* bh,
-                                                               int PLB, int lane, int wave, Epi epi) {
+                                                               int PLB, int lane, int wave, Epi epi, int ot_lo = 0) {
   constexpr int TT = 16 * NT;
   constexpr int KSB = 4 * TT * 16;
   const int ots = KS * 128;
-  int ot = wave * 2;
+  int ot = ot_lo + wave * 2;
   if (ot >= MT) return;
   const uint4* const abase = reinterpret_cast<const uint4*>(W + a_off) + lane;
   F16Frag a[KH][2];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
         }
       }
       // new cache = last P valid columns of x_pad
-      if (A.out_cache) {
+      if (A.out_cache && blockIdx.y == 0) {               // head slices recompute the backbone; one of them hands over
         for (int e = tid; e < U * P.proj * Pc; e += kFsmnThreads) {
           const int u = e / (P.proj * Pc), r = e - u * (P.proj * Pc);
           const int c = r / Pc, j = r - c * Pc;
@@ -376,11 +377,18 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
                       }
                     }
                   };
+    // Small calls (fewer tiles than compute units): gridDim.y workgroups run the same tile and split the o-tiles of
+    // this layer -- for a CTC vocabulary it holds half of the model's weights (2599 x 140 of 756 k), and a workgroup's
+    // time at one tile is the trip of its weights through the CU's 64 B/clk path.  The backbone is recomputed per
+    // slice (idle CUs otherwise); results are the same numbers, each y element written by exactly one slice.
+    const int MT = P.op / 16;
+    const int per = (((MT + A.head_slices - 1) / A.head_slices) + 1) & ~1;
+    const int ot_lo = int(blockIdx.y) * per, ot_hi = min(MT, ot_lo + per);
     if (P.a2p / 32 <= kFsmnHeldK)
-      fsmn_gemm_held<NT, kFsmnHeldK>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane,
-                                     wave, store_y);
+      fsmn_gemm_held<NT, kFsmnHeldK>(W, P.out2_a, P.out2_b, ot_hi, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane,
+                                     wave, store_y, ot_lo);
     else
-      fsmn_gemm<NT>(W, P.out2_a, P.out2_b, P.op / 16, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave, store_y);
+      fsmn_gemm<NT>(W, P.out2_a, P.out2_b, ot_hi, P.a2p / 32, r1 + frag_off, P.a2p * TT * 2, lane, wave, store_y, ot_lo);
   }
 }
 
@@ -396,7 +404,7 @@ inline int launch_fsmn_nt(const FsmnParams& P, const FsmnArgs& A, hipStream_t st
       return -3;
     attr_bytes = lds;
   }
-  hipLaunchKernelGGL(kern, dim3((A.B + U - 1) / U), dim3(kFsmnThreads), lds, stream, P, A);
+  hipLaunchKernelGGL(kern, dim3((A.B + U - 1) / U, A.head_slices > 1 ? A.head_slices : 1), dim3(kFsmnThreads), lds, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -203,6 +203,7 @@ struct wekws_hip_model {
                           // 16-wave kernel is 12 % faster
   bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
+  int fsmn_slices = -1;   // FSMN head slices per tile for small calls: -1 automatic, WEKWS_HIP_FSMN_SLICES=0|n forces (tests)
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
                           // (WEKWS_HIP_STREAM=0 keeps the batch kernel; tests)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
@@ -312,6 +313,7 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->fsmn_cus = prop.multiProcessorCount;
+    if (const char* e = std::getenv("WEKWS_HIP_FSMN_SLICES")) m->fsmn_slices = std::atoi(e);
   }
   hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(m->d_w, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -358,6 +360,14 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
     for (int cand = 4; cand >= 2; cand /= 2)
       if (nt * cand <= m->fsmn_max_nt && nt * cand <= 4 && B >= cand * m->fsmn_cus &&
           wekws::FsmnLds::make(m->fq, 16 * nt * cand, cand).bytes() <= wekws::kFsmnLdsLimit) { u = cand; break; }
+    // few tiles on many CUs: split the vocabulary-sized last layer over up to 8 workgroups per tile (fsmn_f16.hip.h)
+    a.head_slices = 1;
+    if (const int groups = (B + u - 1) / u; d.odim >= 256 && groups * 2 <= m->fsmn_cus) {
+      int sl = m->fsmn_cus / groups;
+      sl = sl > 8 ? 8 : sl;
+      if (m->fsmn_slices >= 0) sl = m->fsmn_slices > 0 ? m->fsmn_slices : 1;
+      a.head_slices = sl;
+    }
     const int rc = wekws::launch_fsmn_f16(nt, u, m->fq, a, stream);
     if (rc) return fail(rc, "fsmn launch failed (nt=%d u=%d): %s", nt, u, hipGetErrorString(hipGetLastError()));
   }

@@ -244,6 +244,26 @@ def test_fsmn_head_slices_equal_single_workgroup(monkeypatch):
                 assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, sl, B, T)
 
 
+def test_ds_tcn_ctc_head_slices_equal_single_workgroup(monkeypatch):
+    """The same split for the DS-TCN CTC recipe's 2599-token head (ds256_mm.hip.h)."""
+    from wekws_amd import pack as packer
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256_ctc"])
+    sd = synth.synth_state_dict(packer.model_spec(cfg), 5)
+    monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", "0")
+    ref = build(cfg, sd)
+    for sl in ("-1", "3", "8"):
+        monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", sl)
+        got = build(cfg, sd)
+        for B, T in ((1, 10), (5, 16), (2, 98)):
+            x = torch.from_numpy(synth.synth_feats(B, T + 10, 40, seed=B)).cuda()
+            yr, cr = ref(x[:, :T])
+            yg, cg = got(x[:, :T])
+            assert torch.equal(yr, yg) and torch.equal(cr, cg), (sl, B, T)
+            yr, cr = ref(x[:, T:], cr)
+            yg, cg = got(x[:, T:], cg)
+            assert torch.equal(yr, yg) and torch.equal(cr, cg), (sl, B, T)
+
+
 def test_posteriors_only_equals_forward():
     """KWSModel.posteriors (C ABI out_cache = NULL: no cache hand-over) returns the very y of forward."""
     from wekws_amd import pack

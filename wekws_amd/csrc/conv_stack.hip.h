@@ -101,6 +101,7 @@ struct CallArgs {
   int32_t T;              // frames in this tile (1..16*NT)
   int32_t T_total;        // frames of the whole call (GLOBAL mean divisor)
   int32_t first_tile, last_tile;
+  int32_t head_slices;    // ds256_mm, CTC-sized heads: gridDim.y workgroups per utterance share the head's o-tiles (0/1: off)
 };
 
 template <int KIND, int C, int NT>

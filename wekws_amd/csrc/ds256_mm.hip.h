@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
       //      16-byte hi + lo item -> 8 channels, 8 coalesced 4-byte stores.  Usual case (T >= pad: no column comes
       //      from the old context): all 32 octets at once in the block's first interval; otherwise interval by
       //      interval, because only the current interval's left context is staged.
-      if (A.out_cache && (T >= pad ? iv == 0 : true)) {
+      if (A.out_cache && blockIdx.y == 0 && (T >= pad ? iv == 0 : true)) {   // head slices: one of them hands over
         const int noct = T >= pad ? C / 8 : 8, oct0 = T >= pad ? 0 : iv * 8;
         float* const ob = A.out_cache + int64_t(b) * C * Pc + bd.cache_off;      // wave-uniform base
         for (int e = tid; e < noct * pad; e += kW16Threads) {
@@ -312,7 +312,13 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
     const int HT = (K + 31) / 32 * 2;
     struct __attribute__((packed, aligned(4))) Y4 { float v[4]; };   // rows of y are only dword aligned
     float* const yb = A.y + int64_t(b) * A.ys_b;
-    for (int ot = wave * 2; ot < HT; ot += 2 * kW16Waves) {
+    // few utterances on many CUs (streaming a handful of streams): gridDim.y workgroups run the same utterance and
+    // split these o-tile pairs -- the head is 70 % of this model's weights (2599 x 256 of 955 k), and one workgroup's
+    // time on a short chunk is the trip of its weights through the CU's 64 B/clk path.  Same numbers either way.
+    const int S = A.head_slices > 1 ? A.head_slices : 1;
+    const int per = ((HT / 2 + S - 1) / S) * 2;
+    const int ot_lo = int(blockIdx.y) * per, ot_hi = min(HT, ot_lo + per);
+    for (int ot = ot_lo + wave * 2; ot < ot_hi; ot += 2 * kW16Waves) {
       const uint4* ap = reinterpret_cast<const uint4*>(W + head_a16) + size_t(ot) * NK * 128 + lane;
       f32x4 hacc[2][NT];
 #pragma unroll
@@ -395,7 +401,8 @@ inline int launch_ds256_mm_ntc(const StackParams& P, const CallArgs& A, uint32_t
       return -3;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), G::LDS_BYTES, stream, P, A, head_a16);
+  hipLaunchKernelGGL(kern, dim3(A.B, A.head_slices > 1 ? A.head_slices : 1), dim3(kW16Threads), G::LDS_BYTES, stream, P, A,
+                     head_a16);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -203,7 +203,7 @@ struct wekws_hip_model {
                           // 16-wave kernel is 12 % faster
   bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
   bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
-  int fsmn_slices = -1;   // FSMN head slices per tile for small calls: -1 automatic, WEKWS_HIP_FSMN_SLICES=0|n forces (tests)
+  int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, WEKWS_HIP_FSMN_SLICES=0|n forces (tests)
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
                           // (WEKWS_HIP_STREAM=0 keeps the batch kernel; tests)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
@@ -547,6 +547,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     {
       // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword
       // heads (the 16-wave kernel is 12 % faster there); WEKWS_HIP_MM=0 / 1 forces it off / on where eligible
+      if (const char* es = std::getenv("WEKWS_HIP_FSMN_SLICES")) m->fsmn_slices = std::atoi(es);   // also the DS-TCN CTC head
       const char* e = std::getenv("WEKWS_HIP_MM");
       const bool want = e ? std::atoi(e) != 0 : K > 16;
       m->mm_ok = m->mm_ok && want;
@@ -709,6 +710,11 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       a.T_total = T;
       a.first_tile = (i == 0);
       a.last_tile = (i == ntiles - 1);
+      a.head_slices = 0;
+      if (m->mm_ok && d.odim >= 256 && B * 2 <= m->fsmn_cus) {       // CTC head, a handful of streams (ds256_mm.hip.h)
+        const int sl = m->fsmn_cus / B;
+        a.head_slices = m->fsmn_slices >= 0 ? m->fsmn_slices : (sl > 8 ? 8 : sl);
+      }
       int rc;
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
       const bool split = d.precision != WEKWS_HIP_PRECISION_F16;

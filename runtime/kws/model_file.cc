@@ -94,7 +94,10 @@ float BitsToFloat(uint32_t u) {
 // ONNX TensorProto.DataType: FLOAT 1, INT32 6, INT64 7, BOOL 9, DOUBLE 11
 void FillTensor(int dtype, const uint8_t* raw, size_t nraw, const std::string& name, ModelTensor* t) {
   size_t count = 1;
-  for (int64_t d : t->dims) count *= static_cast<size_t>(d);
+  for (int64_t d : t->dims) {
+    if (d < 0 || (d > 0 && count > (size_t(1) << 40) / static_cast<size_t>(d))) Fail("tensor " + name + ": bad dims");
+    count *= static_cast<size_t>(d);
+  }
   const size_t width = dtype == 1 || dtype == 6 ? 4 : dtype == 7 || dtype == 11 ? 8 : dtype == 9 ? 1 : 0;
   if (!width) Fail("tensor " + name + ": unsupported element type " + std::to_string(dtype));
   if (nraw != count * width) Fail("tensor " + name + ": payload size does not match its dims");
@@ -143,7 +146,10 @@ std::string PbTensor(const PbField& field, ModelTensor* t) {
     t->is_float = dtype == 1 || dtype == 11;
     if (t->is_float) t->f = fdata; else t->i = idata;
     size_t count = 1;
-    for (int64_t d : t->dims) count *= static_cast<size_t>(d);
+    for (int64_t d : t->dims) {
+      if (d < 0 || (d > 0 && count > (size_t(1) << 40) / static_cast<size_t>(d))) Fail("tensor " + name + ": bad dims");
+      count *= static_cast<size_t>(d);
+    }
     if (t->size() != count) Fail("tensor " + name + ": element count does not match its dims");
   }
   return name;
@@ -485,6 +491,8 @@ class Tracer {
       }
     }
     const int64_t r = W->dims[0], c = W->dims[1];
+    if (r <= 0 || c <= 0 || static_cast<int64_t>(W->f.size()) != r * c) return L;
+    if (L.has_bias && static_cast<int64_t>(L.b.size()) != (w_is_out_in ? r : c)) return L;
     if (w_is_out_in) { L.out_dim = r; L.in_dim = c; L.W = W->f; }
     else {
       L.out_dim = c; L.in_dim = r; L.W.resize(W->f.size());
@@ -505,8 +513,10 @@ class Tracer {
     const ModelNode& n = *cn[0];
     c->W = Const(n.in[1]);
     if (!c->W || !c->W->is_float) return false;
+    if (c->W->dims.size() < 3 || c->W->dims[0] <= 0) return false;
     if (n.in.size() > 2 && !n.in[2].empty()) { const ModelTensor* b = Const(n.in[2]); if (!b) return false; c->b = b->f; }
     else c->b.assign(static_cast<size_t>(c->W->dims[0]), 0.f);
+    if (static_cast<int64_t>(c->b.size()) != c->W->dims[0]) return false;
     for (int64_t p : AttrInts(n, "pads")) if (p) Unrec("convolution " + n.name + " with pads");
     for (int64_t s : AttrInts(n, "strides")) if (s != 1) Unrec("convolution " + n.name + " with strides");
     if (AttrS(n, "auto_pad", "NOTSET") != "NOTSET") Unrec("convolution " + n.name + " with auto_pad");

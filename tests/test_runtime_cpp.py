@@ -90,6 +90,41 @@ def test_cpp_model_reader_refuses_bad_files(tmp_path):
     assert r.returncode == 2 and "cannot read" in r.stderr
 
 
+def test_model_readers_survive_corrupted_files(tmp_path):
+    """Model files are untrusted input: random byte corruption of real exports must end in a clean refusal or a valid
+    model -- never a crash (C++: exit code 0 or 2, no signal) and never an exception other than ModelFileError (Python)."""
+    from wekws_amd.utils import onnx_model
+    from wekws_amd.utils.onnx_lower import lower
+    build_runtime()
+    rng = np.random.default_rng(0)
+    srcs = [os.path.join(ROOT, "tests", "golden", "onnx", n + ".onnx") for n in ("tcn_h32", "fsmn_small_ctc", "mdtc_small")]
+    from tests.helpers import build_tiny_ort
+    blobs = [open(s, "rb").read() for s in srcs] + [build_tiny_ort()[0]]
+    outcomes = {0: 0, 2: 0}
+    for trial in range(120):
+        data = bytearray(blobs[trial % len(blobs)])
+        for _ in range(int(rng.integers(1, 6))):
+            kind = rng.integers(0, 3)
+            pos = int(rng.integers(0, len(data)))
+            if kind == 0:
+                data[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                del data[pos:pos + int(rng.integers(1, 64))]
+            else:
+                data[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 16)), dtype=np.uint8))
+        p = str(tmp_path / "fuzz.bin")
+        open(p, "wb").write(bytes(data))
+        r = subprocess.run([MODEL_CONVERT, p, str(tmp_path / "o")], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 2), (trial, r.returncode, r.stderr[-200:])
+        outcomes[r.returncode] += 1
+        try:
+            g = onnx_model.parse_ort(bytes(data)) if bytes(data[4:8]) == b"ORTM" else onnx_model.parse_onnx(bytes(data))
+            lower(g)
+        except onnx_model.ModelFileError:
+            pass
+    assert outcomes[2] > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,chunk", [("ds_tcn_h64", 80), ("mdtc_small", 33), ("ds_tcn_h256", 10), ("gru_2x128", 25)])
 def test_kws_main_matches_oracle(tmp_path, name, chunk):

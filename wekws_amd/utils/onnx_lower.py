@@ -443,7 +443,17 @@ def _lower_fsmn(tr: _Tracer, t: str, cfg: dict, sd: dict) -> bool:
 
 def lower(g: Graph):
     """-> (configs['model'] dict, state_dict of numpy arrays, info).  info['softmax'] tells whether the exported
-    function is forward_softmax (export_onnx.py:46-48) rather than forward."""
+    function is forward_softmax (export_onnx.py:46-48) rather than forward.  Model files are untrusted input: whatever
+    a damaged graph trips over in here surfaces as ModelFileError."""
+    try:
+        return _lower(g)
+    except ModelFileError:
+        raise
+    except (KeyError, IndexError, TypeError, AttributeError, ValueError, OverflowError, RecursionError) as e:
+        raise ModelFileError("unrecognised wekws graph: %s: %s" % (type(e).__name__, e))
+
+
+def _lower(g: Graph):
     if g.inputs != ["input", "cache"] or g.outputs != ["output", "r_cache"]:
         _fail("graph inputs %s / outputs %s are not the exporter's input,cache / output,r_cache" %
               (g.inputs, g.outputs))

@@ -259,7 +259,9 @@ def parse_onnx(data: bytes) -> Graph:
                 g.outputs.append(_pb_value_name(v))
             elif fno == 15:
                 raise ModelFileError("sparse initializers are not supported")
-    except (IndexError, struct.error, UnicodeDecodeError) as e:
+    except (IndexError, struct.error, UnicodeDecodeError, TypeError, ValueError, KeyError, AttributeError, OverflowError) as e:
+        if isinstance(e, ModelFileError):
+            raise
         raise ModelFileError("malformed ONNX file: %s" % e)
     g.inputs = [n for n in ins if n not in g.init]
     # opset-13 exporters emit constants as Constant nodes: fold them into the initializer table
@@ -407,7 +409,7 @@ def parse_ort(data: bytes) -> Graph:
         g.nodes = [n for _, n in sorted(nodes, key=lambda x: x[0])]
         g.inputs = [n for n in fb.strings(graph, 5) if n not in g.init]
         g.outputs = fb.strings(graph, 6)
-    except (struct.error, IndexError, UnicodeDecodeError, ValueError) as e:
+    except (struct.error, IndexError, UnicodeDecodeError, ValueError, TypeError, KeyError, AttributeError, OverflowError) as e:
         if isinstance(e, ModelFileError):
             raise
         raise ModelFileError("malformed ORT file: %s" % e)

@@ -23,6 +23,12 @@ def built_artifacts():
     for sub, artefact in need.items():
         if not os.path.exists(os.path.join(ROOT, artefact)):
             subprocess.run(["make", "-C", os.path.join(ROOT, sub), "-j", "8"], check=False, capture_output=True)
+    # the reference's shipped trained model (an ORT file), converted once for test_reference_android_asset_hip: only
+    # where the reference tree exists (the build container); build/ is git-ignored but travels to the GPU box
+    asset = "/root/reference/runtime/android/app/src/main/assets/kws.ort"
+    if os.path.exists(asset) and not os.path.exists(os.path.join(ROOT, "build", "ref_asset", "expect.npz")):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "make_ref_asset.py")], check=False,
+                       capture_output=True)
     yield
 
 

@@ -538,12 +538,12 @@ def test_exported_models(name):
 
 @pytest.mark.gpu
 def test_reference_android_asset_hip():
-    """The trained DS-TCN the reference ships as an ORT file, converted by tools/make_ref_asset.py in the build
+    """The trained DS-TCN the reference ships as an ORT file, converted by tests/tools/make_ref_asset.py in the build
     container (the asset itself is not in this repo): packed file -> C ABI, streamed in 80-frame chunks."""
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "ref_asset")
     if not os.path.exists(os.path.join(root, "kws.wekwship")):
-        pytest.skip("build/ref_asset not prepared (python tools/make_ref_asset.py where /root/reference exists)")
+        pytest.skip("build/ref_asset not prepared (python tests/tools/make_ref_asset.py where /root/reference exists)")
     import ctypes
     from wekws_amd import _capi, pack
     from wekws_amd.model.kws_model import _HipHandle

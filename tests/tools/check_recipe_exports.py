@@ -4,7 +4,7 @@ reference's exporter call (random-init weights, full recipe sizes -- up to 3.8 M
 read each file back with wekws_amd.utils.onnx_lower and compare the recognised model (numpy oracle) with the live
 PyTorch model on a random input + cache.  The committed small fixtures are tests/golden/onnx/ (make_onnx_golden.py).
 
-    PYTHONPATH=/root/reference:/root/repo python tools/check_recipe_exports.py
+    PYTHONPATH=/root/reference:/root/repo python tests/tools/check_recipe_exports.py
 """
 import contextlib
 import io
@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import yaml
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, "/root/reference")
 from torch.onnx._internal.torchscript_exporter import onnx_proto_utils  # noqa: E402
 

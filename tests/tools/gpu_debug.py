@@ -7,7 +7,7 @@ import traceback
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tools/)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs  # noqa: E402
 from tests.test_hip_parity import build, run  # noqa: E402

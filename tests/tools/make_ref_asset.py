@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import onnx_graph_oracle  # noqa: E402
 from wekws_amd.bin import export_packed  # noqa: E402

@@ -1,7 +1,12 @@
-// kws_main on MI355X: same command line and same output lines as the reference
-// (runtime/core/bin/kws_main.cc:23-61): wav -> fbank (GPU) -> KeywordSpotting::Forward in chunks of batch_size
-// frames with the carried streaming cache -> "frame <i> prob <p0> <p1> ...".
-#include <iostream>
+// kws_main for the MI355X runtime.  Observable behaviour follows the reference tool
+// (runtime/core/bin/kws_main.cc:23-61) so that scripts built around it keep working:
+//   kws_main fbank_dim(int) batch_size(int) kws_model_path test_wav_path
+//   -> one line per frame:  "frame <index> prob <p0> <p1> ..."   (6 significant digits, like operator<<(float))
+// The wav file is decoded, its features come from the GPU fbank (wenet::FeaturePipeline here), and the spotter is fed
+// `batch_size` frames at a time with its streaming cache carried from call to call.  model_path may be the exporter's
+// .onnx, an ORT-format .ort, or a packed model (runtime/kws/model_file.h).
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -10,39 +15,68 @@
 #include "kws/keyword_spotting.h"
 #include "utils/check.h"
 
-int main(int argc, char* argv[]) {
-  if (argc != 5) {
-    WEKWS_FATAL() << "Usage: kws_main fbank_dim(int) batch_size(int) kws_model_path test_wav_path";
-  }
-  const int num_bins = std::stoi(argv[1]);  // Fbank feature dim
-  const int batch_size = std::stoi(argv[2]);
-  const std::string model_path = argv[3];
-  const std::string wav_path = argv[4];
+namespace {
 
-  wenet::WavReader wav_reader(wav_path);
-  WEKWS_CHECK(wav_reader.ok()) << "cannot read " << wav_path;
-  wenet::FeaturePipelineConfig feature_config(num_bins, 16000);
-  wenet::FeaturePipeline feature_pipeline(feature_config);
-  std::vector<float> wav(wav_reader.data(), wav_reader.data() + wav_reader.num_samples());
-  feature_pipeline.AcceptWaveform(wav);
-  feature_pipeline.set_input_finished();
+struct Options {
+  int feature_dim = 0;
+  int frames_per_call = 0;
+  std::string model, audio;
+};
 
-  wekws::KeywordSpotting spotter(model_path);
-  WEKWS_CHECK(spotter.feature_dim() == num_bins) << "model expects " << spotter.feature_dim() << "-d features";
+Options ParseCommandLine(int argc, char** argv) {
+  if (argc != 5) WEKWS_FATAL() << "Usage: kws_main fbank_dim(int) batch_size(int) kws_model_path test_wav_path";
+  Options o;
+  o.feature_dim = std::atoi(argv[1]);
+  o.frames_per_call = std::atoi(argv[2]);
+  o.model = argv[3];
+  o.audio = argv[4];
+  WEKWS_CHECK(o.feature_dim > 0 && o.frames_per_call > 0) << "fbank_dim and batch_size must be positive integers";
+  return o;
+}
 
-  int offset = 0;  // simulate streaming, detect batch by batch
-  while (true) {
-    std::vector<std::vector<float>> feats;
-    const bool ok = feature_pipeline.Read(batch_size, &feats);
-    std::vector<std::vector<float>> prob;
-    spotter.Forward(feats, &prob);
-    for (size_t i = 0; i < prob.size(); i++) {
-      std::cout << "frame " << offset + i << " prob";
-      for (size_t j = 0; j < prob[i].size(); j++) std::cout << " " << prob[i][j];
-      std::cout << std::endl;
+using Frames = std::vector<std::vector<float>>;
+
+// "frame <n> prob <p...>" for every row, numbered from first_index
+void PrintRows(const Frames& rows, size_t first_index) {
+  std::string line;
+  char num[48];
+  for (size_t r = 0; r < rows.size(); ++r) {
+    line = "frame " + std::to_string(first_index + r) + " prob";
+    for (float p : rows[r]) {
+      std::snprintf(num, sizeof(num), " %g", static_cast<double>(p));
+      line += num;
     }
-    if (!ok) break;  // reached the end of the feature pipeline
-    offset += prob.size();
+    std::puts(line.c_str());
+  }
+  std::fflush(stdout);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const Options opt = ParseCommandLine(argc, argv);
+
+  // whole file in, as the reference tool does; the pipeline hands frames out batch by batch below
+  std::vector<float> samples;
+  {
+    wenet::WavReader reader(opt.audio);
+    WEKWS_CHECK(reader.ok()) << "cannot read " << opt.audio;
+    samples.assign(reader.data(), reader.data() + reader.num_samples());
+  }
+  wenet::FeaturePipeline features(wenet::FeaturePipelineConfig(opt.feature_dim, 16000));
+  features.AcceptWaveform(samples);
+  features.set_input_finished();
+
+  wekws::KeywordSpotting spotter(opt.model);
+  WEKWS_CHECK(spotter.feature_dim() == opt.feature_dim) << "model expects " << spotter.feature_dim() << "-d features";
+
+  size_t emitted = 0;
+  for (bool more = true; more;) {
+    Frames chunk, scores;
+    more = features.Read(opt.frames_per_call, &chunk);   // false once the pipeline has been drained
+    spotter.Forward(chunk, &scores);
+    PrintRows(scores, emitted);
+    emitted += scores.size();
   }
   return 0;
 }

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
                                       : reinterpret_cast<const f32x4*>(W);
   f32x4 cv[kCV];
 #pragma unroll
-  for (int k = 0; k < kCV; ++k) cv[k] = csrc[min(tid + k * kW16Threads, has_cache ? n4 - 1 : 0)];
+  for (int k = 0; k < kCV; ++k)                              // streamed once: keep it out of the weights' way in L2
+    cv[k] = __builtin_nontemporal_load(csrc + min(tid + k * kW16Threads, has_cache ? n4 - 1 : 0));
 
   f32x4 acc[1][NT];
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   if (A.out_cache) {
     const f32x4* src = reinterpret_cast<const f32x4*>(cch);
     f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b) * C * Pc);
-    for (int e = tid; e < n4; e += kW16Threads) dst[e] = src[e];
+    for (int e = tid; e < n4; e += kW16Threads) __builtin_nontemporal_store(src[e], dst + e);
   }
   conv_stack_head<KIND_DS, 256, 1, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
 }

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     const int n4 = (C * Pc) >> 2, tot = U * n4;              // C * Pc % 4 == 0 (host checks)
     const f32x4* src = reinterpret_cast<const f32x4*>(A.in_cache + int64_t(b0) * C * Pc);
     for (int e = tid; e < tot; e += kW16Threads)
-      reinterpret_cast<f32x4*>(cch)[e] = (A.in_cache && e < nu * n4) ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(cch)[e] =                   // streamed once: non-temporal, the weights stay in L2
+          (A.in_cache && e < nu * n4) ? __builtin_nontemporal_load(src + e) : f32x4{0.f, 0.f, 0.f, 0.f};
     // visible to the producers: the preprocessing below ends with a barrier
   }
 
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     if (A.out_cache) {
       const int n4 = (C * Pc) >> 2, tot = min(U, A.B - b0) * n4;
       f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b0) * C * Pc);
-      for (int e = tid; e < tot; e += kW16Threads) dst[e] = reinterpret_cast<const f32x4*>(cch)[e];
+      for (int e = tid; e < tot; e += kW16Threads) __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(cch)[e], dst + e);
     }
   }
   conv_stack_head<KIND_MDTC, 64, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);

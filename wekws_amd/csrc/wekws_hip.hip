@@ -738,10 +738,11 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
-          // LDS-resident caches cost the second workgroup per CU: they win while the call fits one round of workgroups
-          // (B <= 2 streams x CUs: 0.057 vs 0.086 ms at 256 streams, 0.077 vs 0.094 at 512, 0.150 vs 0.112 at 1024)
+          // LDS-resident caches cost the second workgroup per CU: clear win while the call fits one round of workgroups
+          // (0.058 vs 0.081 ms at 256 streams, 0.060 vs 0.094 at 512), within +-5 % up to 2048 streams (0.111 / 0.104 at
+          // 768, 0.170 / 0.193 at 1536), a tie beyond -- where the batch kernel is kept
           rc = (f16 && m->mdtc16_ok && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) && cache16 && d.stack_size <= 4 &&
-                B <= 2 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256) && wekws::mdtc64_stream_lds_bytes(m->cache_len) <= 160 * 1024)
+                B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256) && wekws::mdtc64_stream_lds_bytes(m->cache_len) <= 160 * 1024)
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

@@ -36,3 +36,23 @@ def built_artifacts():
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "model_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def scale_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "scale_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def error_report():
+    """Measured errors of the parity tests, written to gpurun_out/parity_errors.json when the session ends (the bar
+    is an assertion; the margin is worth knowing: VERDICT r1)."""
+    import json
+    rec = {}
+    yield rec
+    if rec:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)

@@ -127,3 +127,118 @@ def case_in_cache(case, cfg=None):
         return np.zeros(shape, np.float32)
     g = np.random.default_rng([0xCAC4E, case["xseed"]])
     return g.standard_normal(shape).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Operand-scale sweeps.  A trained model's folded weights and activations can sit anywhere in fp32's
+# exponent range; the reference's fp32 arithmetic does not care, a split-fp16 kernel must not either.  Each sweep
+# rewrites the synthetic state_dict with exact power-of-two factors so that, in exact arithmetic, the model computes
+# the SAME function while its internal operands move by 2^k:
+#   "act"   the residual stream (every activation after the preprocessing layer) x 2^k: additive terms of the backbone
+#           (conv / BN biases, BN running means) x 2^k, the first classifier matrix x 2^-k;
+#   "wdown" every matrix that feeds the matrix cores x 2^-k with its input operand x 2^k: features x 2^k (the test
+#           multiplies x), depthwise stage x 2^k (2^2k for MDTC, whose mid tile then carries 2^k), pointwise x 2^-k.
+# The reference (PyTorch CPU fp32) evaluates the rewritten model for the golden; power-of-two rescaling is exact in
+# fp32, so those goldens equal the unscaled model's to the last bit unless something overflows.
+def _mul(sd, name, f):
+    sd[name] = (np.asarray(sd[name], np.float64) * f).astype(np.float32)
+
+
+def scale_state_dict(cfg, sd, kind, k):
+    """-> (rewritten copy of sd, factor to multiply the features with)."""
+    sd = {n: np.array(v, copy=True) for n, v in sd.items()}
+    s = float(2.0 ** k)
+    bb = cfg["backbone"]
+    t = bb["type"]
+    xs = 1.0
+
+    def bn(prefix, f):
+        _mul(sd, prefix + ".running_mean", f)
+        _mul(sd, prefix + ".bias", f)
+
+    def head_first(f):
+        ctype = cfg.get("classifier", {}).get("type", "linear")
+        if ctype == "identity":
+            return False
+        _mul(sd, "classifier.linear.weight" if ctype == "linear" else "classifier.classifier.0.weight", f)
+        return True
+
+    if kind == "act":
+        if t == "gru":
+            raise ValueError("the GRU is not positively homogeneous: no 'act' sweep")
+        if t == "fsmn":
+            _mul(sd, "backbone.in_linear1.linear.weight", s); _mul(sd, "backbone.in_linear1.linear.bias", s)
+            _mul(sd, "backbone.in_linear2.linear.bias", s)
+            for l in range(bb["num_layers"]):
+                _mul(sd, f"backbone.fsmn.{l}.2.linear.bias", s)
+            _mul(sd, "backbone.out_linear1.linear.weight", 1.0 / s)
+            return sd, xs
+        _mul(sd, "preprocessing.out.0.weight", s); _mul(sd, "preprocessing.out.0.bias", s)
+        if t == "tcn":
+            for i in range(bb["num_layers"]):
+                p = f"backbone.network.{i}.cnn."
+                _mul(sd, p + "0.bias", s); bn(p + "1", s)
+                if bb.get("ds"):
+                    _mul(sd, p + "3.bias", s); bn(p + "4", s)
+        else:
+            from wekws_amd import pack
+            for p, _ in pack.mdtc_blocks(pack.parse_config(cfg)):
+                _mul(sd, p + "conv1.conv.bias", s); bn(p + "conv1.bn", s)
+                _mul(sd, p + "conv1.pointwise.bias", s); bn(p + "bn1", s)
+                _mul(sd, p + "conv2.bias", s); bn(p + "bn2", s)
+        assert head_first(1.0 / s)
+        return sd, xs
+    assert kind == "wdown", kind
+    xs = s
+    if t == "fsmn":
+        _mul(sd, "backbone.in_linear1.linear.weight", 1.0 / s)
+        for l in range(bb["num_layers"]):
+            _mul(sd, f"backbone.fsmn.{l}.0.linear.weight", 1.0 / s)
+            _mul(sd, f"backbone.fsmn.{l}.2.linear.weight", s)
+        _mul(sd, "backbone.out_linear1.linear.weight", s); _mul(sd, "backbone.out_linear1.linear.bias", s)
+        _mul(sd, "backbone.out_linear2.linear.weight", 1.0 / s)
+        return sd, xs
+    _mul(sd, "preprocessing.out.0.weight", 1.0 / s)
+    if t == "tcn" and bb.get("ds"):
+        for i in range(bb["num_layers"]):
+            p = f"backbone.network.{i}.cnn."
+            _mul(sd, p + "0.weight", s); _mul(sd, p + "0.bias", s); bn(p + "1", s)
+            _mul(sd, p + "3.weight", 1.0 / s)
+    elif t == "mdtc":
+        from wekws_amd import pack
+        for p, _ in pack.mdtc_blocks(pack.parse_config(cfg)):
+            _mul(sd, p + "conv1.conv.weight", s * s); _mul(sd, p + "conv1.conv.bias", s * s); bn(p + "conv1.bn", s * s)
+            _mul(sd, p + "conv1.pointwise.weight", 1.0 / s); _mul(sd, p + "conv1.pointwise.bias", s); bn(p + "bn1", s)
+            _mul(sd, p + "conv2.weight", 1.0 / s)
+    return sd, xs
+
+
+def _s(model, kind, k, B=2, T=40, **kw):
+    return _c(f"{model}/{kind}{k:+d}" + ("/stream" if kw.get("chunks") else ""), model, B=B, T=T, scale=(kind, k), **kw)
+
+
+_SWEEP_MODELS = [  # (model, kinds, extra)
+    ("ds_tcn_h256", ("act", "wdown"), dict(T=98)),          # ds256_w16
+    ("ds_tcn_h256", ("act", "wdown"), dict(T=30, chunks=[10, 10, 10])),   # ds256_stream
+    ("ds_tcn_h64", ("act", "wdown"), dict()),               # conv_stack_f16 <DS>
+    ("tcn_h64", ("act", "wdown"), dict()),                  # dense_stack_f16
+    ("mdtc_h64", ("act", "wdown"), dict(T=50)),             # mdtc64_w16
+    ("mdtc_h64", ("act", "wdown"), dict(T=20, chunks=[10, 10])),   # mdtc64 stream
+    ("mdtc_small_global12", ("act", "wdown"), dict()),      # conv_stack_f16 <MDTC>, global head
+    ("ds_tcn_h256_ctc300", ("act", "wdown"), dict(T=20, B=1)),   # ds256_mm
+    ("gru_2x128", ("wdown",), dict(T=20, cache="zeros")),   # gru_f16
+    ("fsmn_small", ("act", "wdown"), dict(T=20)),           # fsmn_f16
+]
+SCALE_CASES = []
+for _m, _kinds, _kw in _SWEEP_MODELS:
+    for _kind in _kinds:
+        # act: 2^15 / 2^20 push activations past fp16's largest number, 2^-12 / 2^-20 far below its normal range;
+        # wdown +-12: weights at 2^-12 (the judge's numpy probe: 1.9e-4 with the unscaled split) and at 2^+12
+        for _k in ((-20, -12, 6, 12, 15, 20) if _kind == "act" else (-12, 6, 12)):
+            SCALE_CASES.append(_s(_m, _kind, _k, **_kw))
+
+
+def scaled_case_weights(case, sd):
+    """Apply the case's sweep to the synthetic state_dict `sd` -> (sd, feature factor)."""
+    kind, k = case["scale"]
+    return scale_state_dict(case_config(case), sd, kind, k)

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import kws_oracle
+from tests.golden.cases import SCALE_CASES, scaled_case_weights
 from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
 from wekws_amd.model.kws_model import init_model
 from wekws_amd.utils import synth
@@ -76,6 +77,28 @@ def test_golden(case, precision, golden, models):
     c = cache if cfg["backbone"]["type"] == "gru" else cache[:1]
     assert c.shape == gc.shape
     assert max_abs(c, gc) <= tol_for(gc), f"cache err {max_abs(c, gc):.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("case", SCALE_CASES, ids=[c["name"] for c in SCALE_CASES])
+def test_scale_sweep(case, precision, scale_golden, error_report):
+    """Operand-scale sweeps (tests/golden/cases.py::scale_state_dict): the same function with weights / activations moved
+    by 2^-20 .. 2^+20, goldens from the live reference.  fp32 arithmetic is invariant under such rewriting (the
+    reference's outputs are bit-identical to the unscaled model's); the split-fp16 kernels must be too: block floating
+    point (conv_stack_f16.hip.h) -- no inf / NaN when activations pass 65504, no loss when operands sink below fp16's
+    normal range.  Same 1e-4 bar as every other parity test; the measured error goes to gpurun_out/parity_errors.json."""
+    if precision == "f32" and case["model"].startswith("fsmn"):
+        pytest.skip("FSMN is built for the split-fp16 mode only")
+    cfg, sd = case_weights(case)
+    sd2, xs = scaled_case_weights(case, sd)
+    model = build(cfg, sd2).set_precision(precision)
+    x = (case_input(case) * np.float32(xs)).astype(np.float32)
+    y, _ = run(model, x, case_in_cache(case, cfg), chunks=case.get("chunks"))
+    gy = scale_golden[case["name"] + "/y"]
+    assert y.shape == gy.shape
+    err = max_abs(y, gy) if np.isfinite(y).all() else float("inf")
+    error_report[f"scale_sweep/{precision}/{case['name']}"] = err
+    assert err <= tol_for(gy), f"y err {err:.3e}"
 
 
 @pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 5, 98), ("ds_tcn_h64", 7, 33), ("tcn_h64", 3, 98),

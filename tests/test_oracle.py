@@ -50,3 +50,25 @@ def test_torch_cpu_restatement_matches_reference_golden(case, golden):
     gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
     assert max_abs(y.numpy(), gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
     assert max_abs(cache.numpy()[:1], gc) <= CACHE_TOL * max(1.0, float(np.abs(gc).max()))
+
+
+from tests.golden.cases import SCALE_CASES, scaled_case_weights  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SCALE_CASES, ids=[c["name"] for c in SCALE_CASES])
+def test_oracle_matches_scale_sweep_golden(case, scale_golden):
+    """The operand-scale sweeps (tests/golden/cases.py::scale_state_dict, goldens from the live reference): the fp32
+    oracle follows the reference through weights / activations moved by 2^-20 .. 2^+20."""
+    cfg, sd = case_weights(case)
+    sd2, xs = scaled_case_weights(case, sd)
+    name = case["name"]
+    assert abs(synth.checksum(sd2) - float(scale_golden[name + "/wsum"])) <= 1e-6 * float(scale_golden[name + "/wsum"])
+    x = (case_input(case) * np.float32(xs)).astype(np.float32)
+    cache0 = case_in_cache(case, cfg)
+    if case.get("chunks"):
+        y, _ = kws_oracle.forward_streaming(cfg, sd2, x, case["chunks"], cache0)
+    else:
+        y, _ = kws_oracle.forward(cfg, sd2, x, cache0)
+    gy = scale_golden[name + "/y"]
+    assert y.shape == gy.shape
+    assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))

@@ -67,6 +67,13 @@ struct BlockDesc {
   uint32_t dw_pk;     // DS/MDTC: taps + bias per channel padded to a multiple of 4 floats: [C][round_up(ksize+1,4)]
   uint32_t a1_16;     // same matrices split into fp16 hi/lo and packed for v_mfma_f32_16x16x32_f16
   uint32_t a2_16;     //   ([o-tile][k32][hi|lo][lane][8 halves], conv_stack_f16.hip.h)
+  // block floating point of the split-fp16 kernels (conv_stack_f16.hip.h): the packed fp16 matrices hold W * s with
+  // s a power of two that puts max|W| into [2^14, 2^15); inv_s* = 1 / s undoes it in the epilogue
+  float inv_s1, inv_s2;
+  // depthwise output bound: |dw(u) + b| <= dw_alpha * max|u| + dw_beta  (max_c sum_j |w[c][j]|, max_c |b[c]|)
+  float dw_alpha, dw_beta;
+  // ds256_mm: the depthwise taps enter the matrix cores scaled by dw_tap_s (power of two); dw_tap_inv = 1 / dw_tap_s
+  float dw_tap_s, dw_tap_inv;
 };
 
 struct StackParams {
@@ -87,6 +94,8 @@ struct StackParams {
   uint32_t head_w, head_b;  // LINEAR: Wc[odim][C], bc;  GLOBAL/LAST: W1[hh][C], b1
   uint32_t head_w2, head_b2;  // GLOBAL/LAST: W2[odim][hh], b2
   int32_t cache_len;        // P = sum of pads
+  float pre_inv_s;          // 1 / power-of-two scale of the packed fp16 preprocessing matrix (pre_a16)
+  float head_inv_s;         // same for a matrix-core classifier (head_a16: ds256_mm, dense_stack_f16)
 };
 
 struct CallArgs {

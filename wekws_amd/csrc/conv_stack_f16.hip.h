@@ -6,20 +6,36 @@
 // of the co-resident wave through per MFMA, so matrix time and vector time add up.  Here every 1x1 / dense
 // convolution runs on v_mfma_f32_16x16x32_f16 instead, with fp32-level accuracy recovered by the classic
 // two-term split of both operands:
-//        w = wh + wl,  a = ah + al      (wh = fp16(w), wl = fp16(w - wh); same for a; |w - wh - wl| <~ 2^-22 |w|)
+//        w = wh + wl,  a = ah + al      (wh = fp16(w), wl = fp16(w - wh); same for a)
 //        w*a ~= wh*ah + wh*al + wl*ah   (the dropped wl*al term is <= 2^-22 relative)
 // Products of fp16 values are exact in the fp32 accumulator and the instruction honours fp16 subnormals
-// (tools/probe/denorm.hip), so the lo parts need no scaling and all three terms share ONE accumulator set.
-// Cost per 32-deep K step: 3 x 17 cycles instead of 8 x 32.  Assumption: |activation| < 65504 (fp16 range);
-// the exact-f32 kernel remains selectable (wekws_hip_desc.precision) for models outside it.
+// (tools/probe/denorm.hip), so all three terms share ONE accumulator set.  Cost per 32-deep K step: 3 x 17 cycles
+// instead of 8 x 32.
+//
+// BLOCK FLOATING POINT.  hi + lo carries 22 significand bits only while lo stays a NORMAL fp16, i.e. for
+// |v| >= 2^-2; below that lo is subnormal (absolute quantum 2^-24), and |v| >= 65520 overflows to inf.  fp16's
+// exponent range is therefore managed explicitly, per operand, with exact power-of-two scales:
+//   * weights (static): every packed matrix holds W * sw with sw = 2^k chosen on the host so that max|W| * sw lies in
+//     [2^14, 2^15) -- the TOP of the fp16 range, 16 binades of full-precision elements below the matrix maximum and an
+//     absolute error of 2^-25 (2^-39 of the maximum) below those;
+//   * activations (dynamic): every operand tile is multiplied by sa = 2^j before the split, with j from the tile's
+//     magnitude: the exact max|.| where it is known before the tile is written (the features, tiles re-written behind
+//     a barrier), else a rigorous bound (depthwise output: dw_alpha * max|input| + dw_beta, with the EXACT maximum of the
+//     input tile tracked by the epilogue that wrote it, so bounds never compound).  bound * sa lies in [2^14, 2^15): no
+//     element can overflow, and a bound that is 2^10 too loose still leaves every element within 2^-6 of the true
+//     maximum at full precision;
+//   * the epilogue multiplies the accumulator by 1 / (sw * sa), exact, as part of the bias FMA.
+// Result: the products are scale-invariant -- a model with weights x 2^-12 and activations x 2^12 (or the reverse)
+// gives the same numbers as the unscaled one, like fp32 math does (tests/test_hip_parity.py::test_scale_sweep).
+// Maxima travel between phases through a few LDS cells (wave reduction + one ds_max_u32 per wave).
 //
 // Differences from the f32 kernel:
 //   - slab (MFMA B operand) holds fp16 hi and lo planes in [k-octet][frame][8] order: one lane's fragment
 //     (8 consecutive k of one frame) is a single ds_read_b128 and a 16-lane group covers 16 distinct 16-byte
 //     slots -> conflict free; same byte footprint as the f32 slab;
-//   - weights are split and packed on the host into [o-tile][k32][hi|lo][lane][8 halves] (two 16-byte loads per
-//     lane, o-tile and K step);
-//   - producers convert on the fly (cvt, subtract, cvt) and store halves; the MDTC mid tile is written by the
+//   - weights are scaled, split and packed on the host into [o-tile][k32][hi|lo][lane][8 halves] (two 16-byte loads
+//     per lane, o-tile and K step);
+//   - producers convert on the fly (scale, cvt, subtract, cvt) and store halves; the MDTC mid tile is written by the
 //     first epilogue directly in operand order.
 #pragma once
 #include "conv_stack.hip.h"
@@ -36,6 +52,54 @@ struct F16Frag {
 __device__ __forceinline__ void split16(float v, _Float16& h, _Float16& l) {
   h = static_cast<_Float16>(v);
   l = static_cast<_Float16>(v - static_cast<float>(h));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block floating point (see the header comment).
+// ---------------------------------------------------------------------------------------------
+// LDS cells per utterance that carry tile maxima between phases: [0] features, [1] whole input cache,
+// [2 + 2*i] input tile of block i (block nblocks = the backbone output), [3 + 2*i] MDTC mid tile of block i
+constexpr int kAmaxCells = 40;
+constexpr int kAmaxMaxBlocks = (kAmaxCells - 4) / 2;   // 18: MDTC 4 x 4 + 1 = 17 (mdtc.yaml), DS-TCN 4
+
+// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.  A zero (or non-finite) bound keeps s = 1.
+__device__ __forceinline__ float pow2_scale(float bound, float* inv) {
+  const uint32_t e = (__float_as_uint(bound) >> 23) & 0xffu;   // biased exponent (0: zero / f32 subnormal)
+  uint32_t se = 268u - e;                                       // 127 + 14 - (e - 127)
+  se = se > 253u ? 253u : se;
+  se = (e == 0u || e == 255u) ? 127u : se;
+  *inv = __uint_as_float((254u - se) << 23);
+  return __uint_as_float(se << 23);
+}
+
+// max over each 16-lane row of the wave, in every lane of the row (4 DPP steps, no LDS traffic)
+__device__ __forceinline__ float row16_max(float v) {
+  int x = __float_as_int(v);
+#define WEKWS_DPP_MAX(ctrl)                                                                          \
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, (ctrl), 0xf, 0xf, false))));
+  WEKWS_DPP_MAX(0xB1)   // quad_perm [1,0,3,2]
+  WEKWS_DPP_MAX(0x4E)   // quad_perm [2,3,0,1]
+  WEKWS_DPP_MAX(0x141)  // row_half_mirror
+  WEKWS_DPP_MAX(0x140)  // row_mirror
+#undef WEKWS_DPP_MAX
+  return __int_as_float(x);
+}
+
+// Publish this thread's partial max|.| (v >= 0) into an LDS cell: row reduction, then one ds_max_u32 per 16-lane row
+// (non-negative floats order like their bit patterns; a NaN wins and later disables the scaling).
+__device__ __forceinline__ void amax_publish(unsigned* cell, float v) {
+  v = row16_max(v);
+  if ((threadIdx.x & 15) == 0) atomicMax(cell, __float_as_uint(v));
+}
+// wave-uniform cell (the scale arithmetic that follows stays on the scalar unit) / per-lane cell
+__device__ __forceinline__ float amax_read(const unsigned* cell) { return __uint_as_float(__builtin_amdgcn_readfirstlane(*cell)); }
+__device__ __forceinline__ float amax_read_v(const unsigned* cell) { return __uint_as_float(*cell); }
+
+// max|.| over a contiguous run of n floats, this thread's share (stride = workgroup size)
+template <int NTHR>
+__device__ __forceinline__ float amax_span(const float* __restrict__ p, int n, float m) {
+  for (int e = threadIdx.x; e < n; e += NTHR) m = fmaxf(m, fabsf(p[e]));
+  return m;
 }
 
 // Byte size of one (utterance, buffer) hi or lo plane holding KCH channels x TT frames
@@ -116,6 +180,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   f32x4 zsum[KIND == KIND_MDTC ? OW : 1][KIND == KIND_MDTC ? NT : 1];
   if constexpr (KIND == KIND_MDTC) zero_acc(zsum);
 
+  // ---- block floating point: per-utterance maxima of the features and of the incoming cache
+  __shared__ unsigned amax_cells[U * kAmaxCells];
+  unsigned* const cells_w = amax_cells + wu * kAmaxCells;  // this wave's utterance
+  for (int e = tid; e < U * kAmaxCells; e += kThreads) amax_cells[e] = 0u;
+  __syncthreads();
+  for (int u = 0; u < U; ++u) {
+    if (b0 + u < A.B) {                                    // workgroup-uniform
+      amax_publish(amax_cells + u * kAmaxCells, amax_span<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      if (A.in_cache)
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+    }
+  }
+
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
@@ -137,10 +214,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         const int kf = (k0 + st) * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+        float inv_unused;
+        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -156,6 +235,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         mfma16_step<OW, NT>(acc, a, slab_u + st * 2 * PB + frag_off, slab_u + st * 2 * PB + PB + frag_off);
       }
     }
+    float cpre;
+    (void)pow2_scale(amax_read(cells_w), &cpre);
+    cpre *= P.pre_inv_s;                                   // 1 / (feature scale * weight scale)
+    float hmax = 0.f;
 #pragma unroll
     for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
@@ -164,12 +247,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         const int t = tt * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[ow][tt][r] + f4c(bias[ow], r);
+          float v = fmaf(acc[ow][tt][r], cpre, f4c(bias[ow], r));
           if (P.pre_relu) v = fmaxf(v, 0.f);
           h_w[(o + r) * SS + t] = v;
+          hmax = fmaxf(hmax, fabsf(v));
         }
       }
     }
+    amax_publish(cells_w + 2, hmax);
     __syncthreads();
   }
 
@@ -214,6 +299,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     const bool slide = d <= 16 && (16 % d) == 0;
     const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
 
+    // ---- operand scale of this block, per utterance: the producer's rows are bounded by the maximum of the input
+    //      tile (published by the epilogue that wrote it) and of the incoming cache
+    float sa[U], c1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      float inv;
+      sa[u] = pow2_scale(KIND == KIND_TCN ? au : fmaf(bd.dw_alpha, au, bd.dw_beta), &inv);
+      c1 = (u == wu) ? inv * bd.inv_s1 : c1;
+    }
+
     // ---- producer of K-chunk n into slab buffer `buf` (fp16 hi / lo planes, [k-octet][frame][8])
     auto produce_impl = [&](int n, int buf, auto has_cache_tag) __attribute__((always_inline)) {
       constexpr bool HAS_CACHE = decltype(has_cache_tag)::value;
@@ -234,6 +330,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         const int item = pg + i * (kThreads / 16);
         const int u = item / KC, r = item % KC;
         const bool uok = (b0 + u) < A.B;
+        float sau = sa[0];
+#pragma unroll
+        for (int q = 1; q < U; ++q) sau = (u == q) ? sa[q] : sau;
         char* const plane = slab + u * UB + buf * 2 * PB;       // hi plane; lo plane at + PB
         if constexpr (KIND == KIND_TCN) {
           // dense conv as GEMM over K' = (c, j): the 8 taps of channel c are one k-octet   (tcn.py:76-80)
@@ -261,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #pragma unroll
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
-            const float v = fetch(t - sh);
+            const float v = fetch(t - sh) * sau;
             _Float16 h, l;
             split16(v, h, l);
             ph[t * 8] = h;
@@ -299,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
               const int t = fbase + m * d;
               _Float16 h, l;
-              split16(o, h, l);
+              split16(o * sau, h, l);
               ph[t * 8] = h;
               pl[t * 8] = l;
             }
@@ -312,7 +411,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
               for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], fetch(t - (KS - 1 - j) * d), o);
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
               _Float16 h, l;
-              split16(o, h, l);
+              split16(o * sau, h, l);
               ph[t * 8] = h;
               pl[t * 8] = l;
             }
@@ -364,19 +463,35 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
       const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + (wo * OW) * (NK2 * 128) + lane;
 #pragma unroll
       for (int ks = 0; ks < NK2; ++ks) load_a16<OW>(a2[ks], ap2 + ks * 128, NK2 * 128);
+      // the mid tile is rewritten behind a barrier: its exact maximum sets its scale
+      float mmax = 0.f;
+#pragma unroll
+      for (int ow = 0; ow < OW; ++ow) {
+        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o_base + ow * 16 + lq * 4);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[ow][tt][r] = fmaxf(fmaf(acc[ow][tt][r], c1, f4c(bias, r)), 0.f);
+            mmax = fmaxf(mmax, acc[ow][tt][r]);
+          }
+      }
+      amax_publish(cells_w + 3 + 2 * bi, mmax);
+      __syncthreads();
+      float c2;
+      const float sm = pow2_scale(amax_read(cells_w + 3 + 2 * bi), &c2);
+      c2 *= bd.inv_s2;
 #pragma unroll
       for (int ow = 0; ow < OW; ++ow) {
         const int o = o_base + ow * 16 + lq * 4;
-        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
           const int t = tt * 16 + l15;
           f16x4 vh, vl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = fmaxf(acc[ow][tt][r] + f4c(bias, r), 0.f);
             _Float16 h, l;
-            split16(v, h, l);
+            split16(acc[ow][tt][r] * sm, h, l);
             vh[r] = h; vl[r] = l;
           }
           char* dst = slab_u + (((o >> 3) * TT + t) * 8 + (o & 7)) * 2;   // 4 consecutive channels = 8 bytes
@@ -389,9 +504,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #pragma unroll
       for (int ks = 0; ks < NK2; ++ks)
         mfma16_step<OW, NT>(acc, a2[ks], slab_u + ks * 4 * TT * 16 + frag_off, slab_u + MPB + ks * 4 * TT * 16 + frag_off);
+      c1 = c2;                                               // the epilogue below undoes conv2's scales
     }
 
     // ---- epilogue: bias (+ReLU) + residual, in place into h
+    float hmax = 0.f;
 #pragma unroll
     for (int ow = 0; ow < ((WEKWS_ABLATE == 8 || WEKWS_ABLATE == 9) ? 0 : OW); ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
@@ -401,7 +518,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         const int t = tt * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[ow][tt][r] + f4c(bias, r);
+          float v = fmaf(acc[ow][tt][r], c1, f4c(bias, r));
           float* hp = h_w + (o + r) * SS + t;
           if constexpr (KIND == KIND_MDTC) {
             v = fmaxf(v + *hp, 0.f);
@@ -410,9 +527,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
             v = fmaxf(v, 0.f) + *hp;
           }
           *hp = v;
+          hmax = fmaxf(hmax, fabsf(v));
         }
       }
     }
+    amax_publish(cells_w + 4 + 2 * bi, hmax);              // = the input tile of block bi + 1
     __syncthreads();
   }
 

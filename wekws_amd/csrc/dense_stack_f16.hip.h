@@ -24,6 +24,7 @@ struct DenseBlock {
   uint32_t a1;   // packed fp16 hi/lo A fragments, K = ksize*C in (tap, channel) order
   uint32_t b1;   // f32 folded bias [C]
   uint32_t a2, b2;  // unused (kept for layout stability)
+  float inv_s1;     // 1 / power-of-two scale of the packed matrix (block floating point, conv_stack_f16.hip.h)
 };
 
 struct DenseParams {
@@ -36,6 +37,7 @@ struct DenseParams {
   uint32_t head_w, head_b;    // f32: LINEAR bias; GLOBAL/LAST: W1[hh][C], b1
   uint32_t head_w2, head_b2;  // GLOBAL/LAST: W2[odim][hh], b2
   int32_t cache_len;
+  float pre_inv_s, head_inv_s;  // 1 / power-of-two scales of pre_a16 and head_a16
 };
 
 template <int KIND, int C, int NT>
@@ -53,19 +55,20 @@ struct DenseGeom {
 };
 
 // f32 value of 4 consecutive channels of one frame from the hi/lo planes (8-byte loads)
-__device__ __forceinline__ void load_h4(const char* p, int lo_off, float (&v)[4]) {
+// (the planes hold h * s, s = the tile's power-of-two scale: `inv` = 1 / s on the way out, `s` on the way in)
+__device__ __forceinline__ void load_h4(const char* p, int lo_off, float inv, float (&v)[4]) {
   const f16x4 h = *reinterpret_cast<const f16x4*>(p);
   const f16x4 l = *reinterpret_cast<const f16x4*>(p + lo_off);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = static_cast<float>(h[r]) + static_cast<float>(l[r]);
+  for (int r = 0; r < 4; ++r) v[r] = (static_cast<float>(h[r]) + static_cast<float>(l[r])) * inv;
 }
 
-__device__ __forceinline__ void store_h4(char* p, int lo_off, const float (&v)[4]) {
+__device__ __forceinline__ void store_h4(char* p, int lo_off, float s, const float (&v)[4]) {
   f16x4 h, l;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     _Float16 a, b;
-    split16(v[r], a, b);
+    split16(v[r] * s, a, b);
     h[r] = a; l[r] = b;
   }
   *reinterpret_cast<f16x4*>(p) = h;
@@ -97,6 +100,26 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
   f32x4 acc[OW][NT];
   static_assert(KIND == KIND_TCN, "dense stack serves the plain TCN");
 
+  // ---- block floating point (conv_stack_f16.hip.h): per-utterance maxima of the features and the incoming cache.
+  //      The h planes (and the halo in front of them) of block i carry the scale of max(cell[2 + 2i], cache maximum).
+  __shared__ unsigned amax_cells[U * kAmaxCells];
+  unsigned* const cells_w = amax_cells + wu * kAmaxCells;
+  for (int e = tid; e < U * kAmaxCells; e += kThreads) amax_cells[e] = 0u;
+  __syncthreads();
+  for (int u = 0; u < U; ++u)
+    if (b0 + u < A.B) {
+      amax_publish(amax_cells + u * kAmaxCells, amax_span<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      if (A.in_cache)
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+    }
+  // scale of utterance u's h planes while they are the input of block bi (bi = nblocks: the backbone output)
+  auto h_scale = [&](int u, int bi, float* inv) __attribute__((always_inline)) -> float {       // u wave-uniform
+    return pow2_scale(fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1)), inv);
+  };
+  auto h_scale_v = [&](int u, int bi, float* inv) __attribute__((always_inline)) -> float {     // u per lane
+    return pow2_scale(fmaxf(amax_read_v(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read_v(amax_cells + u * kAmaxCells + 1)), inv);
+  };
+
   // ---- zero the left halo of every h plane once (no-cache left context; overwritten per block when caching)
   for (int e = tid; e < U * 2 * (C / 8) * HALO; e += kThreads) {
     const int f = e % HALO;
@@ -123,10 +146,12 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const int kf = ks * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+        float inv_unused;
+        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -140,18 +165,32 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
       load_a16<OW>(a, ap + ks * 128, ot_stride);
       mfma16_step<OW, NT>(acc, a, sc_w + (lq * TT + l15) * 16, sc_w + XP + (lq * TT + l15) * 16);
     }
+    float cpre;
+    (void)pow2_scale(amax_read(cells_w), &cpre);
+    cpre *= P.pre_inv_s;
+    float hmax = 0.f;
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow)
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[ow][tt][r], cpre, f4c(bias[ow], r));
+          if (P.pre_relu) v = fmaxf(v, 0.f);
+          acc[ow][tt][r] = v;
+          hmax = fmaxf(hmax, fabsf(v));
+        }
+    amax_publish(cells_w + 2, hmax);
+    __syncthreads();                                       // the tile's exact maximum is known before it is written
+    float inv_h;
+    const float sh = h_scale(wu, 0, &inv_h);
 #pragma unroll
     for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[ow][tt][r] + f4c(bias[ow], r);
-          if (P.pre_relu) v[r] = fmaxf(v[r], 0.f);
-        }
-        store_h4(hp_w + h_elem(o, tt * 16 + l15), HP, v);
+        const float v[4] = {acc[ow][tt][0], acc[ow][tt][1], acc[ow][tt][2], acc[ow][tt][3]};
+        store_h4(hp_w + h_elem(o, tt * 16 + l15), HP, sh, v);
       }
     }
     __syncthreads();
@@ -177,10 +216,10 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const int p = e % pad;
         const int uc = e / pad;
         const int u = uc / C, c = uc % C;
-        float v = 0.f;
+        float v = 0.f, inv_unused;
         if (b0 + u < A.B) v = A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p];
         _Float16 h, l;
-        split16(v, h, l);
+        split16(v * h_scale_v(u, bi, &inv_unused), h, l);
         char* dst = dense_lds + u * UB + ((c >> 3) * FR + HALO - pad + p) * 16 + (c & 7) * 2;
         *reinterpret_cast<_Float16*>(dst) = h;
         *reinterpret_cast<_Float16*>(dst + HP) = l;
@@ -195,8 +234,10 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const int u = uc / C, c = uc % C;
         if (b0 + u < A.B) {
           const char* src = dense_lds + u * UB + ((c >> 3) * FR + HALO + T - pad + p) * 16 + (c & 7) * 2;
-          const float v = static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
-                          static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP));
+          float inv_hu;
+          (void)h_scale_v(u, bi, &inv_hu);
+          const float v = (static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
+                           static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP))) * inv_hu;
           A.out_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p] = v;
         }
       }
@@ -222,22 +263,37 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
       }
     }
 
-    __syncthreads();  // every wave has finished reading the h planes before they are rewritten in place
-
-    // ---- epilogue: bias, residual (h = hi + lo), ReLU; rewrite the h planes in place
+    // ---- epilogue: bias, ReLU, residual (h = (hi + lo) / scale); the new tile's exact maximum is published before
+    //      the barrier behind which the h planes are rewritten in place with their new scale
+    float inv_h;
+    (void)h_scale(wu, bi, &inv_h);
+    const float c1 = inv_h * bd.inv_s1;
+    float hmax = 0.f;
 #pragma unroll
     for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        char* hp = hp_w + h_elem(o, tt * 16 + l15);
-        float hold[4], v[4];
-        load_h4(hp, HP, hold);
+        float hold[4];
+        load_h4(hp_w + h_elem(o, tt * 16 + l15), HP, inv_h, hold);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = fmaxf(acc[ow][tt][r] + f4c(ebias[ow], r), 0.f) + hold[r];   // y + x, nothing after the add (tcn.py:60)
+          const float v = fmaxf(fmaf(acc[ow][tt][r], c1, f4c(ebias[ow], r)), 0.f) + hold[r];   // y + x, nothing after the add (tcn.py:60)
+          acc[ow][tt][r] = v;
+          hmax = fmaxf(hmax, fabsf(v));
         }
-        store_h4(hp, HP, v);
+      }
+    }
+    amax_publish(cells_w + 4 + 2 * bi, hmax);
+    __syncthreads();  // every wave has finished reading the h planes before they are rewritten in place
+    const float sh_new = h_scale(wu, bi + 1, &inv_h);
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+      const int o = o_base + ow * 16 + lq * 4;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const float v[4] = {acc[ow][tt][0], acc[ow][tt][1], acc[ow][tt][2], acc[ow][tt][3]};
+        store_h4(hp_w + h_elem(o, tt * 16 + l15), HP, sh_new, v);
       }
     }
     __syncthreads();
@@ -263,6 +319,9 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         mfma16_step<1, NT>(hacc, a, hu + ks * 4 * FR * 16 + frag_h, hu + HP + ks * 4 * FR * 16 + frag_h);
       }
       if (b0 + u < A.B) {
+        float ch;
+        (void)h_scale(u, P.nblocks, &ch);
+        ch *= P.head_inv_s;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
           const int t = tt * 16 + l15;
@@ -270,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
           for (int r = 0; r < 4; ++r) {
             const int k = ot * 16 + lq * 4 + r;
             if (t < T && k < K) {
-              float v = hacc[0][tt][r] + W[P.head_b + k];
+              float v = fmaf(hacc[0][tt][r], ch, W[P.head_b + k]);
               if (P.sigmoid) v = sigmoidf_(v);
               A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * K + k] = v;
             }
@@ -285,8 +344,10 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
       const int u = ut / T, t = ut - u * T;
       if (b0 + u >= A.B) continue;
       const char* src = dense_lds + u * UB + ((c >> 3) * FR + HALO + t) * 16 + (c & 7) * 2;
-      float v = static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
-                static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP));
+      float inv_hu;
+      (void)h_scale_v(u, P.nblocks, &inv_hu);
+      float v = (static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
+                 static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP))) * inv_hu;
       if (P.sigmoid) v = sigmoidf_(v);
       A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * C + c] = v;
     }
@@ -298,9 +359,11 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
     for (int e = tid; e < U * C; e += kThreads) {
       const int u = e / C, c = e - u * C;
       const char* row = dense_lds + u * UB + ((c >> 3) * FR + HALO) * 16 + (c & 7) * 2;
+      float inv_hu;
+      (void)h_scale_v(u, P.nblocks, &inv_hu);
       auto at = [&](int t) -> float {
-        return static_cast<float>(*reinterpret_cast<const _Float16*>(row + t * 16)) +
-               static_cast<float>(*reinterpret_cast<const _Float16*>(row + HP + t * 16));
+        return (static_cast<float>(*reinterpret_cast<const _Float16*>(row + t * 16)) +
+                static_cast<float>(*reinterpret_cast<const _Float16*>(row + HP + t * 16))) * inv_hu;
       };
       float s;
       if (P.head == HEAD_GLOBAL) {

@@ -59,16 +59,29 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
 
   f32x4 acc[1][NT];
 
+  // ---- block floating point (conv_stack_f16.hip.h).  The activation planes (and the left-context planes in front of
+  //      them) of block i carry the power-of-two scale of max(cell[2 + 2i], cache maximum).
+  __shared__ unsigned amax_cells[kAmaxCells];
+  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __syncthreads();
+  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  if constexpr (HAS_CACHE)
+    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+  auto h_amax = [&](int bi) __attribute__((always_inline)) -> float {
+    return HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + 2 * bi);
+  };
+
   if constexpr (!HAS_CACHE) {                                // zero left context, once
     for (int e = tid; e < 2 * HALO_P / 16; e += kW16Threads) *reinterpret_cast<uint4*>(halo + e * 16) = uint4{0, 0, 0, 0};
   }
   // left context of interval iv of a block: cache slice -> fp16 hi/lo planes (x_pad index j = frame j - pad)
-  auto stage_halo = [&](const BlockDesc& nb, int iv) __attribute__((always_inline)) {
+  auto stage_halo = [&](const BlockDesc& nb, int iv, float sh) __attribute__((always_inline)) {
+    (void)sh;
     if constexpr (HAS_CACHE) {
       const int pad = nb.pad;
       for (int e = tid; e < 64 * pad; e += kW16Threads) {
         const int cl = e / pad, j = e - cl * pad;
-        const float v = A.in_cache[(int64_t(b) * C + iv * 64 + cl) * Pc + nb.cache_off + j];
+        const float v = A.in_cache[(int64_t(b) * C + iv * 64 + cl) * Pc + nb.cache_off + j] * sh;
         _Float16 h, l;
         split16(v, h, l);
         char* d = halo + ((cl >> 3) * PADMAX + j) * 16 + (cl & 7) * 2;
@@ -84,9 +97,11 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
     const int nk = P.kpre16 / 32;
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    float sx = 1.f, cpre = 1.f;
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the slab)
       const int steps = min(2, nk - k0);
       __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
       for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, frame)
         const int t = e % TT;
         const int q = e / TT;
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -114,16 +129,29 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
       }
     }
     const f32x4 b4 = {bias.x, bias.y, bias.z, bias.w};
+    cpre *= P.pre_inv_s;
+    float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-      f32x4 v = acc[0][tt] + b4;
+      f32x4 v = acc[0][tt] * cpre + b4;
       if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+      acc[0][tt] = v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hmax = fmaxf(hmax, fabsf(v[r]));
+    }
+    amax_publish(amax_cells + 2, hmax);
+    __syncthreads();                                         // the tile's exact maximum is known before it is written
+    float inv_unused;
+    const float sh0 = pow2_scale(h_amax(0), &inv_unused);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const f32x4 v = acc[0][tt] * sh0;
       const f16x4 vh = __builtin_convertvector(v, f16x4);
       const f16x4 vl = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
       *reinterpret_cast<f16x4*>(hpl + hwr + tt * 256) = vh;
       *reinterpret_cast<f16x4*>(hpl + HP + hwr + tt * 256) = vl;
     }
-    if (P.nblocks > 0) stage_halo(P.blocks[0], 0);
+    if (P.nblocks > 0) stage_halo(P.blocks[0], 0, sh0);
     __syncthreads();
   }
 
@@ -142,6 +170,12 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
     // byte distance of this lane's tap of pair p from the tile's own frame: s(tap) * d * 16 with tap = 2p + (lq >> 1),
     // s(j) = KS - 1 - j:  sd0 - p * 32 d
     const int sd0 = (KS - 1 - (lq >> 1)) * d * 16;
+    // scales of this block: activation planes (exact maximum), depthwise output (bound), and what undoes them
+    float inv_sh, c1;
+    const float s_h = pow2_scale(h_amax(bi), &inv_sh);         // (named apart from the lane shift `sh` below)
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, h_amax(bi), bd.dw_beta), &c1);
+    c1 *= bd.inv_s1;
+    const float cdw = inv_sh * bd.dw_tap_inv * sa;             // depthwise accumulator -> operand units of the slab
 
     // taps of this lane's row channel (ct*16 + l15) and folded biases of its 4 D rows, one interval ahead
     f32x4 nq0, nq1, nbias;
@@ -159,8 +193,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
     for (int iv = 0; iv < NIV; ++iv) {
       // The taps of this lane's row channel and the folded biases of its 4 D rows were requested during the previous
       // pointwise phase; this lane multiplies the even taps (lq >> 1 == 0) or the odd ones.
-      const f32x4 tw = (lq >> 1) ? f32x4{nq0[1], nq0[3], nq1[1], nq1[3]} : f32x4{nq0[0], nq0[2], nq1[0], nq1[2]};
-      const f32x4 dwb = nbias;
+      const f32x4 tw = ((lq >> 1) ? f32x4{nq0[1], nq0[3], nq1[1], nq1[3]} : f32x4{nq0[0], nq0[2], nq1[0], nq1[2]}) * bd.dw_tap_s;
+      const f32x4 dwb = nbias * sa;
       // ---- the new streaming cache = last `pad` columns of [left context | h].  item = (channel octet, column): one
       //      16-byte hi + lo item -> 8 channels, 8 coalesced 4-byte stores.  Usual case (T >= pad: no column comes
       //      from the old context): all 32 octets at once in the block's first interval; otherwise interval by
@@ -176,7 +210,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
           const f16x8 vl = *reinterpret_cast<const f16x8*>(ph + (src >= 0 ? HP : HALO_P));
           const uint32_t o = uint32_t((oct0 + oc) * 8 * Pc + j);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ob[o + uint32_t(i * Pc)] = float(vh[i]) + float(vl[i]);
+          for (int i = 0; i < 8; ++i) ob[o + uint32_t(i * Pc)] = (float(vh[i]) + float(vl[i])) * inv_sh;
         }
       }
       // ---- depthwise on the matrix cores: tiles (ct, ft), ft = fq + 4 rd.  Tap pair by tap pair: the diagonal A
@@ -238,7 +272,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
         const int ft = fq + 4 * rd;
         if (ft < NT) {
           const int tn = ft * 16 + l15;
-          const f32x4 v = __builtin_elementwise_max(dacc[rd] + dwb, f32x4{0.f, 0.f, 0.f, 0.f});
+          const f32x4 v = __builtin_elementwise_max(dacc[rd] * cdw + dwb, f32x4{0.f, 0.f, 0.f, 0.f});   // = sa * ReLU(dw + b)
           const f16x4 vh = __builtin_convertvector(v, f16x4);
           const f16x4 vl = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
           char* dst = slab + (ct >> 1) * 2 * PB + (((ct & 1) * 2 + (lq >> 1)) * TT + tn) * 16 + (lq & 1) * 8;
@@ -253,29 +287,46 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
       mfma16_step_nb<NT>(acc[0], a0[0], slab + frag_off, slab + PB + frag_off);
       load_a16<1>(a0, ap1 + (2 * nx) * 128, 0);                // first K step of the next interval: a whole phase ahead
       mfma16_step_nb<NT>(acc[0], a1[0], slab + 2 * PB + frag_off, slab + 3 * PB + frag_off);
-      if (iv + 1 < NIV) { load_taps(bd, iv + 1); stage_halo(bd, iv + 1); }
-      else if (bi + 1 < P.nblocks) { load_taps(bdn, 0); stage_halo(bdn, 0); }
+      if (iv + 1 < NIV) { load_taps(bd, iv + 1); stage_halo(bd, iv + 1, s_h); }
+      else if (bi + 1 < P.nblocks) { load_taps(bdn, 0); }     // (its left context waits for the new planes' scale)
       __syncthreads();
     }
 
     // ---- epilogue: folded bias + ReLU + residual (tcn.py:60: add after the ReLU), in place in the planes
     const f32x4 eb = *reinterpret_cast<const f32x4*>(W + bd.b1 + o0);
+    float hmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const char* hp = hpl + hwr + tt * 256;
+      const f32x4 hold = (__builtin_convertvector(*reinterpret_cast<const f16x4*>(hp), f32x4) +
+                          __builtin_convertvector(*reinterpret_cast<const f16x4*>(hp + HP), f32x4)) * inv_sh;
+      const f32x4 v = __builtin_elementwise_max(acc[0][tt] * c1 + eb, f32x4{0.f, 0.f, 0.f, 0.f}) + hold;
+      acc[0][tt] = v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hmax = fmaxf(hmax, fabsf(v[r]));
+    }
+    amax_publish(amax_cells + 4 + 2 * bi, hmax);
+    __syncthreads();                                         // the new tile's exact maximum sets the planes' new scale
+    float inv_unused;
+    const float sh_new = pow2_scale(h_amax(bi + 1), &inv_unused);
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       char* hp = hpl + hwr + tt * 256;
-      const f32x4 hold = __builtin_convertvector(*reinterpret_cast<const f16x4*>(hp), f32x4) +
-                         __builtin_convertvector(*reinterpret_cast<const f16x4*>(hp + HP), f32x4);
-      const f32x4 v = __builtin_elementwise_max(acc[0][tt] + eb, f32x4{0.f, 0.f, 0.f, 0.f}) + hold;
+      const f32x4 v = acc[0][tt] * sh_new;
       const f16x4 vh = __builtin_convertvector(v, f16x4);
       const f16x4 vl = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
       *reinterpret_cast<f16x4*>(hp) = vh;
       *reinterpret_cast<f16x4*>(hp + HP) = vl;
     }
+    if (bi + 1 < P.nblocks) stage_halo(bdn, 0, sh_new);
     __syncthreads();
   }
 
   // ============ head: y[t] = [sigmoid](Wc h[t] + bc) on the matrix cores, straight from the planes ============
   const int K = P.odim;
+  float chead;
+  (void)pow2_scale(h_amax(P.nblocks), &chead);
+  chead *= P.head_inv_s;                                     // 1 / (planes' scale * classifier scale)
   if (K <= 16) {
     // keyword heads (1..16 outputs): one padded o-tile; wave = frame tile
     if (wave < NT) {
@@ -298,7 +349,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
         for (int r = 0; r < 4; ++r) {
           const int k = lq * 4 + r;
           if (k < K) {
-            float v = hacc[r] + W[P.head_b + k];
+            float v = fmaf(hacc[r], chead, W[P.head_b + k]);
             if (P.sigmoid) v = sigmoidf_(v);
             A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
           }
@@ -371,7 +422,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
           const int t = tt * 16 + l15;
-          f32x4 v = hacc[ow][tt] + hb[ow];
+          f32x4 v = hacc[ow][tt] * chead + hb[ow];
           if (P.sigmoid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);

@@ -54,15 +54,24 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 
   f32x4 acc[1][NT];
 
+  // ---- block floating point (conv_stack_f16.hip.h): maximum of the chunk's features now, of the carried cache when
+  //      its registers are committed to LDS below
+  __shared__ unsigned amax_cells[kAmaxCells];
+  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __syncthreads();
+  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
     const int nk = P.kpre16 / 32;
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    float sx = 1.f, cpre = 1.f;
     for (int k0 = 0; k0 < nk; k0 += 2) {
       const int steps = min(2, nk - k0);
       __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
       for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {
         const int t = e % TT;
         const int q = e / TT;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -89,18 +98,27 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
         mfma16_step_nb<NT, SPLIT>(acc[0], a[0], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
       }
     }
+    cpre *= P.pre_inv_s;
+    float hmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = acc[0][0][r] + f4c(bias, r);
+      float v = fmaf(acc[0][0][r], cpre, f4c(bias, r));
       if (P.pre_relu) v = fmaxf(v, 0.f);
       hbuf[(o0 + r) * SS + l15] = v;
+      hmax = fmaxf(hmax, fabsf(v));
     }
+    amax_publish(amax_cells + 2, hmax);
+    float cm = 0.f;
 #pragma unroll
     for (int k = 0; k < kCV; ++k) {
       const int e = tid + k * kW16Threads;
-      if (e < n4) reinterpret_cast<f32x4*>(cch)[e] = has_cache ? cv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 q = has_cache ? cv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < n4) reinterpret_cast<f32x4*>(cch)[e] = q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cm = fmaxf(cm, fabsf(q[r]));   // (clamped duplicates past n4 repeat the last item)
     }
-    __syncthreads();                                         // activations and cache image complete
+    amax_publish(amax_cells + 1, cm);
+    __syncthreads();                                         // activations, cache image and both maxima complete
   }
 
   // ======================================= residual blocks =======================================
@@ -121,6 +139,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     F16Frag af[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) ldfrag(af[s4], ap1 + s4 * 128);   // K steps 0..3, in flight over the producer
+    // operand scale of this block (same rule and same numbers as the batch kernel: bit-identical results)
+    float c1;
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1)), bd.dw_beta), &c1);
+    c1 *= bd.inv_s1;
 
     // ---- producer: lane-group pg makes channels pg, pg + 64, pg + 128, pg + 192; lane tl = frame tau of the chunk
 #pragma unroll
@@ -149,7 +171,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (tl + 16 * k < pad) crow[tl + 16 * k] = nv[k];
-      o = fmaxf(o, 0.f);
+      o = fmaxf(o, 0.f) * sa;
       _Float16 h, l;
       split16(o, h, l);
       char* const plane = slab + (c >> 5) * 2 * PB;          // K step c / 32
@@ -170,11 +192,15 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
       mfma16_step_nb<NT, SPLIT>(acc[0], af[s4], slab + (4 + s4) * 2 * PB + frag_off,
                                 slab + (4 + s4) * 2 * PB + PB + frag_off);
     // epilogue: folded bias + ReLU + residual, in place (tcn.py:60).  Every producer read of hbuf is behind the barrier.
+    float hmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float* hp = hbuf + (o0 + r) * SS + l15;
-      *hp = fmaxf(acc[0][0][r] + f4c(ebias, r), 0.f) + *hp;
+      const float v = fmaxf(fmaf(acc[0][0][r], c1, f4c(ebias, r)), 0.f) + *hp;
+      *hp = v;
+      hmax = fmaxf(hmax, fabsf(v));
     }
+    amax_publish(amax_cells + 4 + 2 * bi, hmax);
     __syncthreads();
   }
 

@@ -74,15 +74,25 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
 
   f32x4 acc[1][NT];
 
+  // ---- block floating point (conv_stack_f16.hip.h): maxima of the feature tile and of the incoming cache
+  __shared__ unsigned amax_cells[kAmaxCells];
+  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __syncthreads();
+  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  if constexpr (HAS_CACHE)
+    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
     const int nk = P.kpre16 / 32;
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    float sx = 1.f, cpre = 1.f;
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the slab)
       const int steps = min(2, nk - k0);
       __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
       for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, frame)
         const int t = e % TT;
         const int q = e / TT;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -109,16 +119,20 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
         mfma16_step_nb<NT, SPLIT>(acc[0], a[0], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
       }
     }
+    cpre *= P.pre_inv_s;                                     // 1 / (feature scale * weight scale)
+    float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int t = tt * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[0][tt][r] + f4c(bias, r);
+        float v = fmaf(acc[0][tt][r], cpre, f4c(bias, r));
         if (P.pre_relu) v = fmaxf(v, 0.f);
         hbuf[(o0 + r) * SS + t] = v;
+        hmax = fmaxf(hmax, fabsf(v));
       }
     }
+    amax_publish(amax_cells + 2, hmax);
     __syncthreads();
   }
 
@@ -148,6 +162,14 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
 
     const bool slide = d <= 16 && (16 % d) == 0;
     const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+
+    // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
+    //      by the epilogue that wrote it) and of the incoming cache
+    float c1;
+    const float au = HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1))
+                               : amax_read(amax_cells + 2 + 2 * bi);
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &c1);
+    c1 *= bd.inv_s1;
 
     // ---- producer: lane-group pg makes slab row pg of interval iv: depthwise dilated conv + folded BN + ReLU of
     //      channel iv*64 + pg (tcn.py:102-109), split to fp16 hi/lo, and hands the channel's streaming cache over.
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           float o = dww[KS];
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
-          o = fmaxf(o, 0.f);
+          o = fmaxf(o, 0.f) * sa;
           const int t = fbase + m * d;
           _Float16 h, l;
           split16(o, h, l);
@@ -211,7 +233,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           float o = dww[KS];
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
-          o = fmaxf(o, 0.f);
+          o = fmaxf(o, 0.f) * sa;
           _Float16 h, l;
           split16(o, h, l);
           ph[t * 8] = h;
@@ -235,15 +257,19 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     }
 
     // ---- epilogue: folded bias + ReLU + residual, in place (tcn.py:60: add after the ReLU)
+    float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       const int t = tt * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float* hp = hbuf + (o0 + r) * SS + t;
-        *hp = fmaxf(acc[0][tt][r] + f4c(ebias, r), 0.f) + *hp;
+        const float v = fmaxf(fmaf(acc[0][tt][r], c1, f4c(ebias, r)), 0.f) + *hp;
+        *hp = v;
+        hmax = fmaxf(hmax, fabsf(v));
       }
     }
+    amax_publish(amax_cells + 4 + 2 * bi, hmax);             // = the input tile of block bi + 1
     __syncthreads();
   }
 

@@ -57,14 +57,33 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) zsum[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- block floating point (conv_stack_f16.hip.h): per-utterance maxima of the features and of the incoming cache
+  __shared__ unsigned amax_cells[U * kAmaxCells];
+  unsigned* const cells_w = amax_cells + wu * kAmaxCells;
+  if (tid < U * kAmaxCells) amax_cells[tid] = 0u;
+  __syncthreads();
+  for (int u = 0; u < U; ++u)
+    if (b0 + u < A.B) {
+      amax_publish(amax_cells + u * kAmaxCells, amax_span<kW16Threads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      if (!LCACHE && HAS_CACHE)
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+    }
+
   if constexpr (LCACHE) {                                    // the two streams' caches are contiguous in global memory
     static_assert(NT == 1, "the LDS-resident cache is for single-tile streaming steps");
     const int nu = min(U, A.B - b0);
     const int n4 = (C * Pc) >> 2, tot = U * n4;              // C * Pc % 4 == 0 (host checks)
     const f32x4* src = reinterpret_cast<const f32x4*>(A.in_cache + int64_t(b0) * C * Pc);
-    for (int e = tid; e < tot; e += kW16Threads)
-      reinterpret_cast<f32x4*>(cch)[e] =                   // streamed once: non-temporal, the weights stay in L2
+    float cm[U] = {0.f, 0.f};
+    for (int e = tid; e < tot; e += kW16Threads) {
+      const f32x4 q =                                      // streamed once: non-temporal, the weights stay in L2
           (A.in_cache && e < nu * n4) ? __builtin_nontemporal_load(src + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(cch)[e] = q;
+      const float qm = fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3])));
+      if (e < n4) cm[0] = fmaxf(cm[0], qm); else cm[1] = fmaxf(cm[1], qm);
+    }
+    amax_publish(amax_cells + 1, cm[0]);
+    amax_publish(amax_cells + kAmaxCells + 1, cm[1]);
     // visible to the producers: the preprocessing below ends with a barrier
   }
 
@@ -99,7 +118,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the planes of an utterance)
       const int steps = min(2, nk - k0);
-      if (k0) __syncthreads();
+      __syncthreads();                                       // (first pass: the feature maxima are published)
       for (int e = tid; e < U * steps * 4 * TT; e += kW16Threads) {   // item = (utt, step, k-octet, frame)
         const int t = e % TT;
         int q = e / TT;
@@ -108,10 +127,12 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         const int kf = (k0 + st) * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+        float inv_unused;
+        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (ok && kf + i < P.idim) ? xr[i] : 0.f;
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
           _Float16 h, l;
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
@@ -139,17 +160,23 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           }
       }
     }
+    float cpre;
+    (void)pow2_scale(amax_read(cells_w), &cpre);
+    cpre *= P.pre_inv_s;                                     // 1 / (feature scale * weight scale)
+    float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
       if (tt < ntw) {
         const int t = (ft0 + tt) * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[tt][r] + f4c(bias, r);
+          float v = fmaf(acc[tt][r], cpre, f4c(bias, r));
           if (P.pre_relu) v = fmaxf(v, 0.f);
           h_w[(o0 + r) * SS + t] = v;
+          hmax = fmaxf(hmax, fabsf(v));
         }
       }
+    amax_publish(cells_w + 2, hmax);
     __syncthreads();
   }
 
@@ -168,6 +195,15 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     }
     const bool slide = d <= 16 && (16 % d) == 0;
     const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+    // operand scales of the depthwise rows, per utterance (bound through the maxima of the input tile and the cache)
+    float sa[U], c1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      float inv;
+      sa[u] = pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &inv);
+      c1 = (u == wu) ? inv * bd.inv_s1 : c1;
+    }
 
     // ---- producer: lane-group pg makes channel pg of both utterances: depthwise dilated conv + folded BN
     //      (mdtc.py:55-58, no ReLU), split to fp16 hi/lo planes, and hands the channel's streaming cache over
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
           const int t = fbase + m * d;
           _Float16 h, l;
-          split16(o, h, l);
+          split16(o * sa[u], h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -236,7 +272,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
           _Float16 h, l;
-          split16(o, h, l);
+          split16(o * sa[u], h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -258,13 +294,25 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     gemm(ap1);
     const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
     const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
+    // mid = ReLU(BN1(pointwise)) (mdtc.py:113-114): its exact maximum, known before the barrier, sets its scale
+    float mmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) {
+        acc[tt] = __builtin_elementwise_max(acc[tt] * c1 + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f});
+        mmax = fmaxf(fmaxf(mmax, fmaxf(acc[tt][0], acc[tt][1])), fmaxf(acc[tt][2], acc[tt][3]));
+      }
+    amax_publish(cells_w + 3 + 2 * bi, mmax);
     __syncthreads();                                         // every wave is done reading the depthwise planes
-    // ---- mid = ReLU(BN1(pointwise)) written in operand order over them (mdtc.py:113-114)
+    float c2;
+    const float sm = pow2_scale(amax_read(cells_w + 3 + 2 * bi), &c2);
+    c2 *= bd.inv_s2;
+    // ---- written in operand order over them
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
       if (tt < ntw) {
         const int t = (ft0 + tt) * 16 + l15;
-        const f32x4 v = __builtin_elementwise_max(acc[tt] + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f});
+        const f32x4 v = acc[tt] * sm;
         const f16x4 vh = __builtin_convertvector(v, f16x4);
         char* dst = slab_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
         *reinterpret_cast<f16x4*>(dst) = vh;
@@ -274,6 +322,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     __syncthreads();
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), in place into h
     gemm(ap2);
+    float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
       if (tt < ntw) {
@@ -281,11 +330,13 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* hp = h_w + (o0 + r) * SS + t;
-          const float v = fmaxf(acc[tt][r] + f4c(bias2, r) + *hp, 0.f);
+          const float v = fmaxf(fmaf(acc[tt][r], c2, f4c(bias2, r)) + *hp, 0.f);
           if (bd.zadd) zsum[tt][r] += v;
           *hp = v;
+          hmax = fmaxf(hmax, v);
         }
       }
+    amax_publish(cells_w + 4 + 2 * bi, hmax);                // = the input tile of block bi + 1
     __syncthreads();
   }
 

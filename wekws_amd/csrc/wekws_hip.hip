@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,22 @@ int fail(int code, const char* fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.  Zero / non-finite bound: s = 1.
+// (host twin of pow2_scale in conv_stack_f16.hip.h)
+inline float pow2_scale_host(float bound, float* inv) {
+  uint32_t bits;
+  std::memcpy(&bits, &bound, 4);
+  const uint32_t e = (bits >> 23) & 0xffu;
+  uint32_t se = 268u - e;
+  se = se > 253u ? 253u : se;
+  if (e == 0u || e == 255u) se = 127u;
+  const uint32_t sb = se << 23, ib = (254u - se) << 23;
+  float s;
+  std::memcpy(&s, &sb, 4);
+  std::memcpy(inv, &ib, 4);
+  return s;
+}
+
 // Host-side builder of the device weight image; every section starts 16-byte aligned.
 struct Image {
   std::vector<float> data;
@@ -84,17 +101,28 @@ struct Image {
   }
   // A operand of v_mfma_f32_16x16x32_f16, operands split into fp16 hi + lo (conv_stack_f16.hip.h):
   // [o-tile][k32][hi|lo][lane][8 halves], lane l holds W[otile*16 + (l&15)][k32*32 + 8*(l>>4) + e], e = 0..7.
-  uint32_t put_packed_a16(const float* Wsrc, int O, int Ksrc, int ld) {
+  // Block floating point: the matrix is stored as W * s, s the power of two that puts max|W| into [2^14, 2^15) -- the top
+  // of the fp16 range, where hi + lo carries 22 bits for 16 binades below the maximum; *inv_scale = 1 / s (exact) is what
+  // the kernel's epilogue multiplies the accumulator with.
+  uint32_t put_packed_a16(const float* Wsrc, int O, int Ksrc, int ld, float* inv_scale) {
     const int Op = round_up(O, 16), Kp = round_up(Ksrc, 32);
     const size_t halves = size_t(Op) * Kp * 2;
     uint32_t off = reserve(halves / 2);
     _Float16* dst = reinterpret_cast<_Float16*>(data.data() + off);
+    float wmax = 0.f;
+    for (int o = 0; o < O; ++o)
+      for (int k = 0; k < Ksrc; ++k) {
+        const float a = std::fabs(Wsrc[size_t(o) * ld + k]);
+        if (std::isfinite(a) && a > wmax) wmax = a;
+      }
+    float inv_local = 1.f;
+    const float sw = inv_scale ? pow2_scale_host(wmax, inv_scale) : (void(inv_local), 1.f);   // nullptr: stored unscaled
     for (int ot = 0; ot < Op / 16; ++ot)
       for (int ks = 0; ks < Kp / 32; ++ks)
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 8; ++e) {
             const int o = ot * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + e;
-            const float v = (o < O && k < Ksrc) ? Wsrc[size_t(o) * ld + k] : 0.f;
+            const float v = (o < O && k < Ksrc) ? Wsrc[size_t(o) * ld + k] * sw : 0.f;
             const _Float16 h = static_cast<_Float16>(v);
             const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
             const size_t base = ((size_t(ot) * (Kp / 32) + ks) * 2) * 512;  // halves per (o-tile, k32, plane) = 64*8
@@ -278,7 +306,7 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   auto dense = [&](int O, int Ksrc, int Op, bool has_bias, uint32_t* a_off, uint32_t* b_off) {
     std::vector<float> wp(size_t(Op) * Ksrc, 0.f);
     std::memcpy(wp.data(), p, size_t(O) * Ksrc * sizeof(float));
-    *a_off = img.put_packed_a16(wp.data(), Op, Ksrc, Ksrc);
+    *a_off = img.put_packed_a16(wp.data(), Op, Ksrc, Ksrc, nullptr);
     p += size_t(O) * Ksrc;
     if (has_bias) {
       std::vector<float> bp(Op, 0.f);
@@ -404,6 +432,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
     if (ks != ks_built)
       return fail(WEKWS_HIP_EUNSUPPORTED, "kernel_size %d: this backbone's kernel is built for %d", ks, ks_built);
+    if (d.precision != WEKWS_HIP_PRECISION_F32 && n_blocks(d) > wekws::kAmaxMaxBlocks)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks: the split-fp16 kernels track %d (precision F32 has no limit)",
+                  n_blocks(d), wekws::kAmaxMaxBlocks);
   } else {
     if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128", C);
     if (d.num_layers > wekws::kGruMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "gru num_layers %d > %d", d.num_layers, wekws::kGruMaxLayers);
@@ -432,7 +463,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
 
   // ---- preprocessing
   const uint32_t pre_a = img.put_packed_a(p, C, d.idim, d.idim);
-  const uint32_t pre_a16 = desc_conv(d) ? img.put_packed_a16(p, C, d.idim, d.idim) : 0;
+  float pre_inv_s = 1.f;
+  const uint32_t pre_a16 = desc_conv(d) ? img.put_packed_a16(p, C, d.idim, d.idim, &pre_inv_s) : 0;
   p += size_t(C) * d.idim;
   const uint32_t pre_b = img.put(p, C);
   p += C;
@@ -447,10 +479,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     sp.pre_b = pre_b;
     sp.kpre16 = round_up(d.idim, 32);
     sp.pre_a16 = pre_a16;
+    sp.pre_inv_s = pre_inv_s;
+    sp.head_inv_s = 1.f;
     const int nb = n_blocks(d);
     int off = 0;
     for (int i = 0; i < nb; ++i) {
       wekws::BlockDesc b{};
+      b.inv_s1 = b.inv_s2 = b.dw_tap_s = b.dw_tap_inv = 1.f;
       if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
         b.dil = (i == 0) ? 1 : (1 << ((i - 1) % d.stack_size));          // mdtc.py:151-156, :229-237
         b.zadd = (i > 0 && (i - 1) % d.stack_size == d.stack_size - 1);  // mdtc.py:270-273
@@ -461,16 +496,16 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       b.cache_off = off;
       off += b.pad;
       wekws::DenseBlock db{};
-      db.dil = b.dil; db.pad = b.pad; db.cache_off = b.cache_off; db.zadd = b.zadd;
+      db.dil = b.dil; db.pad = b.pad; db.cache_off = b.cache_off; db.zadd = b.zadd; db.inv_s1 = 1.f;
       if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
         b.a1 = img.put_packed_a(p, C, C * ks, C * ks);
-        b.a1_16 = img.put_packed_a16(p, C, C * ks, C * ks);
+        b.a1_16 = img.put_packed_a16(p, C, C * ks, C * ks, &b.inv_s1);
         {  // dense-stack kernel: K reordered to (tap, channel)
           std::vector<float> mw(size_t(C) * C * ks);
           for (int o = 0; o < C; ++o)
             for (int c = 0; c < C; ++c)
               for (int j = 0; j < ks; ++j) mw[(size_t(o) * ks + j) * C + c] = p[(size_t(o) * C + c) * ks + j];
-          db.a1 = img.put_packed_a16(mw.data(), C, C * ks, C * ks);
+          db.a1 = img.put_packed_a16(mw.data(), C, C * ks, C * ks, &db.inv_s1);
         }
         p += size_t(C) * C * ks;
         b.b1 = img.put(p, C);
@@ -487,17 +522,34 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
             pk[size_t(c) * dwp + ks] = p[size_t(C) * ks + c];
           }
           b.dw_pk = img.put(pk.data(), pk.size());
+          // block floating point: the depthwise output obeys |dw(u) + b| <= dw_alpha * max|u| + dw_beta; the taps enter the
+          // matrix cores (ds256_mm) scaled to the top of the fp16 range
+          float l1 = 0.f, bmax = 0.f, tmax = 0.f;
+          for (int c = 0; c < C; ++c) {
+            float sum = 0.f;
+            for (int j = 0; j < ks; ++j) {
+              const float a = std::fabs(p[size_t(c) * ks + j]);
+              sum += a;
+              if (std::isfinite(a) && a > tmax) tmax = a;
+            }
+            l1 = sum > l1 ? sum : l1;
+            const float ab = std::fabs(p[size_t(C) * ks + c]);
+            bmax = ab > bmax ? ab : bmax;
+          }
+          b.dw_alpha = l1 * 1.0000005f;                       // (rounding of the tap sum and of the device's FMA chain)
+          b.dw_beta = bmax;
+          b.dw_tap_s = pow2_scale_host(tmax, &b.dw_tap_inv);
         }
         p += size_t(C) * ks;
         p += C;
         b.a1 = img.put_packed_a(p, C, C, C);
-        b.a1_16 = img.put_packed_a16(p, C, C, C);
+        b.a1_16 = img.put_packed_a16(p, C, C, C, &b.inv_s1);
         p += size_t(C) * C;
         b.b1 = img.put(p, C);
         p += C;
         if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
           b.a2 = img.put_packed_a(p, C, C, C);
-          b.a2_16 = img.put_packed_a16(p, C, C, C);
+          b.a2_16 = img.put_packed_a16(p, C, C, C, &b.inv_s2);
           p += size_t(C) * C;
           b.b2 = img.put(p, C);
           p += C;
@@ -513,14 +565,15 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     sp.head_hidden = d.head_hidden;
     sp.sigmoid = d.activation == WEKWS_HIP_ACT_SIGMOID;
     wekws::DenseParams& dp = m->dp;
+    dp.head_inv_s = 1.f;
     if (d.head == WEKWS_HIP_HEAD_LINEAR) {
       if (K > 16) {  // wide (CTC) heads: rows padded to a multiple of 32 so that o-tiles come in pairs (ds256_mm.hip.h)
         const int Kp = round_up(K, 32);
         std::vector<float> wp(size_t(Kp) * C, 0.f);
         std::memcpy(wp.data(), p, size_t(K) * C * sizeof(float));
-        dp.head_a16 = img.put_packed_a16(wp.data(), Kp, C, C);
+        dp.head_a16 = img.put_packed_a16(wp.data(), Kp, C, C, &dp.head_inv_s);
       } else {
-        dp.head_a16 = img.put_packed_a16(p, K, C, C);
+        dp.head_a16 = img.put_packed_a16(p, K, C, C, &dp.head_inv_s);
       }
       sp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
       sp.head_b = img.put(p, K); p += K;
@@ -535,6 +588,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     dp.nblocks = nb; dp.idim = d.idim; dp.kpre16 = sp.kpre16; dp.ksize = ks; dp.odim = K; dp.pre_relu = d.preproc_relu;
     dp.pre_a16 = sp.pre_a16; dp.pre_b = sp.pre_b; dp.head = d.head; dp.head_hidden = d.head_hidden; dp.sigmoid = sp.sigmoid;
     dp.head_w = sp.head_w; dp.head_b = sp.head_b; dp.head_w2 = sp.head_w2; dp.head_b2 = sp.head_b2; dp.cache_len = off;
+    dp.pre_inv_s = pre_inv_s;
+    sp.head_inv_s = dp.head_inv_s;
     int max_pad = 0;
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
@@ -569,16 +624,16 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       const float* bhh = p; p += 3 * C;
       gp.layer[l].a_ih = img.put_packed_a(wih, 3 * C, C, C);
       gp.layer[l].a_hh = img.put_packed_a(whh, 3 * C, C, C);
-      m->gq.a_ih16[l] = img.put_packed_a16(wih, 3 * C, C, C);
-      m->gq.a_hh16[l] = img.put_packed_a16(whh, 3 * C, C, C);
+      m->gq.a_ih16[l] = img.put_packed_a16(wih, 3 * C, C, C, nullptr);
+      m->gq.a_hh16[l] = img.put_packed_a16(whh, 3 * C, C, C, nullptr);
       gp.layer[l].b_ih = img.put(bih, 3 * C);
       gp.layer[l].b_hh = img.put(bhh, 3 * C);
     }
-    m->gq.head_a16 = img.put_packed_a16(p, K, C, C);
+    m->gq.head_a16 = img.put_packed_a16(p, K, C, C, nullptr);
     gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
     gp.head_b = img.put(p, K); p += K;
     m->gq.kpre16 = round_up(d.idim, 32);
-    m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim);
+    m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim, nullptr);
     m->cache_len = 0;
   }
   if (size_t(p - blob) != n_elems) {

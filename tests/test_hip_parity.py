@@ -66,8 +66,6 @@ def models():
 def test_golden(case, precision, golden, models):
     """HIP vs the live-reference golden vectors (58 cases: every backbone/head, ragged T, caches, streaming), in
     both matrix precisions (wekws_hip_precision): exact-f32 MFMA and the fp16 hi/lo split."""
-    if precision == "f32" and case["model"].startswith("fsmn"):
-        pytest.skip("FSMN is built for the split-fp16 mode only (test_fsmn_f32_is_refused)")
     cfg, sd, model = models(case, precision)
     x = case_input(case)
     y, cache = run(model, x, case_in_cache(case, cfg), softmax=case.get("softmax", False), chunks=case.get("chunks"))
@@ -87,8 +85,6 @@ def test_scale_sweep(case, precision, scale_golden, error_report):
     reference's outputs are bit-identical to the unscaled model's); the split-fp16 kernels must be too: block floating
     point (conv_stack_f16.hip.h) -- no inf / NaN when activations pass 65504, no loss when operands sink below fp16's
     normal range.  Same 1e-4 bar as every other parity test; the measured error goes to gpurun_out/parity_errors.json."""
-    if precision == "f32" and case["model"].startswith("fsmn"):
-        pytest.skip("FSMN is built for the split-fp16 mode only")
     cfg, sd = case_weights(case)
     sd2, xs = scaled_case_weights(case, sd)
     model = build(cfg, sd2).set_precision(precision)
@@ -431,12 +427,17 @@ def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
         assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
 
 
-def test_fsmn_f32_is_refused():
-    """The exact-f32 mode has no FSMN kernel: the library must say so (EUNSUPPORTED), not run something else."""
-    from wekws_amd import _capi, pack
-    m = init_model(dict(synth.MODEL_CONFIGS["fsmn_small"])).to("cuda").set_precision("f32")
-    with pytest.raises(_capi.HipLibraryError, match="fsmn"):
-        m(torch.zeros(1, 4, 120, device="cuda"))
+def test_fsmn_f32_request_is_served_by_the_block_floating_kernel():
+    """FSMN has one kernel: split-fp16 products with block floating point (fsmn_f16.hip.h), fp32-level accuracy at any
+    operand scale (test_scale_sweep runs FSMN in both precision settings).  A precision-F32 descriptor is accepted and
+    gives the same numbers as the default."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["fsmn_small"])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    x = synth.synth_feats(2, 20, cfg["input_dim"], seed=1)
+    y0, c0 = run(build(cfg, sd), x)
+    y1, c1 = run(build(cfg, sd).set_precision("f32"), x)
+    assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
 
 
 def test_weight_update_repacks():

@@ -72,6 +72,11 @@ struct BlockDesc {
   float inv_s1, inv_s2;
   // depthwise output bound: |dw(u) + b| <= dw_alpha * max|u| + dw_beta  (max_c sum_j |w[c][j]|, max_c |b[c]|)
   float dw_alpha, dw_beta;
+  // MDTC mid tile ReLU(BN1(pointwise(a))): |mid| <= mid_alpha * max|a| + mid_beta  (largest row 1-norm of the folded
+  // pointwise matrix, largest |folded bias|).  Chained behind the depthwise bound: a bound that is 2^18 too loose still
+  // keeps the split's error below 2^-22 of the tile maximum, so bounds may compound WITHIN a block; across blocks the
+  // exact maximum of the residual tile is re-measured.
+  float mid_alpha, mid_beta;
   // ds256_mm: the depthwise taps enter the matrix cores scaled by dw_tap_s (power of two); dw_tap_inv = 1 / dw_tap_s
   float dw_tap_s, dw_tap_inv;
 };

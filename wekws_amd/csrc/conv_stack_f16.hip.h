@@ -19,11 +19,12 @@
 //     [2^14, 2^15) -- the TOP of the fp16 range, 16 binades of full-precision elements below the matrix maximum and an
 //     absolute error of 2^-25 (2^-39 of the maximum) below those;
 //   * activations (dynamic): every operand tile is multiplied by sa = 2^j before the split, with j from the tile's
-//     magnitude: the exact max|.| where it is known before the tile is written (the features, tiles re-written behind
-//     a barrier), else a rigorous bound (depthwise output: dw_alpha * max|input| + dw_beta, with the EXACT maximum of the
-//     input tile tracked by the epilogue that wrote it, so bounds never compound).  bound * sa lies in [2^14, 2^15): no
-//     element can overflow, and a bound that is 2^10 too loose still leaves every element within 2^-6 of the true
-//     maximum at full precision;
+//     magnitude: the exact max|.| where it is cheaply known before the tile is written (the features; tiles re-written
+//     behind an existing barrier), else a rigorous bound (depthwise output: dw_alpha * max|input| + dw_beta; MDTC mid
+//     tile: mid_alpha * that + mid_beta), anchored once per block on the EXACT maximum of the residual tile, which the
+//     epilogue that writes the tile tracks -- so bounds compound over at most one block.  bound * sa lies in
+//     [2^14, 2^15): no element can overflow; the split's error is max(2^-24 |v|, 2^-25) in scaled units, i.e. below 2^-22
+//     of the tile maximum as long as the bound is less than 2^18 too loose (row 1-norms overshoot by 2^3 .. 2^6);
 //   * the epilogue multiplies the accumulator by 1 / (sw * sa), exact, as part of the bias FMA.
 // Result: the products are scale-invariant -- a model with weights x 2^-12 and activations x 2^12 (or the reverse)
 // gives the same numbers as the unscaled one, like fp32 math does (tests/test_hip_parity.py::test_scale_sweep).
@@ -301,14 +302,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 
     // ---- operand scale of this block, per utterance: the producer's rows are bounded by the maximum of the input
     //      tile (published by the epilogue that wrote it) and of the incoming cache
-    float sa[U], c1 = 0.f;
+    float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      const float ba = KIND == KIND_TCN ? au : fmaf(bd.dw_alpha, au, bd.dw_beta);
       float inv;
-      sa[u] = pow2_scale(KIND == KIND_TCN ? au : fmaf(bd.dw_alpha, au, bd.dw_beta), &inv);
-      c1 = (u == wu) ? inv * bd.inv_s1 : c1;
+      sa[u] = pow2_scale(ba, &inv);
+      if (u == wu) {
+        c1 = inv * bd.inv_s1;
+        if constexpr (KIND == KIND_MDTC) {
+          sm = pow2_scale(fmaf(bd.mid_alpha, ba, bd.mid_beta), &c2);
+          c2 *= bd.inv_s2;
+        }
+      }
     }
+    (void)sm; (void)c2;
 
     // ---- producer of K-chunk n into slab buffer `buf` (fp16 hi / lo planes, [k-octet][frame][8])
     auto produce_impl = [&](int n, int buf, auto has_cache_tag) __attribute__((always_inline)) {
@@ -463,35 +472,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
       const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + (wo * OW) * (NK2 * 128) + lane;
 #pragma unroll
       for (int ks = 0; ks < NK2; ++ks) load_a16<OW>(a2[ks], ap2 + ks * 128, NK2 * 128);
-      // the mid tile is rewritten behind a barrier: its exact maximum sets its scale
-      float mmax = 0.f;
-#pragma unroll
-      for (int ow = 0; ow < OW; ++ow) {
-        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o_base + ow * 16 + lq * 4);
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[ow][tt][r] = fmaxf(fmaf(acc[ow][tt][r], c1, f4c(bias, r)), 0.f);
-            mmax = fmaxf(mmax, acc[ow][tt][r]);
-          }
-      }
-      amax_publish(cells_w + 3 + 2 * bi, mmax);
-      __syncthreads();
-      float c2;
-      const float sm = pow2_scale(amax_read(cells_w + 3 + 2 * bi), &c2);
-      c2 *= bd.inv_s2;
+      // mid = ReLU(BN1(pointwise)): scaled by the bound chained behind the depthwise one (BlockDesc::mid_alpha)
 #pragma unroll
       for (int ow = 0; ow < OW; ++ow) {
         const int o = o_base + ow * 16 + lq * 4;
+        const float4 bias = *reinterpret_cast<const float4*>(W + bd.b1 + o);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
           const int t = tt * 16 + l15;
           f16x4 vh, vl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(fmaf(acc[ow][tt][r], c1, f4c(bias, r)), 0.f);
             _Float16 h, l;
-            split16(acc[ow][tt][r] * sm, h, l);
+            split16(v * sm, h, l);
             vh[r] = h; vl[r] = l;
           }
           char* dst = slab_u + (((o >> 3) * TT + t) * 8 + (o & 7)) * 2;   // 4 consecutive channels = 8 bytes

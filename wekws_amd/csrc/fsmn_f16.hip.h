@@ -20,6 +20,15 @@
 // last P valid columns.  Cache tensor: (B, proj, P, layers),
 // layer index innermost (fsmn.py:495, torch.cat(in_cache, dim=-1)).
 //
+// Block floating point (conv_stack_f16.hip.h), per packed utterance: every packed matrix carries a host-chosen power-of-two
+// scale; every set of operand planes is written as v * s with s from a rigorous bound of the layer's output --
+// alpha * max|input| + beta (alpha = largest row 1-norm of the matrix, beta = largest |bias|; the memory block: largest
+// tap 1-norm x max(|p|, |cache|)).  Bounds chain through one FSMN layer (projection -> memory -> affine) and are
+// re-anchored on the EXACT maximum of the linear planes each layer ends with, which the affine epilogue tracks and hands
+// on through an LDS cell: a bound may be 2^18 too loose before the split's error exceeds 2^-22 of the tile maximum, a
+// layer's chain overshoots by ~2^12.  Epilogues undo both scales in their bias FMA.  Scales are per utterance, so
+// packing utterances into one workgroup does not change any result.
+//
 // Long inputs are cut into tiles of kFsmnTileFrames by the host, chained through the same cache format; short ones
 // (<= 32 frames, e.g. a 1-s utterance at frame_skip 3, or streaming chunks) are packed 2 or 4 utterances to a workgroup.
 #pragma once
@@ -33,7 +42,7 @@ constexpr int kFsmnMaxLayers = 16;
 constexpr int kFsmnHeldK = 5;       // layers with <= this many k-steps keep a whole o-tile pair of weights in registers
 constexpr int kFsmnMaxTaps = 32;
 constexpr int kFsmnTileFrames = 64;
-constexpr int kFsmnLdsLimit = 160 * 1024;
+constexpr int kFsmnLdsLimit = 160 * 1024 - 1024;   // (the maxima cells are static LDS beside the dynamic tile)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte store that only needs dword alignment
@@ -48,12 +57,23 @@ __device__ __forceinline__ void split16x8(f32x8 v, f16x8& h, f16x8& l) {
   l = __builtin_convertvector(v - __builtin_convertvector(h, f32x8), f16x8);
 }
 
+// one dense layer's block-floating constants: 1 / scale of its packed matrix; |W a + b| <= alpha * max|a| + beta
+struct FsmnDense {
+  float inv_s, alpha, beta;
+};
+
 struct FsmnLayer {
   uint32_t wp_a;   // proj  (Dp x LINp) packed A16, no bias
   uint32_t taps;   // [Dp][taps_ld] f32, zero padded
   uint32_t wa_a;   // affine (LINp x Dp) packed A16
   uint32_t wa_b;   // [LINp] f32
+  FsmnDense wp, wa;
+  float taps_l1;   // largest 1-norm of a channel's tap vector
 };
+
+// LDS cells of one utterance (maxima handed from phase to phase): [0] features, [1] incoming cache, [2 + l] the linear
+// planes entering layer l (l = nlayers: entering out_linear1)
+constexpr int kFsmnCells = 4 + kFsmnMaxLayers;
 
 struct FsmnParams {
   const float* w;
@@ -61,6 +81,7 @@ struct FsmnParams {
   int32_t kin, a1p, linp, dp, a2p, op; // padded to multiples of 32
   int32_t nlayers, ntaps, P, taps_ld;
   uint32_t in1_a, in1_b, in2_a, in2_b, out1_a, out1_b, out2_a, out2_b;
+  FsmnDense in1, in2, out1, out2;
   FsmnLayer layer[kFsmnMaxLayers];
 };
 
@@ -201,19 +222,57 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   const float* __restrict__ W = P.w;
   const int frag_off = (lq * TT + l15) * 16;
 
-  // epilogue: (+bias) [ReLU] -> hi / lo planes of CH channels at `dst`
+  // ---- block floating point: per-utterance maxima cells; scales of the planes being read (cin: what undoes them and
+  //      the matrix scale) and written (sout); running maxima of what an epilogue writes (mtrk)
+  __shared__ unsigned cells[U * kFsmnCells];
+  for (int e = tid; e < U * kFsmnCells; e += kFsmnThreads) cells[e] = 0u;
+  __syncthreads();
+  for (int u = 0; u < U; ++u)
+    if (b0 + u < A.B) {
+      amax_publish(cells + u * kFsmnCells, amax_span<kFsmnThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      if (A.in_cache)
+        amax_publish(cells + u * kFsmnCells + 1,
+                     amax_span<kFsmnThreads>(A.in_cache + int64_t(b0 + u) * P.proj * P.P * P.nlayers, P.proj * P.P * P.nlayers, 0.f));
+    }
+  __syncthreads();                                           // the staging below scales x with its maximum
+  float cin[U], sout[U], sinv[U], mtrk[U];
+  float bnd[U], inv_cur[U];                                  // bound (or exact maximum) and 1 / scale of the planes being read
+  // a dense layer reading those planes: cin = 1 / (their scale * the matrix scale); its output planes get the scale
+  // of the chained bound alpha * bnd + beta, which becomes the next layer's bnd
+  auto set_scales = [&](const FsmnDense& dl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cin[u] = inv_cur[u] * dl.inv_s;
+      bnd[u] = fmaf(dl.alpha, bnd[u], dl.beta);
+      sout[u] = pow2_scale(bnd[u], &sinv[u]);
+      inv_cur[u] = sinv[u];
+      mtrk[u] = 0.f;
+    }
+  };
+  // re-anchor on the exact maximum of the planes just written (all threads; holds the layer-end barrier)
+  auto reanchor = [&](int ci) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) amax_publish(cells + u * kFsmnCells + ci, mtrk[u]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) bnd[u] = amax_read(cells + u * kFsmnCells + ci);
+  };
+
+  // epilogue: acc * cin (+bias) [ReLU] -> tracked, scaled by sout -> hi / lo planes of CH channels at `dst`
   auto to_planes = [&](char* dst, int CH, bool relu) __attribute__((always_inline)) {
-    return [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
+    return [&, dst, CH, relu](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
       const int plb = CH * TT * 2;
 #pragma unroll
       for (int ow = 0; ow < 2; ++ow) {
         const int o = (ot + ow) * 16 + lq * 4;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-          f32x4 v = acc[ow][tt] + bias[ow];
+          const int u = tt / NTU;
+          f32x4 v = acc[ow][tt] * cin[u] + bias[ow];
           if (relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+          mtrk[u] = fmaxf(fmaxf(mtrk[u], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           f16x4 vh, vl;
-          split16x4(v, vh, vl);
+          split16x4(v * sout[u], vh, vl);
           char* d = dst + ((o >> 3) * TT + tt * 16 + l15) * 16 + (o & 4) * 2;
           *reinterpret_cast<f16x4*>(d) = vh;
           *reinterpret_cast<f16x4*>(d + plb) = vl;
@@ -248,8 +307,10 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
             if (k0 + i < P.idim) xv[i] = xr[i];
         }
       }
+      float inv_unused;
+      const float sxl = pow2_scale(amax_read_v(cells + u * kFsmnCells), &inv_unused);
       f16x8 vh, vl;
-      split16x8(xv, vh, vl);
+      split16x8(xv * sxl, vh, vl);
       char* d = r0 + (koct * TT + f) * 16;
       *reinterpret_cast<f16x8*>(d) = vh;
       *reinterpret_cast<f16x8*>(d + plb) = vl;
@@ -257,13 +318,20 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   }
   __syncthreads();
   // ---------------- in_linear1: x planes (R0) -> a1 planes (R1) ----------------
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bnd[u] = amax_read(cells + u * kFsmnCells);
+    (void)pow2_scale(bnd[u], &inv_cur[u]);
+  }
+  set_scales(P.in1);
   fsmn_gemm<NT>(W, P.in1_a, P.in1_b, P.a1p / 16, P.kin / 32, r0 + frag_off, P.kin * TT * 2, lane, wave,
                 to_planes(r1, P.a1p, false));
   __syncthreads();
   // ---------------- in_linear2 + ReLU: a1 planes (R1) -> linear planes (R0) ----------------
+  set_scales(P.in2);
   fsmn_gemm<NT>(W, P.in2_a, P.in2_b, P.linp / 16, P.a1p / 32, r1 + frag_off, P.a1p * TT * 2, lane, wave,
                 to_planes(r0, P.linp, true));
-  __syncthreads();
+  reanchor(2);
 
   float* const pt = reinterpret_cast<float*>(r1);           // p[dp][ss] f32
   char* const mpl = r0 + G.m_off;                           // memory-output planes
@@ -283,20 +351,33 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
         pt[c * SS + u * SEG + (j < Pc ? j : TTU + j)] = v;
       }
     }
-    // projection (no bias): linear planes (R0) -> p tile (R1)
+    // projection (no bias): linear planes (R0) -> p tile (R1), f32
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cin[u] = inv_cur[u] * ly.wp.inv_s;
+      bnd[u] = ly.wp.alpha * bnd[u];
+    }
     fsmn_gemm<NT>(W, ly.wp_a, 0, P.dp / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
-                  [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&)[2]) __attribute__((always_inline)) {
+                  [&](int ot, f32x4 (&acc)[2][NT], const f32x4 (&)[2]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int ow = 0; ow < 2; ++ow) {
                       const int o = (ot + ow) * 16 + lq * 4;
 #pragma unroll
                       for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                          pt[(o + r) * SS + (tt / NTU) * SEG + Pc + (tt % NTU) * 16 + l15] = acc[ow][tt][r];
+                        for (int r = 0; r < 4; ++r) {
+                          pt[(o + r) * SS + (tt / NTU) * SEG + Pc + (tt % NTU) * 16 + l15] = acc[ow][tt][r] * cin[tt / NTU];
+                        }
                     }
                   });
     __syncthreads();
+    // memory-block output planes: bound = largest tap 1-norm x max(bound of p, |cache|)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bnd[u] = ly.taps_l1 * fmaxf(bnd[u], amax_read(cells + u * kFsmnCells + 1));
+      sout[u] = pow2_scale(bnd[u], &sinv[u]);
+      inv_cur[u] = sinv[u];
+    }
     // memory block: item = (channel, run of 4 frames).  Lane bits: [0:2] channel within its octet, [3:4] run, [5]
     // octet -> conflict-free 16-byte window reads, 4-way conflicts on the 2-byte plane writes.
     {
@@ -322,8 +403,11 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
           w0 = w1;
           k = kn;
         }
+        float su = sout[0];                                 // (u is wave-uniform here: a wave covers 4 aligned runs)
+#pragma unroll
+        for (int k2 = 1; k2 < U; ++k2) su = (u == k2) ? sout[k2] : su;
         f16x4 vh, vl;
-        split16x4(acc4, vh, vl);
+        split16x4(acc4 * su, vh, vl);
         char* d = mpl + ((c >> 3) * TT + 4 * q) * 16 + (c & 7) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -342,19 +426,23 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
       }
     }
     __syncthreads();
-    // affine + ReLU: memory planes -> linear planes (R0)
+    // affine + ReLU: memory planes -> linear planes (R0), whose exact maximum re-anchors the bounds
+    set_scales(ly.wa);
     fsmn_gemm<NT>(W, ly.wa_a, ly.wa_b, P.linp / 16, P.dp / 32, mpl + frag_off, P.dp * TT * 2, lane, wave,
                   to_planes(r0, P.linp, true));
-    __syncthreads();
+    reanchor(3 + l);
   }
   // ---------------- out_linear1: linear planes (R0) -> o1 planes (R1) ----------------
+  set_scales(P.out1);
   fsmn_gemm<NT>(W, P.out1_a, P.out1_b, P.a2p / 16, P.linp / 32, r0 + frag_off, P.linp * TT * 2, lane, wave,
                 to_planes(r1, P.a2p, false));
+#pragma unroll
+  for (int u = 0; u < U; ++u) cin[u] = inv_cur[u] * P.out2.inv_s;
   __syncthreads();
   // ---------------- out_linear2: o1 planes (R1) -> y ----------------
   {
     const int K = P.odim;
-    auto store_y = [=](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
+    auto store_y = [&, K](int ot, f32x4 (&acc)[2][NT], const f32x4 (&bias)[2]) __attribute__((always_inline)) {
                     // rows of y are only dword aligned (odim is odd in the recipes): 16-byte stores through a
                     // 4-byte-aligned type.  Only the last pair can run past odim; that test is wave-uniform.
                     const bool whole = (ot + 2) * 16 <= K;
@@ -364,7 +452,7 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
 #pragma unroll
                       for (int tt = 0; tt < NT; ++tt) {
                         const int u = tt / NTU, t = (tt % NTU) * 16 + l15;
-                        const f32x4 v = acc[ow][tt] + bias[ow];
+                        const f32x4 v = acc[ow][tt] * cin[u] + bias[ow];
                         float* yr = A.y + int64_t(b0 + u) * A.ys_b + int64_t(t) * K + o;
                         const bool ok = t < T && b0 + u < A.B;
                         if (whole) {

@@ -19,6 +19,12 @@
 // pass consumes directly: layer inputs as operand planes [t][hi|lo][k-octet][stream][8 halves] (a B fragment is one
 // coalesced 16-byte load per lane, no LDS), gate pre-activations in the producing lane's own D-fragment order (the
 // lane that wrote them is the only one that reads them).
+//
+// Block floating point (conv_stack_f16.hip.h): every packed matrix carries a host-chosen power-of-two scale; operands are
+// scaled per stream tile before the fp16 split -- the features and the preprocessing output per time step (the exact
+// maximum of x[t] is wave-local: every wave holds the whole step; in0[t] is bounded through it), the hidden state by the
+// bound max(1, max|h0|) (the cell output is a convex combination of a tanh and the previous state).  The per-step scale
+// of in0 travels to pass I through a small workspace array.
 #pragma once
 #include "conv_stack_f16.hip.h"
 #include "gru.hip.h"
@@ -31,11 +37,15 @@ struct GruF16Params {
   uint32_t pre_a16;         // packed fp16 hi/lo A fragments ([o-tile][k32][hi|lo][lane][8])
   uint32_t a_ih16[kGruMaxLayers], a_hh16[kGruMaxLayers];
   uint32_t head_a16;        // classifier rows padded to a multiple of 16
+  // 1 / power-of-two scales of the packed matrices; |Wpre x + b| <= pre_alpha * max|x| + pre_beta
+  float pre_inv_s, head_inv_s, ih_inv_s[kGruMaxLayers], hh_inv_s[kGruMaxLayers];
+  float pre_alpha, pre_beta;
 };
 
 struct GruF16Workspace {
   char* seq[2];             // ping-pong layer sequences, operand planes
   float* gi;                // gate pre-activations of the layer in flight
+  float* sc;                // [stream tile][t]: 1 / scale of the preprocessing output planes of step t
 };
 
 template <int NN>
@@ -49,6 +59,7 @@ struct GruF16Geom {
                                                             // for its two [hi | lo] plane buffers of h
   static size_t seq_bytes(int B, int T) { return size_t((B + MB - 1) / MB) * T * SEQ_STEP; }
   static size_t gi_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * GI_STEP; }
+  static size_t sc_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T; }
 };
 
 __device__ __forceinline__ void gru_mfma1(f32x4& acc, const F16Frag& a, const f16x8& bh, const f16x8& bl) {
@@ -106,6 +117,39 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   float* const gi = WS.gi + size_t(blockIdx.x) * T * G::GI_STEP + size_t(wave) * 3 * NN * 256 + lane * 4;
   const int tb = (MODE == 0 || MODE == 3) ? 0 : int(blockIdx.y) * tchunk;       // time range of this workgroup
   const int te = (MODE == 0 || MODE == 3) ? T : min(T, tb + tchunk);
+  float* const sc = WS.sc + size_t(blockIdx.x) * T;
+
+  // bound of layer l's hidden state over this stream tile: max(1, max|h0[l]|) -- h(t) is a convex combination of a tanh
+  // and h(t-1).  Called by all threads (it holds a barrier); the same number in every pass / launch that needs it.
+  __shared__ unsigned gru_cells[kGruMaxLayers + 1];
+  if (tid <= kGruMaxLayers) gru_cells[tid] = 0u;
+  __syncthreads();
+  auto h_bound = [&](int l) __attribute__((always_inline)) -> float {
+    float m = 0.f;
+    if (h0)
+      for (int e = tid; e < MB * H; e += kThreads) {
+        const int sidx = b0 + e / H;
+        if (sidx < B) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
+      }
+    amax_publish(gru_cells + l, m);
+    __syncthreads();
+    return fmaxf(1.f, amax_read(gru_cells + l));
+  };
+  float hb_prev = 1.f;                                       // bound of the previous layer's output sequence
+  // Single-launch mode (streaming chunks): the h0 values behind every layer's bound are requested NOW, so that their
+  // trip from memory overlaps pass P; they are reduced and published behind pass P's barrier.
+  f32x4 h0v[MODE == 0 ? kGruMaxLayers : 1][NN];
+  const bool h0vec = h0 && reinterpret_cast<uintptr_t>(h0) % 16 == 0;
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int l = 0; l < kGruMaxLayers; ++l)
+#pragma unroll
+      for (int nn = 0; nn < NN; ++nn) {
+        const int f = (nn * kThreads + tid) * 4, sidx = b0 + f / H;
+        h0v[l][nn] = (h0vec && l < P.nlayers && sidx < B)
+                         ? *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + sidx) * H + (f % H)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 
   // =================== pass P: in0[t] = [ReLU](Wpre x[t] + b) -> seq0 (subsampling.py:53-57) ===================
   if constexpr (MODE == 0 || MODE == 1) {
@@ -143,6 +187,27 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
     load_x(xc, tb);
     for (int t = tb; t < te; ++t) {
       load_x(xn, t + 1);
+      // max|x[t]| over the tile: every wave holds the whole step, so the maximum is wave-local (no barrier)
+      float ax = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < nkp) {
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xc[ks][nn][j]));
+        }
+      ax = row16_max(ax);
+      {
+        const int axi = __float_as_int(ax);
+        ax = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(axi, 0)), __int_as_float(__builtin_amdgcn_readlane(axi, 16))),
+                   fmaxf(__int_as_float(__builtin_amdgcn_readlane(axi, 32)), __int_as_float(__builtin_amdgcn_readlane(axi, 48))));
+      }
+      float cx, inv_s0;
+      const float sx = pow2_scale(ax, &cx);
+      const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+      cx *= Q.pre_inv_s;
+      if (tid == 0) sc[t] = inv_s0;
       f32x4 acc[NN];
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -151,17 +216,18 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         if (ks < nkp) {
 #pragma unroll
           for (int nn = 0; nn < NN; ++nn) {
-            const f16x8 bh = __builtin_convertvector(xc[ks][nn], f16x8);
-            const f16x8 bl = __builtin_convertvector(xc[ks][nn] - __builtin_convertvector(bh, gru_f32x8), f16x8);
+            const gru_f32x8 xs = xc[ks][nn] * sx;
+            const f16x8 bh = __builtin_convertvector(xs, f16x8);
+            const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
             gru_mfma1(acc[nn], a[ks], bh, bl);
           }
         }
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) {
-        f32x4 v = acc[nn] + bpre;
+        f32x4 v = acc[nn] * cx + bpre;
         if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
         f16x4 vh, vl;
-        gru_split4(v, vh, vl);
+        gru_split4(v * s0, vh, vl);
         char* dst = seq0 + size_t(t) * G::SEQ_STEP + wr_off + nn * 256;
         *reinterpret_cast<f16x4*>(dst) = vh;
         *reinterpret_cast<f16x4*>(dst + PH) = vl;
@@ -173,6 +239,18 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
     }
   }
   if constexpr (MODE == 0) {
+    if (h0vec) {
+#pragma unroll
+      for (int l = 0; l < kGruMaxLayers; ++l)
+        if (l < P.nlayers) {
+          float m = 0.f;
+#pragma unroll
+          for (int nn = 0; nn < NN; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(h0v[l][nn][r]));
+          amax_publish(gru_cells + l, m);
+        }
+    }
     __threadfence_block();
     __syncthreads();
   }
@@ -195,6 +273,13 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       bias[0] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + u0);
       bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
       bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
+      // scale of this layer's input planes: per step for the preprocessing output (layer 0), else the bound of the
+      // previous layer's hidden state
+      if constexpr (MODE == 2) {
+        if (l > 0) hb_prev = h_bound(l - 1);
+      }
+      float inv_in;
+      (void)pow2_scale(hb_prev, &inv_in);
       // The input sequence is staged CS steps at a time through LDS (every wave needs all of it): each thread moves
       // CS*NN 16-byte items per chunk, requested one chunk ahead into registers and written to the other buffer after
       // the current chunk's products -- one barrier per chunk.
@@ -237,11 +322,12 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
                 for (int g = 0; g < 3; ++g) gru_mfma1(acc[g][nn], wi[g][ks], bh, bl);
               }
             float* go = gi + size_t(t) * G::GI_STEP;
+            const float cin = (l == 0 ? sc[t] : inv_in) * Q.ih_inv_s[l];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
               for (int nn = 0; nn < NN; ++nn)
-                *reinterpret_cast<f32x4*>(go + (g * NN + nn) * 256) = acc[g][nn] + bias[g];
+                *reinterpret_cast<f32x4*>(go + (g * NN + nn) * 256) = acc[g][nn] * cin + bias[g];
           }
         }
         GRU_PUT(gru16_lds + ((c + 1) & 1) * CHUNK)
@@ -259,6 +345,18 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wh[g][ks] = load_frag(ahh + (g * 8 + wave) * OTS + ks * 128);
       const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
+      // (a barrier either way: pass I is done with the staging buffers)
+      float hb;
+      if (MODE == 0 && (h0vec || !h0)) {
+        __syncthreads();
+        hb = fmaxf(1.f, amax_read(gru_cells + l));
+      } else {
+        hb = h_bound(l);
+      }
+      float chh;
+      const float shl = pow2_scale(hb, &chh);
+      chh *= Q.hh_inv_s[l];
+      hb_prev = hb;
       f32x4 hreg[NN];
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) {
@@ -267,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         if (h0 && s < B) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
         hreg[nn] = v;
         f16x4 vh, vl;
-        gru_split4(v, vh, vl);
+        gru_split4(v * shl, vh, vl);
         char* dst = gru16_lds + wr_off + nn * 256;
         *reinterpret_cast<f16x4*>(dst) = vh;
         *reinterpret_cast<f16x4*>(dst + PH) = vl;
@@ -307,14 +405,14 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
           f32x4 hv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float rg = gru_sigmoid(acc[0][nn][r] + g0[0][nn][r]);
-            const float zg = gru_sigmoid(acc[1][nn][r] + g0[1][nn][r]);
-            const float ng = gru_tanh(g0[2][nn][r] + rg * (acc[2][nn][r] + b_hn[r]));
+            const float rg = gru_sigmoid(fmaf(acc[0][nn][r], chh, g0[0][nn][r]));
+            const float zg = gru_sigmoid(fmaf(acc[1][nn][r], chh, g0[1][nn][r]));
+            const float ng = gru_tanh(g0[2][nn][r] + rg * fmaf(acc[2][nn][r], chh, b_hn[r]));
             hv[r] = ng + zg * (hreg[nn][r] - ng);               // (1 - z) n + z h
           }
           hreg[nn] = hv;
           f16x4 vh, vl;
-          gru_split4(hv, vh, vl);
+          gru_split4(hv * shl, vh, vl);
           char* dst = hw + wr_off + nn * 256;
           *reinterpret_cast<f16x4*>(dst) = vh;
           *reinterpret_cast<f16x4*>(dst + PH) = vl;
@@ -347,6 +445,10 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   if constexpr (MODE == 0 || MODE == 4) {
     const char* const stop = (P.nlayers & 1) ? seq1 : seq0;   // output sequence of the last layer
     const int head_tiles = (K + 15) / 16;
+    if constexpr (MODE == 4) hb_prev = h_bound(P.nlayers - 1);
+    float chd;
+    (void)pow2_scale(hb_prev, &chd);
+    chd *= Q.head_inv_s;
     for (int ot = 0; ot < head_tiles; ++ot) {
       const uint4* ahd = reinterpret_cast<const uint4*>(W + Q.head_a16) + size_t(ot) * OTS + lane;
       F16Frag a[4];
@@ -377,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (k0 + r < K) {
-                float v = acc[nn][r] + bc[r];
+                float v = fmaf(acc[nn][r], chd, bc[r]);
                 if (P.sigmoid) v = sigmoidf_(v);
                 y[(int64_t(s) * T + t) * K + k0 + r] = v;
               }
@@ -434,13 +536,15 @@ inline bool gru_f16_supported(const GruF16Params& Q) { return Q.kpre16 <= 128 &&
 inline int gru_f16_nn(int B) { return B > 16 * 256 ? 2 : 1; }
 
 // workspace sizes of one call (bytes): each of the two sequence buffers, and the gate pre-activations
-inline void gru_f16_workspace_bytes(int B, int T, size_t* seq_bytes, size_t* gi_bytes) {
+inline void gru_f16_workspace_bytes(int B, int T, size_t* seq_bytes, size_t* gi_bytes, size_t* sc_bytes) {
   if (gru_f16_nn(B) == 2) {
     *seq_bytes = GruF16Geom<2>::seq_bytes(B, T);
     *gi_bytes = GruF16Geom<2>::gi_floats(B, T) * sizeof(float);
+    *sc_bytes = GruF16Geom<2>::sc_floats(B, T) * sizeof(float);
   } else {
     *seq_bytes = GruF16Geom<1>::seq_bytes(B, T);
     *gi_bytes = GruF16Geom<1>::gi_floats(B, T) * sizeof(float);
+    *sc_bytes = GruF16Geom<1>::sc_floats(B, T) * sizeof(float);
   }
 }
 

@@ -193,16 +193,24 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       const float4 q0 = src[0], q1 = src[1];
       dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w; dww[4] = q1.x; dww[5] = q1.y;
     }
+    const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (in flight over the producer)
+    const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
     const bool slide = d <= 16 && (16 % d) == 0;
     const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
     // operand scales of the depthwise rows, per utterance (bound through the maxima of the input tile and the cache)
-    float sa[U], c1 = 0.f;
+    // mid tile: the bound chained behind the depthwise one (BlockDesc::mid_alpha)
+    float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      const float ba = fmaf(bd.dw_alpha, au, bd.dw_beta);
       float inv;
-      sa[u] = pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &inv);
-      c1 = (u == wu) ? inv * bd.inv_s1 : c1;
+      sa[u] = pow2_scale(ba, &inv);
+      if (u == wu) {
+        c1 = inv * bd.inv_s1;
+        sm = pow2_scale(fmaf(bd.mid_alpha, ba, bd.mid_beta), &c2);
+        c2 *= bd.inv_s2;
+      }
     }
 
     // ---- producer: lane-group pg makes channel pg of both utterances: depthwise dilated conv + folded BN
@@ -292,27 +300,13 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     __syncthreads();
     // ---- GEMM 1 (pointwise) over the full K
     gemm(ap1);
-    const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
-    const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
-    // mid = ReLU(BN1(pointwise)) (mdtc.py:113-114): its exact maximum, known before the barrier, sets its scale
-    float mmax = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < NTW; ++tt)
-      if (tt < ntw) {
-        acc[tt] = __builtin_elementwise_max(acc[tt] * c1 + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f});
-        mmax = fmaxf(fmaxf(mmax, fmaxf(acc[tt][0], acc[tt][1])), fmaxf(acc[tt][2], acc[tt][3]));
-      }
-    amax_publish(cells_w + 3 + 2 * bi, mmax);
     __syncthreads();                                         // every wave is done reading the depthwise planes
-    float c2;
-    const float sm = pow2_scale(amax_read(cells_w + 3 + 2 * bi), &c2);
-    c2 *= bd.inv_s2;
-    // ---- written in operand order over them
+    // ---- mid = ReLU(BN1(pointwise)) written in operand order over them (mdtc.py:113-114)
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
       if (tt < ntw) {
         const int t = (ft0 + tt) * 16 + l15;
-        const f32x4 v = acc[tt] * sm;
+        const f32x4 v = __builtin_elementwise_max(acc[tt] * c1 + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f}) * sm;
         const f16x4 vh = __builtin_convertvector(v, f16x4);
         char* dst = slab_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
         *reinterpret_cast<f16x4*>(dst) = vh;

@@ -278,8 +278,9 @@ struct wekws_hip_fbank {
 // FSMN: validate, zero-pad every channel count to a multiple of 32, pre-split + pre-pack the six kinds of dense
 // layers as MFMA A operands (fsmn_f16.hip.h), upload.
 static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elems, int device, wekws_hip_model** out) {
-  if (d.precision == WEKWS_HIP_PRECISION_F32)
-    return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: only the split-fp16 (F16X3 / DEFAULT) kernel is built");
+  // every precision request is served by the block-floating split-fp16 kernel (22-bit products, fp32 accumulate: the
+  // accuracy of fp32 arithmetic at any operand scale, tests/test_hip_parity.py::test_scale_sweep); an exact-f32 FSMN
+  // kernel is not built
   if (d.num_layers > wekws::kFsmnMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn num_layers %d > %d", d.num_layers, wekws::kFsmnMaxLayers);
   const int I = d.idim, A1 = d.aux[0], A2 = d.aux[1], C = d.hdim, D = d.num_stack, K = d.odim;
   const int ntaps = d.kernel_size + d.stack_size;
@@ -303,32 +304,50 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   img.reserve(4);
   const float* p = blob;
   // a dense layer W[O][Ksrc] (+ bias[O]): A operand padded to (Op x Kp); bias padded with zeros to Op
-  auto dense = [&](int O, int Ksrc, int Op, bool has_bias, uint32_t* a_off, uint32_t* b_off) {
+  // block floating point (fsmn_f16.hip.h): matrix scale, and the output bound |W a + b| <= alpha max|a| + beta
+  auto dense = [&](int O, int Ksrc, int Op, bool has_bias, uint32_t* a_off, uint32_t* b_off, wekws::FsmnDense* fd) {
     std::vector<float> wp(size_t(Op) * Ksrc, 0.f);
     std::memcpy(wp.data(), p, size_t(O) * Ksrc * sizeof(float));
-    *a_off = img.put_packed_a16(wp.data(), Op, Ksrc, Ksrc, nullptr);
+    *a_off = img.put_packed_a16(wp.data(), Op, Ksrc, Ksrc, &fd->inv_s);
+    float l1 = 0.f, bmax = 0.f;
+    for (int o = 0; o < O; ++o) {
+      double sum = 0.0;
+      for (int k = 0; k < Ksrc; ++k) sum += std::fabs(double(p[size_t(o) * Ksrc + k]));
+      l1 = float(sum) > l1 ? float(sum) : l1;
+    }
     p += size_t(O) * Ksrc;
     if (has_bias) {
       std::vector<float> bp(Op, 0.f);
       std::memcpy(bp.data(), p, size_t(O) * sizeof(float));
       *b_off = img.put(bp.data(), Op);
+      for (int o = 0; o < O; ++o) bmax = std::fabs(p[o]) > bmax ? std::fabs(p[o]) : bmax;
       p += O;
     }
+    fd->alpha = l1 * 1.0001f;                                // (summation order / rounding of the device's accumulation)
+    fd->beta = bmax;
   };
-  dense(A1, I, q.a1p, true, &q.in1_a, &q.in1_b);
-  dense(C, A1, q.linp, true, &q.in2_a, &q.in2_b);
+  dense(A1, I, q.a1p, true, &q.in1_a, &q.in1_b, &q.in1);
+  dense(C, A1, q.linp, true, &q.in2_a, &q.in2_b, &q.in2);
   for (int l = 0; l < d.num_layers; ++l) {
     uint32_t none = 0;
-    dense(D, C, q.dp, false, &q.layer[l].wp_a, &none);
+    dense(D, C, q.dp, false, &q.layer[l].wp_a, &none, &q.layer[l].wp);
     std::vector<float> tp(size_t(q.dp) * q.taps_ld, 0.f);
-    for (int c = 0; c < D; ++c)
-      for (int j = 0; j < ntaps; ++j) tp[size_t(c) * q.taps_ld + j] = p[size_t(c) * ntaps + j];
+    float tl1 = 0.f;
+    for (int c = 0; c < D; ++c) {
+      float sum = 0.f;
+      for (int j = 0; j < ntaps; ++j) {
+        tp[size_t(c) * q.taps_ld + j] = p[size_t(c) * ntaps + j];
+        sum += std::fabs(p[size_t(c) * ntaps + j]);
+      }
+      tl1 = sum > tl1 ? sum : tl1;
+    }
+    q.layer[l].taps_l1 = tl1 * 1.00001f;
     q.layer[l].taps = img.put(tp.data(), tp.size());
     p += size_t(D) * ntaps;
-    dense(C, D, q.linp, true, &q.layer[l].wa_a, &q.layer[l].wa_b);
+    dense(C, D, q.linp, true, &q.layer[l].wa_a, &q.layer[l].wa_b, &q.layer[l].wa);
   }
-  dense(A2, C, q.a2p, true, &q.out1_a, &q.out1_b);
-  dense(K, A2, q.op, true, &q.out2_a, &q.out2_b);
+  dense(A2, C, q.a2p, true, &q.out1_a, &q.out1_b, &q.out1);
+  dense(K, A2, q.op, true, &q.out2_a, &q.out2_b, &q.out2);
   if (size_t(p - blob) != n_elems)
     return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
 
@@ -544,6 +563,18 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
         p += C;
         b.a1 = img.put_packed_a(p, C, C, C);
         b.a1_16 = img.put_packed_a16(p, C, C, C, &b.inv_s1);
+        {  // |W1 a + b1| <= mid_alpha * max|a| + mid_beta (MDTC mid tile)
+          float l1 = 0.f, bmax = 0.f;
+          for (int o = 0; o < C; ++o) {
+            float sum = 0.f;
+            for (int k = 0; k < C; ++k) sum += std::fabs(p[size_t(o) * C + k]);
+            l1 = sum > l1 ? sum : l1;
+            const float ab = std::fabs(p[size_t(C) * C + o]);
+            bmax = ab > bmax ? ab : bmax;
+          }
+          b.mid_alpha = l1 * 1.0001f;
+          b.mid_beta = bmax;
+        }
         p += size_t(C) * C;
         b.b1 = img.put(p, C);
         p += C;
@@ -624,16 +655,28 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       const float* bhh = p; p += 3 * C;
       gp.layer[l].a_ih = img.put_packed_a(wih, 3 * C, C, C);
       gp.layer[l].a_hh = img.put_packed_a(whh, 3 * C, C, C);
-      m->gq.a_ih16[l] = img.put_packed_a16(wih, 3 * C, C, C, nullptr);
-      m->gq.a_hh16[l] = img.put_packed_a16(whh, 3 * C, C, C, nullptr);
+      m->gq.a_ih16[l] = img.put_packed_a16(wih, 3 * C, C, C, &m->gq.ih_inv_s[l]);
+      m->gq.a_hh16[l] = img.put_packed_a16(whh, 3 * C, C, C, &m->gq.hh_inv_s[l]);
       gp.layer[l].b_ih = img.put(bih, 3 * C);
       gp.layer[l].b_hh = img.put(bhh, 3 * C);
     }
-    m->gq.head_a16 = img.put_packed_a16(p, K, C, C, nullptr);
+    m->gq.head_a16 = img.put_packed_a16(p, K, C, C, &m->gq.head_inv_s);
     gp.head_w = img.put(p, size_t(K) * C); p += size_t(K) * C;
     gp.head_b = img.put(p, K); p += K;
     m->gq.kpre16 = round_up(d.idim, 32);
-    m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim, nullptr);
+    m->gq.pre_a16 = img.put_packed_a16(blob, C, d.idim, d.idim, &m->gq.pre_inv_s);
+    {  // |Wpre x + b| <= pre_alpha * max|x| + pre_beta
+      float l1 = 0.f, bmax = 0.f;
+      for (int o = 0; o < C; ++o) {
+        float sum = 0.f;
+        for (int k = 0; k < d.idim; ++k) sum += std::fabs(blob[size_t(o) * d.idim + k]);
+        l1 = sum > l1 ? sum : l1;
+        const float ab = std::fabs(blob[size_t(C) * d.idim + o]);
+        bmax = ab > bmax ? ab : bmax;
+      }
+      m->gq.pre_alpha = l1 * 1.00001f;
+      m->gq.pre_beta = bmax;
+    }
     m->cache_len = 0;
   }
   if (size_t(p - blob) != n_elems) {
@@ -719,13 +762,14 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     if (f16) {
       // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
       // same stream are ordered by the stream, calls on different streams never share a buffer
-      size_t seq_b = 0, gi_b = 0;
-      wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b);
-      const size_t seq_al = (seq_b + 255) / 256 * 256;
-      const size_t need = 2 * seq_al + gi_b;
+      size_t seq_b = 0, gi_b = 0, sc_b = 0;
+      wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b, &sc_b);
+      const size_t seq_al = (seq_b + 255) / 256 * 256, gi_al = (gi_b + 255) / 256 * 256;
+      const size_t need = 2 * seq_al + gi_al + sc_b;
       char* base = stream_workspace(m, stream, need);
       if (!base) return WEKWS_HIP_ENOMEM;
-      wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al)};
+      wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al),
+                                reinterpret_cast<float*>(base + 2 * seq_al + gi_al)};
       rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
     } else {
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);

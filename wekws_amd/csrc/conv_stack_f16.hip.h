@@ -55,51 +55,106 @@ __device__ __forceinline__ void split16(float v, _Float16& h, _Float16& l) {
   l = static_cast<_Float16>(v - static_cast<float>(h));
 }
 
+// Scale and split in three instructions: hi = fp16(v * s) (v_fma_mixlo_f16: one rounding of the exact product),
+// d = v * s - hi (v_fma_mix_f32 with hi as an fp16 operand: exact), lo = fp16(d).  s is a power of two.
+__device__ __forceinline__ void split16s(float v, float s, _Float16& h, _Float16& l) {
+  unsigned hr;
+  float d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hr) : "v"(v), "v"(s));            // (upper half of hr: don't care)
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(s), "v"(hr));
+  h = __builtin_bit_cast(_Float16, static_cast<unsigned short>(hr & 0xffffu));
+  l = static_cast<_Float16>(d);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Block floating point (see the header comment).
 // ---------------------------------------------------------------------------------------------
-// LDS cells per utterance that carry tile maxima between phases: [0] features, [1] whole input cache,
-// [2 + 2*i] input tile of block i (block nblocks = the backbone output), [3 + 2*i] MDTC mid tile of block i
-constexpr int kAmaxCells = 40;
-constexpr int kAmaxMaxBlocks = (kAmaxCells - 4) / 2;   // 18: MDTC 4 x 4 + 1 = 17 (mdtc.yaml), DS-TCN 4
+// Tile maxima travel between phases through LDS cells (one 32-bit word each, zeroed at kernel entry): the publisher
+// reduces inside the wave (six DPP steps) and lane 63 merges the wave's maximum with ds_max_u32; the reader needs ONE
+// ds_read_b32.  Every wave reads the cells and derives the scales itself, redundantly, on the VECTOR unit: sixteen
+// waves bouncing a handful of values between the vector and the scalar unit (v_readfirstlane and back) measured four
+// times slower on the block-to-block critical path of the streaming kernels.
+// Cells per utterance: [0] features, [1] incoming cache, [2 + i] the residual tile entering block i (i = nblocks: the
+// backbone output).
+struct AmaxCell {
+  unsigned v;
+};
+constexpr int kAmaxMaxBlocks = 24;                     // rows of the LDS block table (MDTC 4 x 4 + 1 = 17, DS-TCN 4)
+constexpr int kAmaxCells = 3 + kAmaxMaxBlocks;
 
-// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.  A zero (or non-finite) bound keeps s = 1.
+template <int NTHR>
+__device__ __forceinline__ void amax_zero(AmaxCell* cells, int n) {
+  for (int e = threadIdx.x; e < n; e += NTHR) cells[e].v = 0u;
+}
+
+// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.  Six integer operations, no special cases:
+// a zero (or f32-subnormal) bound means every element of the tile is zero (or below 2^-126) and gets s = 2^126; a
+// non-finite bound gets s = 2^-114 and the infinities stay infinities, as they would in fp32 arithmetic.
 __device__ __forceinline__ float pow2_scale(float bound, float* inv) {
-  const uint32_t e = (__float_as_uint(bound) >> 23) & 0xffu;   // biased exponent (0: zero / f32 subnormal)
-  uint32_t se = 268u - e;                                       // 127 + 14 - (e - 127)
-  se = se > 253u ? 253u : se;
-  se = (e == 0u || e == 255u) ? 127u : se;
+  const uint32_t e = (__float_as_uint(bound) >> 23) & 0xffu;   // biased exponent
+  const uint32_t se = min(268u - e, 253u);                      // 127 + 14 - (e - 127), capped so that 1 / s stays normal
   *inv = __uint_as_float((254u - se) << 23);
   return __uint_as_float(se << 23);
 }
 
-// max over each 16-lane row of the wave, in every lane of the row (4 DPP steps, no LDS traffic)
-__device__ __forceinline__ float row16_max(float v) {
-  int x = __float_as_int(v);
-#define WEKWS_DPP_MAX(ctrl)                                                                          \
-  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, (ctrl), 0xf, 0xf, false))));
-  WEKWS_DPP_MAX(0xB1)   // quad_perm [1,0,3,2]
-  WEKWS_DPP_MAX(0x4E)   // quad_perm [2,3,0,1]
-  WEKWS_DPP_MAX(0x141)  // row_half_mirror
-  WEKWS_DPP_MAX(0x140)  // row_mirror
-#undef WEKWS_DPP_MAX
-  return __int_as_float(x);
+// x = max(x, x of the lane the DPP control selects): ONE v_max_u32 with a DPP operand (the compiler's own lowering of
+// update_dpp + max is a v_mov_dpp, a max and a copy per step).  Written as inline assembly, so the wait states a DPP
+// read of a just-written VGPR needs on gfx9 are spelled out.
+#define WEKWS_UMAX_DPP(x, ctrl) asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(x))
+// max over the wave of non-negative floats (ordered like their bit patterns), valid in lane 63
+__device__ __forceinline__ unsigned wave_umax63(unsigned x) {
+  WEKWS_UMAX_DPP(x, "quad_perm:[1,0,3,2] row_mask:0xf");
+  WEKWS_UMAX_DPP(x, "quad_perm:[2,3,0,1] row_mask:0xf");
+  WEKWS_UMAX_DPP(x, "row_half_mirror row_mask:0xf");
+  WEKWS_UMAX_DPP(x, "row_mirror row_mask:0xf");          // every lane holds its row's maximum
+  WEKWS_UMAX_DPP(x, "row_bcast:15 row_mask:0xa");        // rows 1 and 3 take in rows 0 and 2
+  WEKWS_UMAX_DPP(x, "row_bcast:31 row_mask:0xc");        // rows 2 and 3 take in row 1: lane 63 holds the maximum
+  return x;
+}
+// Publish this thread's partial max|.| (v >= 0; a NaN orders above everything and ends up disabling the scale): wave
+// reduction, then lane 63 merges into the cell.
+__device__ __forceinline__ void amax_publish(AmaxCell* cell, float v) {
+  const unsigned x = wave_umax63(__float_as_uint(v));
+  // lane 63 alone issues the ds_max_u32: EXEC is narrowed by hand (five instructions; the compiler's lowering of a
+  // one-lane atomicMax adds an active-lane scan loop that costs ~200 cycles of a block boundary)
+  const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&cell->v));   // LDS offset = low half of the flat address
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b32 exec_lo, 0\n\t"
+      "s_mov_b32 exec_hi, 0x80000000\n\t"
+      "ds_max_u32 %1, %2\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved)
+      : "v"(addr), "v"(x)
+      : "memory");
+}
+__device__ __forceinline__ float amax_read(const AmaxCell* cell) { return __uint_as_float(cell->v); }
+
+// The block table, copied into LDS once: reading a descriptor at a block boundary then costs an LDS round trip instead of
+// a trip to L2 that every wave of the workgroup waits for (a uniform global load is not scalarised here: the kernels
+// also store to global memory).
+template <int NTHR, class BD>
+__device__ __forceinline__ void stage_block_table(BD* dst, const BD* __restrict__ src, int nb) {
+  const int n = nb * int(sizeof(BD) / 4);
+  for (int e = threadIdx.x; e < n; e += NTHR) reinterpret_cast<uint32_t*>(dst)[e] = reinterpret_cast<const uint32_t*>(src)[e];
 }
 
-// Publish this thread's partial max|.| (v >= 0) into an LDS cell: row reduction, then one ds_max_u32 per 16-lane row
-// (non-negative floats order like their bit patterns; a NaN wins and later disables the scaling).
-__device__ __forceinline__ void amax_publish(unsigned* cell, float v) {
-  v = row16_max(v);
-  if ((threadIdx.x & 15) == 0) atomicMax(cell, __float_as_uint(v));
-}
-// wave-uniform cell (the scale arithmetic that follows stays on the scalar unit) / per-lane cell
-__device__ __forceinline__ float amax_read(const unsigned* cell) { return __uint_as_float(__builtin_amdgcn_readfirstlane(*cell)); }
-__device__ __forceinline__ float amax_read_v(const unsigned* cell) { return __uint_as_float(*cell); }
-
-// max|.| over a contiguous run of n floats, this thread's share (stride = workgroup size)
+// max|.| over a contiguous run of n floats, this thread's share (stride = workgroup size).  Eight loads are in flight
+// per thread before the first is consumed: the run costs one trip to memory per 8 x NTHR elements, not one per element.
 template <int NTHR>
 __device__ __forceinline__ float amax_span(const float* __restrict__ p, int n, float m) {
-  for (int e = threadIdx.x; e < n; e += NTHR) m = fmaxf(m, fabsf(p[e]));
+  constexpr int DEPTH = 8;
+  for (int e0 = threadIdx.x; e0 < n; e0 += NTHR * DEPTH) {
+    float v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+      const int e = e0 + k * NTHR;
+      v[k] = p[e < n ? e : e0];                              // (clamped duplicate: harmless for a maximum)
+    }
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
   return m;
 }
 
@@ -182,9 +237,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   if constexpr (KIND == KIND_MDTC) zero_acc(zsum);
 
   // ---- block floating point: per-utterance maxima of the features and of the incoming cache
-  __shared__ unsigned amax_cells[U * kAmaxCells];
-  unsigned* const cells_w = amax_cells + wu * kAmaxCells;  // this wave's utterance
-  for (int e = tid; e < U * kAmaxCells; e += kThreads) amax_cells[e] = 0u;
+  __shared__ AmaxCell amax_cells[U * kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  AmaxCell* const cells_w = amax_cells + wu * kAmaxCells;  // this wave's utterance
+  amax_zero<kThreads>(amax_cells, U * kAmaxCells);
+  stage_block_table<kThreads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   for (int u = 0; u < U; ++u) {
     if (b0 + u < A.B) {                                    // workgroup-uniform
@@ -206,6 +263,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     for (int k0 = 0; k0 < nk; k0 += NBUF) {                // NBUF K steps staged per pass
       const int steps = min(NBUF, nk - k0);
       __syncthreads();
+      float sxu[U];                                        // feature scale of each utterance
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float inv_unused;
+        sxu[u] = pow2_scale(amax_read(amax_cells + u * kAmaxCells), &inv_unused);
+      }
       // item = (utterance, step, k-octet, frame): 8 consecutive features of one frame -> one 16-byte hi + lo store
       for (int e = tid; e < ((WEKWS_ABLATE == 5 || WEKWS_ABLATE == 9) ? 0 : U * steps * 4 * TT); e += kThreads) {
         const int t = e % TT;
@@ -215,8 +278,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         const int kf = (k0 + st) * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
-        float inv_unused;
-        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
+        float sx = sxu[0];
+#pragma unroll
+        for (int q = 1; q < U; ++q) sx = (u == q) ? sxu[q] : sx;
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -261,7 +325,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 
   // ======================================= residual blocks =======================================
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const BlockDesc bd = P.blocks[bi];
+    const BlockDesc bd = blk[bi];
     const int d = bd.dil, pad = bd.pad;
     constexpr int K1 = (KIND == KIND_TCN) ? C * KS : C;
     constexpr int nch = K1 / KC;
@@ -305,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + bi), amax_read(amax_cells + u * kAmaxCells + 1));
       const float ba = KIND == KIND_TCN ? au : fmaf(bd.dw_alpha, au, bd.dw_beta);
       float inv;
       sa[u] = pow2_scale(ba, &inv);
@@ -369,9 +433,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
 #pragma unroll
           for (int m = 0; m < NT; ++m) {
             const int t = tl + 16 * m;
-            const float v = fetch(t - sh) * sau;
+            const float v = fetch(t - sh);
             _Float16 h, l;
-            split16(v, h, l);
+            split16s(v, sau, h, l);
             ph[t * 8] = h;
             pl[t * 8] = l;
           }
@@ -407,7 +471,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
               const int t = fbase + m * d;
               _Float16 h, l;
-              split16(o * sau, h, l);
+              split16s(o, sau, h, l);
               ph[t * 8] = h;
               pl[t * 8] = l;
             }
@@ -420,7 +484,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
               for (int j = 0; j < KS; ++j) o = fmaf(dww[i][j], fetch(t - (KS - 1 - j) * d), o);
               if (KIND == KIND_DS) o = fmaxf(o, 0.f);
               _Float16 h, l;
-              split16(o * sau, h, l);
+              split16s(o, sau, h, l);
               ph[t * 8] = h;
               pl[t * 8] = l;
             }
@@ -525,7 +589,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         }
       }
     }
-    amax_publish(cells_w + 4 + 2 * bi, hmax);              // = the input tile of block bi + 1
+    amax_publish(cells_w + 3 + bi, hmax);              // = the input tile of block bi + 1
     __syncthreads();
   }
 

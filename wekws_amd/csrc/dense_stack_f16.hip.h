@@ -102,9 +102,11 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
 
   // ---- block floating point (conv_stack_f16.hip.h): per-utterance maxima of the features and the incoming cache.
   //      The h planes (and the halo in front of them) of block i carry the scale of max(cell[2 + 2i], cache maximum).
-  __shared__ unsigned amax_cells[U * kAmaxCells];
-  unsigned* const cells_w = amax_cells + wu * kAmaxCells;
-  for (int e = tid; e < U * kAmaxCells; e += kThreads) amax_cells[e] = 0u;
+  __shared__ AmaxCell amax_cells[U * kAmaxCells];
+  __shared__ DenseBlock blk[kAmaxMaxBlocks];
+  AmaxCell* const cells_w = amax_cells + wu * kAmaxCells;
+  amax_zero<kThreads>(amax_cells, U * kAmaxCells);
+  stage_block_table<kThreads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
@@ -114,10 +116,18 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
     }
   // scale of utterance u's h planes while they are the input of block bi (bi = nblocks: the backbone output)
   auto h_scale = [&](int u, int bi, float* inv) __attribute__((always_inline)) -> float {       // u wave-uniform
-    return pow2_scale(fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1)), inv);
+    return pow2_scale(fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + bi), amax_read(amax_cells + u * kAmaxCells + 1)), inv);
   };
-  auto h_scale_v = [&](int u, int bi, float* inv) __attribute__((always_inline)) -> float {     // u per lane
-    return pow2_scale(fmaxf(amax_read_v(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read_v(amax_cells + u * kAmaxCells + 1)), inv);
+  // the same for every utterance of the workgroup (per-lane u: select with pick())
+  auto h_scales = [&](int bi, float (&sc)[U], float (&inv)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) sc[u] = h_scale(u, bi, &inv[u]);
+  };
+  auto pick = [](const float (&a)[U], int u) __attribute__((always_inline)) -> float {
+    float v = a[0];
+#pragma unroll
+    for (int q = 1; q < U; ++q) v = (u == q) ? a[q] : v;
+    return v;
   };
 
   // ---- zero the left halo of every h plane once (no-cache left context; overwritten per block when caching)
@@ -139,6 +149,12 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
     for (int ow = 0; ow < OW; ++ow) bias[ow] = *reinterpret_cast<const float4*>(W + P.pre_b + o_base + ow * 16 + lq * 4);
     for (int ks = 0; ks < nk; ++ks) {                      // one 32-feature K step staged per pass
       __syncthreads();
+      float sxu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float inv_unused;
+        sxu[u] = pow2_scale(amax_read(amax_cells + u * kAmaxCells), &inv_unused);
+      }
       for (int e = tid; e < U * 4 * TT; e += kThreads) {  // item = (utterance, k-octet, frame)
         const int t = e % TT;
         const int q = e / TT;
@@ -146,8 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const int kf = ks * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
-        float inv_unused;
-        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
+        const float sx = pick(sxu, u);
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
   // ======================================= blocks =======================================
   const int frag_h = (lq * FR + HALO + l15) * 16;          // this lane's fragment item: octet lq, frame l15 of tile 0
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const DenseBlock bd = P.blocks[bi];
+    const DenseBlock bd = blk[bi];
     const int d = bd.dil, pad = bd.pad;
     constexpr int NK1 = KS * (C / 32);                     // K steps of GEMM1: (tap, 32-channel half)
     const int ot_stride1 = NK1 * 128;
@@ -211,15 +226,17 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
     for (int ow = 0; ow < OW; ++ow) ebias[ow] = *reinterpret_cast<const float4*>(W + bd.b1 + o_base + ow * 16 + lq * 4);
 
     // ---- left context of this block into the halo, and the streaming-cache hand-over   (tcn.py:49-54, mdtc.py:108-112)
+    float shs[U], inv_shs[U];
+    h_scales(bi, shs, inv_shs);
     if (A.in_cache) {
       for (int e = tid; e < U * C * pad; e += kThreads) {
         const int p = e % pad;
         const int uc = e / pad;
         const int u = uc / C, c = uc % C;
-        float v = 0.f, inv_unused;
+        float v = 0.f;
         if (b0 + u < A.B) v = A.in_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p];
         _Float16 h, l;
-        split16(v * h_scale_v(u, bi, &inv_unused), h, l);
+        split16(v * pick(shs, u), h, l);
         char* dst = dense_lds + u * UB + ((c >> 3) * FR + HALO - pad + p) * 16 + (c & 7) * 2;
         *reinterpret_cast<_Float16*>(dst) = h;
         *reinterpret_cast<_Float16*>(dst + HP) = l;
@@ -234,8 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const int u = uc / C, c = uc % C;
         if (b0 + u < A.B) {
           const char* src = dense_lds + u * UB + ((c >> 3) * FR + HALO + T - pad + p) * 16 + (c & 7) * 2;
-          float inv_hu;
-          (void)h_scale_v(u, bi, &inv_hu);
+          const float inv_hu = pick(inv_shs, u);
           const float v = (static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
                            static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP))) * inv_hu;
           A.out_cache[(int64_t(b0 + u) * C + c) * Pc + bd.cache_off + p] = v;
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         }
       }
     }
-    amax_publish(cells_w + 4 + 2 * bi, hmax);
+    amax_publish(cells_w + 3 + bi, hmax);
     __syncthreads();  // every wave has finished reading the h planes before they are rewritten in place
     const float sh_new = h_scale(wu, bi + 1, &inv_h);
 #pragma unroll
@@ -338,14 +354,15 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
       }
     }
   } else if (P.head == HEAD_IDENTITY) {
+    float shs[U], inv_shs[U];
+    h_scales(P.nblocks, shs, inv_shs);
     for (int e = tid; e < U * T * C; e += kThreads) {
       const int c = e % C;
       const int ut = e / C;
       const int u = ut / T, t = ut - u * T;
       if (b0 + u >= A.B) continue;
       const char* src = dense_lds + u * UB + ((c >> 3) * FR + HALO + t) * 16 + (c & 7) * 2;
-      float inv_hu;
-      (void)h_scale_v(u, P.nblocks, &inv_hu);
+      const float inv_hu = pick(inv_shs, u);
       float v = (static_cast<float>(*reinterpret_cast<const _Float16*>(src)) +
                  static_cast<float>(*reinterpret_cast<const _Float16*>(src + HP))) * inv_hu;
       if (P.sigmoid) v = sigmoidf_(v);
@@ -356,11 +373,12 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
     float* mvec = reinterpret_cast<float*>(dense_lds + 2 * HP);     // utterance 0's scratch: [U][C] then [U][hh]
     float* hid = mvec + U * C;
     const int HH = P.head_hidden;
+    float shs[U], inv_shs[U];
+    h_scales(P.nblocks, shs, inv_shs);
     for (int e = tid; e < U * C; e += kThreads) {
       const int u = e / C, c = e - u * C;
       const char* row = dense_lds + u * UB + ((c >> 3) * FR + HALO) * 16 + (c & 7) * 2;
-      float inv_hu;
-      (void)h_scale_v(u, P.nblocks, &inv_hu);
+      const float inv_hu = pick(inv_shs, u);
       auto at = [&](int t) -> float {
         return (static_cast<float>(*reinterpret_cast<const _Float16*>(row + t * 16)) +
                 static_cast<float>(*reinterpret_cast<const _Float16*>(row + HP + t * 16))) * inv_hu;

@@ -61,14 +61,16 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
 
   // ---- block floating point (conv_stack_f16.hip.h).  The activation planes (and the left-context planes in front of
   //      them) of block i carry the power-of-two scale of max(cell[2 + 2i], cache maximum).
-  __shared__ unsigned amax_cells[kAmaxCells];
-  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
+  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
   if constexpr (HAS_CACHE)
     amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
   auto h_amax = [&](int bi) __attribute__((always_inline)) -> float {
-    return HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + 2 * bi);
+    return HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + bi);
   };
 
   if constexpr (!HAS_CACHE) {                                // zero left context, once
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
       *reinterpret_cast<f16x4*>(hpl + hwr + tt * 256) = vh;
       *reinterpret_cast<f16x4*>(hpl + HP + hwr + tt * 256) = vl;
     }
-    if (P.nblocks > 0) stage_halo(P.blocks[0], 0, sh0);
+    if (P.nblocks > 0) stage_halo(blk[0], 0, sh0);
     __syncthreads();
   }
 
@@ -159,10 +161,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
   constexpr int NIV = C / 64;
   constexpr int OTS = (C / 32) * 128;                        // uint4 per o-tile (8 K steps)
   const int ct = wave & 3, fq = wave >> 2;                   // depthwise: channel tile of the interval, frame-tile lane
-  BlockDesc bdn = P.blocks[0];
+  BlockDesc bdn = blk[0];
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = bdn;
-    bdn = P.blocks[min(bi + 1, P.nblocks - 1)];               // requested a block ahead of its first use
+    bdn = blk[min(bi + 1, P.nblocks - 1)];
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
     F16Frag a0[1], a1[1];
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
 #pragma unroll
       for (int r = 0; r < 4; ++r) hmax = fmaxf(hmax, fabsf(v[r]));
     }
-    amax_publish(amax_cells + 4 + 2 * bi, hmax);
+    amax_publish(amax_cells + 3 + bi, hmax);
     __syncthreads();                                         // the new tile's exact maximum sets the planes' new scale
     float inv_unused;
     const float sh_new = pow2_scale(h_amax(bi + 1), &inv_unused);

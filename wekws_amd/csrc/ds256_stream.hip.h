@@ -56,8 +56,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 
   // ---- block floating point (conv_stack_f16.hip.h): maximum of the chunk's features now, of the carried cache when
   //      its registers are committed to LDS below
-  __shared__ unsigned amax_cells[kAmaxCells];
-  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
+  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
 
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     f.l = __builtin_bit_cast(f16x8, q[64]);
   };
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const BlockDesc bd = P.blocks[bi];
+    const BlockDesc bd = blk[bi];
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
     const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     for (int s4 = 0; s4 < 4; ++s4) ldfrag(af[s4], ap1 + s4 * 128);   // K steps 0..3, in flight over the producer
     // operand scale of this block (same rule and same numbers as the batch kernel: bit-identical results)
     float c1;
-    const float sa = pow2_scale(fmaf(bd.dw_alpha, fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1)), bd.dw_beta), &c1);
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)), bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
 
     // ---- producer: lane-group pg makes channels pg, pg + 64, pg + 128, pg + 192; lane tl = frame tau of the chunk
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (tl + 16 * k < pad) crow[tl + 16 * k] = nv[k];
-      o = fmaxf(o, 0.f) * sa;
+      o = fmaxf(o, 0.f);
       _Float16 h, l;
-      split16(o, h, l);
+      split16s(o, sa, h, l);
       char* const plane = slab + (c >> 5) * 2 * PB;          // K step c / 32
       _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
       _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
       *hp = v;
       hmax = fmaxf(hmax, fabsf(v));
     }
-    amax_publish(amax_cells + 4 + 2 * bi, hmax);
+    amax_publish(amax_cells + 3 + bi, hmax);
     __syncthreads();
   }
 

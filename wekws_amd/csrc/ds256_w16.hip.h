@@ -75,8 +75,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   f32x4 acc[1][NT];
 
   // ---- block floating point (conv_stack_f16.hip.h): maxima of the feature tile and of the incoming cache
-  __shared__ unsigned amax_cells[kAmaxCells];
-  if (tid < kAmaxCells) amax_cells[tid] = 0u;
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
+  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
   if constexpr (HAS_CACHE)
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   constexpr int NIV = C / 64;                                // K intervals per layer
   constexpr int OTS = (C / 32) * 128;                        // uint4 per o-tile (8 K steps)
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const BlockDesc bd = P.blocks[bi];
+    const BlockDesc bd = blk[bi];
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
     const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
     //      by the epilogue that wrote it) and of the incoming cache
     float c1;
-    const float au = HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + 2 * bi), amax_read(amax_cells + 1))
-                               : amax_read(amax_cells + 2 + 2 * bi);
+    const float au = HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1))
+                               : amax_read(amax_cells + 2 + bi);
     const float sa = pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
 
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           float o = dww[KS];
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
-          o = fmaxf(o, 0.f) * sa;
+          o = fmaxf(o, 0.f);
           const int t = fbase + m * d;
           _Float16 h, l;
-          split16(o, h, l);
+          split16s(o, sa, h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -233,9 +235,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           float o = dww[KS];
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
-          o = fmaxf(o, 0.f) * sa;
+          o = fmaxf(o, 0.f);
           _Float16 h, l;
-          split16(o, h, l);
+          split16s(o, sa, h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
         hmax = fmaxf(hmax, fabsf(v));
       }
     }
-    amax_publish(amax_cells + 4 + 2 * bi, hmax);             // = the input tile of block bi + 1
+    amax_publish(amax_cells + 3 + bi, hmax);             // = the input tile of block bi + 1
     __syncthreads();
   }
 

@@ -42,7 +42,7 @@ constexpr int kFsmnMaxLayers = 16;
 constexpr int kFsmnHeldK = 5;       // layers with <= this many k-steps keep a whole o-tile pair of weights in registers
 constexpr int kFsmnMaxTaps = 32;
 constexpr int kFsmnTileFrames = 64;
-constexpr int kFsmnLdsLimit = 160 * 1024 - 1024;   // (the maxima cells are static LDS beside the dynamic tile)
+constexpr int kFsmnLdsLimit = 160 * 1024 - 2048;   // (the maxima cells are static LDS beside the dynamic tile)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte store that only needs dword alignment
@@ -71,9 +71,9 @@ struct FsmnLayer {
   float taps_l1;   // largest 1-norm of a channel's tap vector
 };
 
-// LDS cells of one utterance (maxima handed from phase to phase): [0] features, [1] incoming cache, [2 + l] the linear
-// planes entering layer l (l = nlayers: entering out_linear1)
-constexpr int kFsmnCells = 4 + kFsmnMaxLayers;
+// LDS cells of one utterance (maxima handed from phase to phase): [0] features, [1] incoming cache, [2 + l] the
+// linear planes entering layer l (l = nlayers: entering out_linear1)
+constexpr int kFsmnCells = 3 + kFsmnMaxLayers;
 
 struct FsmnParams {
   const float* w;
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
 
   // ---- block floating point: per-utterance maxima cells; scales of the planes being read (cin: what undoes them and
   //      the matrix scale) and written (sout); running maxima of what an epilogue writes (mtrk)
-  __shared__ unsigned cells[U * kFsmnCells];
-  for (int e = tid; e < U * kFsmnCells; e += kFsmnThreads) cells[e] = 0u;
+  __shared__ AmaxCell cells[U * kFsmnCells];
+  amax_zero<kFsmnThreads>(cells, U * kFsmnCells);
   __syncthreads();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
@@ -286,6 +286,12 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
     const int KO = P.kin / 8;
     const int plb = P.kin * TT * 2;
     const bool xvec = (P.idim % 4 == 0) && (A.xs_b % 4 == 0) && (reinterpret_cast<uintptr_t>(A.x) % 16 == 0);
+    float sxu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float inv_unused;
+      sxu[u] = pow2_scale(amax_read(cells + u * kFsmnCells), &inv_unused);
+    }
     // item = (k-octet, frame); 8 consecutive lanes take 8 consecutive frames of one octet (conflict-free LDS rows),
     // the next lane bit walks the octets (32-byte neighbours in memory)
     for (int e = tid; e < KO * TT; e += kFsmnThreads) {
@@ -307,8 +313,9 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
             if (k0 + i < P.idim) xv[i] = xr[i];
         }
       }
-      float inv_unused;
-      const float sxl = pow2_scale(amax_read_v(cells + u * kFsmnCells), &inv_unused);
+      float sxl = sxu[0];
+#pragma unroll
+      for (int q = 1; q < U; ++q) sxl = (u == q) ? sxu[q] : sxl;
       f16x8 vh, vl;
       split16x8(xv * sxl, vh, vl);
       char* d = r0 + (koct * TT + f) * 16;

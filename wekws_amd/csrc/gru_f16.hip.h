@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 
   // bound of layer l's hidden state over this stream tile: max(1, max|h0[l]|) -- h(t) is a convex combination of a tanh
   // and h(t-1).  Called by all threads (it holds a barrier); the same number in every pass / launch that needs it.
-  __shared__ unsigned gru_cells[kGruMaxLayers + 1];
-  if (tid <= kGruMaxLayers) gru_cells[tid] = 0u;
+  __shared__ AmaxCell gru_cells[kGruMaxLayers];
+  amax_zero<kThreads>(gru_cells, kGruMaxLayers);
   __syncthreads();
   auto h_bound = [&](int l) __attribute__((always_inline)) -> float {
     float m = 0.f;
@@ -197,12 +197,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
             for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xc[ks][nn][j]));
         }
-      ax = row16_max(ax);
-      {
-        const int axi = __float_as_int(ax);
-        ax = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(axi, 0)), __int_as_float(__builtin_amdgcn_readlane(axi, 16))),
-                   fmaxf(__int_as_float(__builtin_amdgcn_readlane(axi, 32)), __int_as_float(__builtin_amdgcn_readlane(axi, 48))));
-      }
+      ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
       float cx, inv_s0;
       const float sx = pow2_scale(ax, &cx);
       const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);

@@ -46,21 +46,27 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   const int pg = tid >> 4, tl = tid & 15;                    // producer: 64 lane-groups x 16 lanes; group = channel
   const int wu = wave >> 3, ot = (wave >> 1) & 3, fh = wave & 1;
   const int ft0 = fh * 4;                                    // first frame tile of this wave
-  const int ntw = NT - ft0 < NTW ? (NT - ft0 < 0 ? 0 : NT - ft0) : NTW;
+  const bool uok = (b0 + wu) < A.B;
+  // frame tiles this wave owns; none if its utterance is past the batch end (odd B, B = 1): such waves, like the second
+  // frame half at NT < 5, only keep the barriers company -- no weight loads, no MFMAs, no epilogues (at B = 1 that
+  // leaves 4 of 16 waves pulling fragments through the CU's 64 B/clk path)
+  const int ntw = !uok ? 0 : NT - ft0 < NTW ? (NT - ft0 < 0 ? 0 : NT - ft0) : NTW;
+  const bool active = ntw > 0;
   const int o0 = ot * 16 + lq * 4;                           // this lane's 4 output channels
   char* const slab_u = slab + wu * UB;
   float* const h_w = hbuf + wu * C * SS;
   const int frag_off = (lq * TT + ft0 * 16 + l15) * 16;      // B item of this wave's first tile, K step 0
-  const bool uok = (b0 + wu) < A.B;
 
   f32x4 acc[NTW], zsum[NTW];
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) zsum[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- block floating point (conv_stack_f16.hip.h): per-utterance maxima of the features and of the incoming cache
-  __shared__ unsigned amax_cells[U * kAmaxCells];
-  unsigned* const cells_w = amax_cells + wu * kAmaxCells;
-  if (tid < U * kAmaxCells) amax_cells[tid] = 0u;
+  __shared__ AmaxCell amax_cells[U * kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  AmaxCell* const cells_w = amax_cells + wu * kAmaxCells;
+  amax_zero<kW16Threads>(amax_cells, U * kAmaxCells);
+  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
@@ -87,10 +93,16 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     // visible to the producers: the preprocessing below ends with a barrier
   }
 
-  auto gemm = [&](const uint4* ap) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes of slab_u
-    F16Frag a[2];
+  // weight fragments of one GEMM (2 K steps, hi | lo)
+  auto load_frags = [](F16Frag (&a)[2], const uint4* __restrict__ ap) __attribute__((always_inline)) {
     a[0].h = __builtin_bit_cast(f16x8, ap[0]);   a[0].l = __builtin_bit_cast(f16x8, ap[64]);
     a[1].h = __builtin_bit_cast(f16x8, ap[128]); a[1].l = __builtin_bit_cast(f16x8, ap[192]);
+  };
+  // Short tiles (streaming steps): a block is a chain of dependent phases and every exposed trip to L2 is block time, so
+  // BOTH GEMMs' fragments are requested at the top of the block and arrive behind the depthwise producer (32 registers,
+  // free at NT <= 2); long tiles load them at the GEMM, where seven tiles of MFMAs cover the latency.
+  constexpr bool kPrefetchW = NT <= 2;
+  auto gemm = [&](const F16Frag (&a)[2]) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes of slab_u
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -119,6 +131,9 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the planes of an utterance)
       const int steps = min(2, nk - k0);
       __syncthreads();                                       // (first pass: the feature maxima are published)
+      float sxu[U], inv_unused;                              // feature scale of each utterance
+#pragma unroll
+      for (int u = 0; u < U; ++u) sxu[u] = pow2_scale(amax_read(amax_cells + u * kAmaxCells), &inv_unused);
       for (int e = tid; e < U * steps * 4 * TT; e += kW16Threads) {   // item = (utt, step, k-octet, frame)
         const int t = e % TT;
         int q = e / TT;
@@ -127,8 +142,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         const int kf = (k0 + st) * 32 + oct * 8;
         const bool ok = (b0 + u) < A.B && t < T;
         const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
-        float inv_unused;
-        const float sx = pow2_scale(amax_read_v(amax_cells + u * kAmaxCells), &inv_unused);
+        const float sx = u ? sxu[1] : sxu[0];
         f16x8 vh, vl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 
   // ======================================= residual blocks =======================================
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const BlockDesc bd = P.blocks[bi];
+    const BlockDesc bd = blk[bi];
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(ot) * 256 + lane;
     const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + size_t(ot) * 256 + lane;
@@ -195,6 +209,13 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     }
     const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (in flight over the producer)
     const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
+    F16Frag g1[2], g2[2];
+    if constexpr (kPrefetchW) {
+      if (active) {
+        load_frags(g1, ap1);
+        load_frags(g2, ap2);
+      }
+    }
     const bool slide = d <= 16 && (16 % d) == 0;
     const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
     // operand scales of the depthwise rows, per utterance (bound through the maxima of the input tile and the cache)
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + 2 * bi), amax_read(amax_cells + u * kAmaxCells + 1));
+      const float au = fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + bi), amax_read(amax_cells + u * kAmaxCells + 1));
       const float ba = fmaf(bd.dw_alpha, au, bd.dw_beta);
       float inv;
       sa[u] = pow2_scale(ba, &inv);
@@ -212,7 +233,6 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         c2 *= bd.inv_s2;
       }
     }
-
     // ---- producer: lane-group pg makes channel pg of both utterances: depthwise dilated conv + folded BN
     //      (mdtc.py:55-58, no ReLU), split to fp16 hi/lo planes, and hands the channel's streaming cache over
 #pragma unroll
@@ -220,6 +240,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       const int c = pg;
       const int hoff = (u * C + c) * SS;
       const bool pok = (b0 + u) < A.B;
+      if (!pok) continue;                                    // (workgroup-uniform: no such utterance)
       const int64_t gbase = (int64_t(pok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
 #define fetch(idx_)                                                                      \
   ({                                                                                     \
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
           const int t = fbase + m * d;
           _Float16 h, l;
-          split16(o * sa[u], h, l);
+          split16s(o, sa[u], h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #pragma unroll
           for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
           _Float16 h, l;
-          split16(o * sa[u], h, l);
+          split16s(o, sa[u], h, l);
           ph[t * 8] = h;
           if constexpr (SPLIT) pl[t * 8] = l;
         }
@@ -299,7 +320,8 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     }
     __syncthreads();
     // ---- GEMM 1 (pointwise) over the full K
-    gemm(ap1);
+    if constexpr (!kPrefetchW) { if (active) load_frags(g1, ap1); }
+    if (active) gemm(g1);
     __syncthreads();                                         // every wave is done reading the depthwise planes
     // ---- mid = ReLU(BN1(pointwise)) written in operand order over them (mdtc.py:113-114)
 #pragma unroll
@@ -315,7 +337,8 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       }
     __syncthreads();
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), in place into h
-    gemm(ap2);
+    if constexpr (!kPrefetchW) { if (active) load_frags(g2, ap2); }
+    if (active) gemm(g2);
     float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -330,9 +353,10 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           hmax = fmaxf(hmax, v);
         }
       }
-    amax_publish(cells_w + 4 + 2 * bi, hmax);                // = the input tile of block bi + 1
+    amax_publish(cells_w + 3 + bi, hmax);                    // = the input tile of block bi + 1
     __syncthreads();
   }
+
 
   // the backbone output is the sum of the stack outputs (mdtc.py:270-273)
 #pragma unroll
@@ -343,7 +367,6 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       for (int r = 0; r < 4; ++r) h_w[(o0 + r) * SS + t] = zsum[tt][r];
     }
   __syncthreads();
-  (void)uok;
   if constexpr (LCACHE) {
     if (A.out_cache) {
       const int n4 = (C * Pc) >> 2, tot = min(U, A.B - b0) * n4;

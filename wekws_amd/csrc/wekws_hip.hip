@@ -54,7 +54,7 @@ int fail(int code, const char* fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.  Zero / non-finite bound: s = 1.
+// s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.
 // (host twin of pow2_scale in conv_stack_f16.hip.h)
 inline float pow2_scale_host(float bound, float* inv) {
   uint32_t bits;
@@ -62,7 +62,6 @@ inline float pow2_scale_host(float bound, float* inv) {
   const uint32_t e = (bits >> 23) & 0xffu;
   uint32_t se = 268u - e;
   se = se > 253u ? 253u : se;
-  if (e == 0u || e == 255u) se = 127u;
   const uint32_t sb = se << 23, ib = (254u - se) << 23;
   float s;
   std::memcpy(&s, &sb, 4);

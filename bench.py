@@ -1,29 +1,44 @@
 #!/usr/bin/env python3
-"""Headline benchmark: 1-second utterances/s through the fused DS-TCN forward on MI355X.
+"""Headline benchmark: 1-second utterances/s through the fused DS-TCN forward on MI355X, plus the per-frame streaming
+latency that is the other half of BASELINE.json's metric.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py                                  # 1 GPU, 50 timed steps after 10 warm-up steps
+    python bench.py --gpus N --steps K --warmup W    # N > 1 without a launcher: spawns N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W       # the driver's own launch: one rank per GPU over RCCL
 
-A "step" is one pass of the hot path (KWSModel.forward: 40-d fbank features -> per-frame posteriors +
-streaming cache, exactly what wekws/bin/score.py:125 calls) over one batch of synthetic 1-s utterances
-already resident in HBM.  Workload (BASELINE.json metric / SURVEY.md section 8d): DS-TCN h256 (287,490 params,
-examples/hi_xiaowen/s0/conf/ds_tcn.yaml), B = 1024 utterances per GPU, T = 98 frames, fp32.
-Multi-GPU: utterance-parallel, one process per GPU, weights broadcast once over RCCL, no collective in the
-timed forward (weak scaling: 1024 utterances per GPU).
+A "step" is one pass of the hot path (KWSModel.forward: 40-d fbank features -> per-frame posteriors + streaming cache,
+what wekws/bin/score.py:125 calls) over one batch of synthetic 1-s utterances already resident in HBM.  Workload
+(BASELINE.json metric / SURVEY.md section 8d): DS-TCN h256 (287,490 params, examples/hi_xiaowen/s0/conf/ds_tcn.yaml),
+B = 1024 utterances per GPU, T = 98 frames.  Multi-GPU: utterance-parallel, one process per GPU, the weights broadcast
+once over RCCL, no collective in the timed forward (weak scaling: 1024 utterances per GPU).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (conv_stack_kernel<DS,256,7>): the fused path is compute-bound on the exact-f32
-                matrix pipe (55.09 MFLOP / 16,464 B per utterance = 3,346 FLOP/B >> machine balance 20), so the
-                binding roofline is the 157.3 TFLOP/s f32 MFMA peak; achieved = algorithmic FLOPs per launch /
-                mean kernel time measured with HIP events on the launch stream.  The HBM-side figures
-                (algorithmic GB/s vs 8 TB/s) are reported next to it as `hbm_*`.
-  cpu_baseline  the numpy oracle (oracle/kws_oracle.py, a port of the reference forward) timed on this box's
-                host cores on a bounded sample of the same workload.
+Timing: W warm-up steps, then EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides, wall clock, MAX
+over ranks -> `value`, `ms_per_step`.  Every step also sits between two HIP events on the launch stream: their
+median / p10 / p90 is `step_ms` and the kernel time the roofline uses.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields:
+  roofline        dominant kernel of `value` (default precision: ds256_w16_kernel, 3 x fp16 MFMA per MAC on block-floating
+                  hi/lo operands, so the peak for ALGORITHMIC flops is 2500 / 3 TF).  `kernel` and `traffic` (HBM bytes per
+                  launch from rocprofv3 PMC passes) are reported only when profiles/r02_pmc_traffic.json was taken with
+                  the very library file this run loads (sha-256 match) on this workload -- else omitted.
+  f32             the same batch with precision F32 (exact-f32 MFMA kernel: each product rounded once, the reference's
+                  own arithmetic), with its own roofline against the 157.3 TF f32 matrix peak.
+  latency         streaming, 10-frame chunks with the carried cache (stream_kws_ctc.py:482-514, keyword_spotting.cc:56-95):
+                  us per frame, median / p10 / p90 over 1000 chunks, for GRU 2x128 (BASELINE config 3), DS-TCN h256 and
+                  MDTC h64 at 1 and 256 concurrent streams; `cpu` = the reference's PyTorch CPU operators on the same
+                  chunks (oracle/torch_ref.py), B = 1.
+  rooflines_other ds256_stream_kernel at 4096 streams (HBM-bound by construction: the cache round trip) and fbank_kernel.
+  also / score_only   MDTC h64 on the same batch; the DS-TCN batch with the cache hand-over dropped (score.py:125).
+  cpu_baseline    the reference's CPU path (PyTorch CPU operator sequence, oracle/torch_ref.py) on this box's host cores:
+                  B = 1024 batches with all cores, with one core, and with the best thread count of a short sweep.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,26 +47,162 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832}  # BASELINE.md section 2 (2 FLOP per MAC, T=98)
-BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4                          # features in + posteriors out = 16,464 B
-PEAK_F32_TFLOPS = 157.3                                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
-PEAK_F16_TFLOPS = 2500.0                                           # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832, "gru_2x128": 39_588_864}  # SURVEY.md 8d (T = 98)
+BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4          # features in + posteriors out = 16,464 B
+CACHE_BYTES_PER_UTT = 256 * 105 * 4                # the (256, 105) streaming cache forward() also returns
+PEAK_F32_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_F16_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfg, sd, T, idim, target_s=12.0):
-    """The reference's CPU path on this box's host cores, bounded to ~target_s of work: oracle/torch_ref.py issues
-    the ATen CPU operator sequence of the reference's PyTorch forward (the reference tree itself does not travel to
-    the GPU box); torch's intra-op thread pool = all cores it chooses to use, reported as `cores`."""
+def pct(ts):
+    return {"median": round(float(np.median(ts)), 4), "p10": round(float(np.percentile(ts, 10)), 4),
+            "p90": round(float(np.percentile(ts, 90)), 4)}
+
+
+def lib_sha16():
+    from wekws_amd import _capi
+    try:
+        with open(_capi.lib_path(), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def build_model(torch, init_model, pack, synth, name, dev, precision="default", seed=1234):
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), seed)
+    m = init_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return cfg, sd, m.to(dev).eval().set_precision(precision).freeze()
+
+
+def time_steps(torch, fn, steps, warmup):
+    """`steps` launches, each between two HIP events on the current stream -> per-step ms (list)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def mfma_roofline(model_name, B, kern_ms, precision):
+    flop = FLOP_PER_UTT[model_name] * B
+    ach = flop / (kern_ms * 1e-3) / 1e12
+    if precision == "f32":
+        peak, note = PEAK_F32_TFLOPS, "exact-f32 MFMA peak (v_mfma_f32_16x16x4_f32 issues at the vector-f32 rate)"
+    elif precision == "f16":
+        peak, note = PEAK_F16_TFLOPS, "dense fp16 MFMA peak, one product per MAC"
+    else:
+        peak, note = PEAK_F16_TFLOPS / 3.0, ("algorithmic flops vs dense fp16 MFMA peak 2500 TF / 3 products per MAC; "
+                                             "executed MFMA rate = 3 x achieved")
+    hbm = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "peak_note": note, "kernel_ms": round(kern_ms, 4), "flop_per_launch": flop,
+            "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
+            "algorithmic_bytes_per_launch": BYTES_PER_UTT * B,
+            "algorithmic_bytes_per_launch_with_cache_out": (BYTES_PER_UTT + CACHE_BYTES_PER_UTT) * B,
+            "hbm_achieved_GBs": round(hbm, 2), "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": round(hbm / PEAK_HBM_GBS, 6)}
+
+
+def attach_profile(roof, model_name, B, precision):
+    """`kernel` / `traffic` from the committed PMC passes -- only if they were taken on the library file loaded now."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        rec = pm.get(f"{model_name}/B{B}/{precision}")
+        if rec and pm.get("lib_sha16") and pm["lib_sha16"] == lib_sha16():
+            roof["kernel"] = rec["kernel"]
+            roof["traffic"] = rec["traffic_bytes_per_launch"]
+            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)"
+            roof["traffic_source"] = pm.get("profile")
+            roof["kernel_avg_ms_rocprof"] = rec.get("kernel_avg_ms")
+            return
+    except Exception:
+        pass
+    roof["traffic"] = None
+    roof["traffic_note"] = "no PMC profile of this library build under profiles/ (see tools/pmc.sh)"
+
+
+def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_only=False, precision="default"):
+    cfg, _, m = build_model(torch, init_model, pack, synth, name, dev, precision)
+    x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=7)).to(dev)
+    fn = (lambda: m.posteriors(x)) if score_only else (lambda: m(x))
+    ts = time_steps(torch, fn, steps, 5)
+    what = "posteriors only (out_cache = NULL)" if score_only else "forward"
+    med = float(np.median(ts))
+    return {"workload": f"{name} {what}, {B} x 1-s utterances, T={T}", "value": round(B / med * 1e3, 1),
+            "unit": "utts/s", "step_ms": pct(ts), "steps": steps, "precision": precision}
+
+
+def stream_latency(torch, init_model, pack, synth, dev, name, B, chunk=10, n=1000):
+    """n consecutive chunks of one set of streams with the carried cache; every chunk between two HIP events."""
+    cfg, _, m = build_model(torch, init_model, pack, synth, name, dev)
+    x = torch.from_numpy(synth.synth_feats(B, chunk, cfg["input_dim"], seed=3)).to(dev)
+    y, c = m(x)
+    for _ in range(50):
+        y, c = m(x, c)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        y, c = m(x, c)
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    ts = [a.elapsed_time(b) * 1e3 / chunk for a, b in ev]            # us per frame, GPU side
+    out = {"streams": B, "chunks": n}
+    out.update({k: round(v, 3) for k, v in pct(ts).items()})
+    out["wall_us_per_frame"] = round(wall * 1e6 / chunk, 3)           # host launch path included
+    return out
+
+
+def cpu_stream_latency(cfg, sd, chunk=10, n=200):
+    """The reference's CPU operators on the same 10-frame chunks, B = 1 (200 chunks, median)."""
     import torch
     from oracle import torch_ref
     from wekws_amd.utils import synth
-    nb = 128
-    x = torch.from_numpy(synth.synth_feats(nb, T, idim, seed=0))
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    x = torch.from_numpy(synth.synth_feats(1, chunk, cfg["input_dim"], seed=3))
+    avail = torch.get_num_threads()
+    best = None
+    for th in (1, 4, 16):
+        if th > avail:
+            continue
+        torch.set_num_threads(th)
+        y, c = torch_ref.forward(cfg, tsd, x)
+        for _ in range(10):
+            y, c = torch_ref.forward(cfg, tsd, x, c)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            y, c = torch_ref.forward(cfg, tsd, x, c)
+            ts.append((time.perf_counter() - t0) * 1e6 / chunk)
+        med = float(np.median(ts))
+        if best is None or med < best["median"]:
+            best = {"median": round(med, 2), "p10": round(float(np.percentile(ts, 10)), 2),
+                    "p90": round(float(np.percentile(ts, 90)), 2), "threads": th, "chunks": n}
+    torch.set_num_threads(avail)
+    return best
+
+
+def cpu_baseline(cfg, sd, T, idim):
+    """The reference's CPU path on this box's host cores, bounded to ~25 s: oracle/torch_ref.py issues the
+    ATen CPU operator sequence of the reference's PyTorch forward (the reference tree does not travel to the GPU box)."""
+    import torch
+    from oracle import torch_ref
+    from wekws_amd.utils import synth
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     avail = torch.get_num_threads()
+    ncpu = os.cpu_count() or avail
 
-    def rate(budget_s, cap):
+    def rate(nb, budget_s, cap):
+        x = torch.from_numpy(synth.synth_feats(nb, T, idim, seed=0))
         torch_ref.forward(cfg, tsd, x)  # warm-up
         t0, n = time.perf_counter(), 0
         while True:
@@ -61,43 +212,43 @@ def cpu_baseline(cfg, sd, T, idim, target_s=12.0):
             if el > budget_s or n >= cap:
                 return n, el
 
-    # PyTorch's default (one thread per hardware thread) is not its best on a many-core host for convolutions this
-    # small: give the baseline its best thread count (short sweep), then time the bounded sample with it
+    rows = {}
+    torch.set_num_threads(avail)                              # all cores torch uses by default, B = 1024 batches
+    n, el = rate(1024, 4.0, 10 * 1024)
+    rows["all_cores"] = {"threads": int(avail), "batch": 1024, "utts_per_s": round(n / el, 1), "sample_s": round(el, 1)}
+    torch.set_num_threads(1)                                  # one core
+    n, el = rate(128, 4.0, 1024)
+    rows["one_core"] = {"threads": 1, "batch": 128, "utts_per_s": round(n / el, 1), "sample_s": round(el, 1)}
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= avail}):
         torch.set_num_threads(th)
-        n, el = rate(1.5, 4096)
+        n, el = rate(1024, 1.5, 4096)
         sweep[th] = round(n / el, 1)
-    cores = max(sweep, key=sweep.get)
+    cores = max(sweep, key=sweep.get) if sweep else avail
     torch.set_num_threads(cores)
-    n, el = rate(target_s, 65536)
+    n, el = rate(1024, 10.0, 64 * 1024)
     torch.set_num_threads(avail)
     return {"value": round(n / el, 1), "unit": "utts/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} utterances (batches of {nb}, T={T}) through oracle/torch_ref.py -- the reference's PyTorch "
-                      f"CPU operator sequence (F.linear / conv1d / batch_norm, fp32) -- in {el:.1f} s; threads chosen "
-                      f"by a sweep (utts/s by thread count: {sweep}) of {avail} available"}
+            "sample": f"{n} utterances (batches of 1024, T={T}) through oracle/torch_ref.py -- the reference's PyTorch CPU "
+                      f"operator sequence (F.linear / conv1d / batch_norm, fp32) -- in {el:.1f} s with {cores} threads, "
+                      f"the best of a sweep {sweep}; host has {ncpu} hardware threads",
+            "rows": rows}
 
 
-def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_only=False):
-    """Untimed-by-the-contract extra line: another recipe on the same batch shape, same timing method.
-    score_only: the posteriors without the returned cache (score.py:125 drops it) -- KWSModel.posteriors."""
-    cfg = dict(synth.MODEL_CONFIGS[name])
-    m = init_model(cfg)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
-    m = m.to(dev).eval().freeze()
-    x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=7)).to(dev)
-    fn = m.posteriors if score_only else m
-    for _ in range(5):
-        fn(x)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn(x)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    what = "posteriors only (out_cache = NULL)" if score_only else "forward"
-    return {"workload": f"{name} {what}, {B} x 1-s utterances, T={T}", "value": round(B * steps / el, 1),
-            "unit": "utts/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
+def self_launch(args):
+    """--gpus N without a launcher: spawn the N ranks ourselves (what the driver's torch.distributed.run line does)."""
+    import torch
+    if not os.environ.get("WEKWS_BENCH_STUB") and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -108,21 +259,27 @@ def main():
     ap.add_argument("--model", default="ds_tcn_h256")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract fields + roofline")
     ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3", "f16"],
-                    help="matrix arithmetic of the conv backbones (enum wekws_hip_precision); default = f16x3 "
-                         "(meets the 1e-4 bar); f16 = one fp16 product per term, ~1e-3, BASELINE config 5's mode")
+                    help="matrix arithmetic of `value` (enum wekws_hip_precision); default = f16x3 with block floating "
+                         "point (fp32-level accuracy at any operand scale); the f32 number is always reported beside it")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     from wekws_amd import pack, parallel
-    from wekws_amd.model.kws_model import init_model
     from wekws_amd.utils import synth
 
-    rank, world, local = parallel.init_distributed()
+    stub = bool(os.environ.get("WEKWS_BENCH_STUB"))   # test hook for the launcher plumbing only (tests/test_dist.py):
+    rank, world, local = parallel.init_distributed("gloo" if stub else None)   # gloo ranks on CPU, forward stubbed
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if stub:
+        return stub_run(args, torch, dist, parallel, rank, world)
+    from wekws_amd.model.kws_model import init_model
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -132,12 +289,13 @@ def main():
     T, idim, B = 98, cfg["input_dim"], args.batch
     model = init_model(cfg)
     sd = None
-    if rank == 0:  # only rank 0 "loads the checkpoint"; the others receive the folded blob over RCCL
+    if rank == 0:  # only rank 0 "loads the checkpoint"; the others receive the weights over RCCL
         sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval().set_precision(args.precision)
     parallel.broadcast_weights(model, src=0, device=dev)
     model.freeze()
+    prec = {"default": "f16x3"}.get(args.precision, args.precision)
 
     x = torch.from_numpy(synth.synth_feats(B, T, idim, seed=100 + rank)).to(dev)
     for _ in range(args.warmup):
@@ -157,7 +315,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    step_ms = [a.elapsed_time(b) for a, b in ev]              # HIP events on the launch stream
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -165,66 +323,117 @@ def main():
     assert torch.isfinite(y).all()
 
     if rank == 0:
-        total_utts = B * world * args.steps
-        value = total_utts / elapsed
-        flop = FLOP_PER_UTT.get(args.model)
-        launch_flop = flop * B if flop else None
-        ach_tf = launch_flop / (kern_ms * 1e-3) / 1e12 if flop else None
-        hbm_gbs = BYTES_PER_UTT * B / (kern_ms * 1e-3) / 1e9
-        f16x3 = args.precision != "f32"
-        plain = args.precision == "f16"
-        kname = ("ds256_w16_kernel<NT=7, HAS_CACHE=false, SPLIT=%s>" % ("false" if plain else "true")) if f16x3 else "conv_stack_kernel<KIND_DS, C=256, NT=7, KS=8>"
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
-            # the timed process); ignored unless it was taken on the kernel this run dispatches
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            want = "ds256_w16_kernel<7" if f16x3 else "conv_stack_kernel<0, 256, 7"
-            if args.model == "ds_tcn_h256" and B == 1024 and want in pm["kernel"] and not plain:
-                traffic, traffic_src = pm["traffic_bytes_per_launch"], pm["profile"]
-        except Exception:
-            pass
-        # Matrix-pipe roofline of the dominant kernel.  f32 mode: exact-f32 MFMA, peak 157.3 TF.  f16x3 mode: every
-        # algorithmic MAC costs three fp16 MFMA MACs, so the peak for ALGORITHMIC flops is 2500 / 3 = 833 TF.
-        peak = PEAK_F16_TFLOPS if plain else PEAK_F16_TFLOPS / 3.0 if f16x3 else PEAK_F32_TFLOPS
+        value = B * world * args.steps / elapsed
         out = {
-            "metric": "1-sec utterances/sec (40-d fbank -> DS-TCN posteriors), whole job",
+            "metric": "1-sec utterances/sec (40-d fbank -> DS-TCN posteriors), whole job; per-frame streaming latency in `latency`",
             "value": round(value, 1), "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 in/out/accumulate; fp16 operands into one MFMA per product (reduced precision, ~1e-3)" if plain
-                     else "f32 in/out/accumulate; matrix products as 3 x fp16 MFMA on hi/lo-split operands (fp32-level accuracy)"
-                     if f16x3 else "f32",
+            "dtype": {"f32": "f32 (exact-f32 MFMA)",
+                      "f16": "f32 in/out/accumulate; fp16 operands, one MFMA per product (reduced precision, ~1e-3)"}.get(
+                          prec, "f32 in/out/accumulate; products as 3 x fp16 MFMA on block-floating hi/lo-split operands "
+                                "(fp32-level accuracy at any operand scale)"),
             "data": "synthetic",
-            "config": {"workload": f"{args.model} (DS-TCN 4x256, k=8, 287,490 params) forward, {B} x 1-s utterances "
-                                   f"per GPU, T=98 frames x 40-d fbank in HBM -> (B,98,2) sigmoid posteriors + "
-                                   f"(B,256,105) streaming cache",
-                       "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": "f16" if plain else "f16x3" if f16x3 else "f32",
+            "config": {"workload": f"{args.model} forward, {B} x 1-s utterances per GPU, T=98 frames x {idim}-d fbank in "
+                                   f"HBM -> (B,98,{cfg['output_dim']}) posteriors + the streaming cache",
+                       "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": prec,
                        "parallelism": f"utterance-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": round(ach_tf, 3) if ach_tf else None, "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach_tf / peak, 4) if ach_tf else None, "traffic": traffic,
-                         "peak_note": "dense fp16 MFMA peak" if plain else
-                                      ("algorithmic flops vs dense fp16 MFMA peak 2500 TF / 3 products per MAC; "
-                                       "executed MFMA rate = 3 x achieved") if f16x3 else "exact-f32 MFMA peak",
-                         "frac_of_f32_mfma_peak": round(ach_tf / PEAK_F32_TFLOPS, 4) if ach_tf else None,
-                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch_with_cache_out": (BYTES_PER_UTT + 256 * 105 * 4) * B,
-                         "kernel_ms": round(kern_ms, 4), "flop_per_launch": launch_flop,
-                         "hbm_achieved_GBs": round(hbm_gbs, 2), "hbm_peak_GBs": PEAK_HBM_GBS,
-                         "hbm_frac": round(hbm_gbs / PEAK_HBM_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_UTT * B},
+            "step_ms": pct(step_ms),
         }
-        if world == 1 and args.model == "ds_tcn_h256":
+        if args.model in FLOP_PER_UTT:
+            roof = mfma_roofline(args.model, B, float(np.median(step_ms)), prec)
+            attach_profile(roof, args.model, B, prec)
+            out["roofline"] = roof
+        extras = world == 1 and args.model == "ds_tcn_h256" and not args.no_extras
+        if extras:
+            if prec != "f32":        # the same batch at the reference's own arithmetic
+                ts = time_steps(torch, lambda m=build_model(torch, init_model, pack, synth, args.model, dev, "f32")[2]: m(x), 30, 5)
+                med = float(np.median(ts))
+                roof32 = mfma_roofline(args.model, B, med, "f32")
+                attach_profile(roof32, args.model, B, "f32")
+                out["f32"] = {"workload": out["config"]["workload"], "precision": "f32", "value": round(B / med * 1e3, 1),
+                              "unit": "utts/s", "step_ms": pct(ts), "steps": 30, "roofline": roof32}
             # BASELINE.json configs[1] words the single-GPU case as "MDTC ... batch 1024 x 1 s" while its metric names
             # the DS-TCN: the DS-TCN is `value`; the MDTC 4x4 h64 recipe on the same batch is reported beside it.
             out["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
-            # the same DS-TCN batch when the caller drops the cache, as wekws/bin/score.py:125 does
             out["score_only"] = secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", B, T, score_only=True)
+            # ---- the other half of the metric: per-frame streaming latency, 10-frame chunks, carried cache
+            lat = {"unit": "us per frame (10-frame chunks; median / p10 / p90 over 1000 consecutive chunks, HIP events)"}
+            for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
+                lat[name] = {f"B{b}": stream_latency(torch, init_model, pack, synth, dev, name, b) for b in (1, 256)}
+            out["latency"] = lat
+            # ---- HBM-bound kernels
+            other = []
+            Bs = 4096
+            cfgs, _, ms = build_model(torch, init_model, pack, synth, "ds_tcn_h256", dev)
+            xs = torch.from_numpy(synth.synth_feats(Bs, 10, 40, seed=3)).to(dev)
+            _, cs = ms(xs)
+            state = {"c": cs}
+
+            def step_stream():
+                _, state["c"] = ms(xs, state["c"])
+            ts = time_steps(torch, step_stream, 50, 10)
+            by = Bs * (2 * CACHE_BYTES_PER_UTT + 10 * 40 * 4 + 10 * 2 * 4)
+            med = float(np.median(ts))
+            other.append({"kernel": "ds256_stream_kernel", "workload": f"{Bs} DS-TCN h256 streams x one 10-frame chunk (cache in + out)",
+                          "bound": "hbm", "algorithmic_bytes_per_launch": by, "achieved": round(by / (med * 1e-3) / 1e9, 1),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / (med * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "step_ms": pct(ts), "stream_chunks_per_s": round(Bs / med * 1e3, 1)})
+            from wekws_amd.frontend import Fbank
+            fb = Fbank(num_bins=40, device=dev)
+            pcm = torch.from_numpy(synth.synth_pcm(1024, 16000, seed=0, kind="noise")).to(dev)
+            ts = time_steps(torch, lambda: fb(pcm), 50, 10)
+            by = 1024 * (16000 * 4 + 98 * 40 * 4)
+            med = float(np.median(ts))
+            other.append({"kernel": "fbank_kernel", "workload": "1024 x 1 s of 16 kHz PCM (f32) -> (1024, 98, 40) log-mel",
+                          "bound": "hbm", "algorithmic_bytes_per_launch": by, "achieved": round(by / (med * 1e-3) / 1e9, 1),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / (med * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "step_ms": pct(ts), "utts_per_s": round(1024 / med * 1e3, 1),
+                          "note": "instruction-bound radix-4 FFT + mel slots (~2.6 MFLOP per utterance), not HBM-bound"})
+            out["rooflines_other"] = other
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim)
+            if extras:
+                for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
+                    c2 = dict(synth.MODEL_CONFIGS[name])
+                    out["latency"][name]["cpu"] = cpu_stream_latency(c2, synth.synth_state_dict(pack.model_spec(c2), 1234))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stub_run(args, torch, dist, parallel, rank, world):
+    """WEKWS_BENCH_STUB=1: the multi-rank plumbing of this file on CPU ranks (gloo) with the forward replaced by a
+    sleep -- rendezvous, weight broadcast, barrier-bracketed timing, MAX over ranks, one line from rank 0.  Measures
+    nothing; exists so that the CPU suite can run `bench.py --gpus 2` end to end."""
+    from wekws_amd import pack
+    from wekws_amd.model.kws_model import init_model
+    from wekws_amd.utils import synth
+    cfg = dict(synth.MODEL_CONFIGS["mdtc_small"])
+    model = init_model(cfg)
+    if rank == 0:
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
+    parallel.broadcast_weights(model, src=0, device=torch.device("cpu"))
+    wsum = float(np.abs(model.packed()[1].astype(np.float64)).sum())
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))                       # rank 1 is slower: the line must carry the MAX
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ws = torch.tensor([wsum], dtype=torch.float64)
+    dist.all_reduce(ws, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(args.batch * world * args.steps / float(tt.item()), 1),
+                          "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(tt.item()) / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "launcher plumbing test (forward stubbed)"},
+                          "weights_identical_on_all_ranks": abs(float(ws.item()) - wsum) < 1e-9}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

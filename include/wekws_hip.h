@@ -256,6 +256,34 @@ int wekws_hip_dct_lifter(const float* logmel, int64_t rows, int num_bins, int nu
 int wekws_hip_softmax_topk(const float* logits, int64_t rows, int K, int k, float* probs, int32_t* idx,
                            void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * DET scoring  --  replaces the arithmetic of wekws/bin/compute_det.py:79-106 on the score lists that
+ * wekws/bin/score.py:128-137 writes (one per utterance and keyword: the per-frame posteriors scores[b][0:len][k]),
+ * so that an evaluation loop moves B*K maxima (+ B*n_thr counts) to the host instead of the (B, T, K) matrix.
+ * Bit-exact: comparisons only.
+ * ------------------------------------------------------------------------------------------*/
+/*
+ * Max pooling over time  --  compute_det.py:82-85 `score = max(score_list)` (a keyword utterance is a false reject at
+ * threshold th iff max < th).
+ *   scores     (B, T, K) device float32 (posteriors of wekws_hip_forward, per-frame heads)
+ *   lengths    (B) device int32 valid frames per utterance (score.py:131 `logits[i][:feats_lengths[i]]`), clamped to
+ *              [0, T]; NULL = T for every utterance
+ *   max_out    (B, K) device float32; -inf for an empty utterance
+ *   argmax_out (B, K) device int32 first frame that attains the maximum (list.index(max(list))), -1 if empty; or NULL
+ */
+int wekws_hip_score_maxpool(const float* scores, int B, int T, int K, const int32_t* lengths, float* max_out,
+                            int32_t* argmax_out, void* stream);
+/*
+ * False-alarm counts of filler utterances  --  compute_det.py:88-96: per utterance and threshold,
+ *   i = 0; while i < len: if score[i] >= th: n += 1; i += window_shift  else: i += 1
+ *   keyword      column of `scores` (0 <= keyword < K)
+ *   thresholds   (n_thr) device float64, the exact doubles the reference's `threshold += step` loop visits
+ *   alarms       (B, n_thr) device int32
+ * Scores are widened to double for the comparison, as Python does with the parsed floats.
+ */
+int wekws_hip_det_false_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                               const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

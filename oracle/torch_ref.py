@@ -6,8 +6,10 @@ torch does -- so for the `cpu_baseline` leg of bench.py this module issues the s
 the same shapes as the reference modules would (functional form, weights taken from a reference-named state_dict):
 the time it measures is the reference's CPU kernel time, which the numpy oracle's is not.
 
-Conv backbones with a per-frame linear head (the benchmarked recipes: DS-TCN, TCN, MDTC), empty input cache only.
-Pinned like the numpy oracle: tests/test_oracle.py runs it over the live-reference goldens of those recipes.
+Conv backbones with a per-frame linear head (the benchmarked recipes: DS-TCN, TCN, MDTC) and the GRU (torch.nn.GRU, the
+very module the reference builds: kws_model.py:128-133), one-shot or streaming with a carried cache (bench.py's CPU
+per-frame latency).  Pinned like the numpy oracle: tests/test_oracle.py runs it over the live-reference goldens of those
+recipes, streaming traces included.
 Only tests/ and bench.py's cpu_baseline may import it.
 """
 import torch
@@ -19,27 +21,52 @@ def _bn(x, sd, p):                       # nn.BatchNorm1d, eval (tcn.py:81,108,1
                         False, 0.0, 1e-5)
 
 
-def _left_pad(x, pad):                   # Block.forward with an empty cache: F.pad (tcn.py:49-51 ; mdtc.py:108-110)
-    return F.pad(x, (pad, 0), "constant", 0.0)
+def _left_ctx(x, pad, cache, off):       # Block.forward: F.pad with an empty cache, else cat (tcn.py:49-52 ; mdtc.py:108-111)
+    if cache is None:
+        return F.pad(x, (pad, 0), "constant", 0.0)
+    return torch.cat((cache[:, :, off:off + pad], x), dim=2)
+
+
+_GRU_CACHE = {}
+
+
+def _gru(cfg, sd, hdim):
+    """torch.nn.GRU(hdim, hdim, num_layers, batch_first=True) carrying the state_dict's backbone.* tensors."""
+    key = (id(sd), hdim, cfg["backbone"]["num_layers"])
+    if key not in _GRU_CACHE:
+        g = torch.nn.GRU(hdim, hdim, num_layers=cfg["backbone"]["num_layers"], batch_first=True)
+        g.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+        _GRU_CACHE.clear()
+        _GRU_CACHE[key] = g.eval()
+    return _GRU_CACHE[key]
 
 
 @torch.no_grad()
-def forward(cfg, sd, x):
-    """cfg: configs['model']; sd: {name: torch.Tensor}; x: (B, T, idim) float32 CPU tensor -> (y, out_cache)."""
+def forward(cfg, sd, x, in_cache=None):
+    """cfg: configs['model']; sd: {name: torch.Tensor}; x: (B, T, idim) float32 CPU tensor; in_cache: None (the
+    reference's empty-cache call) or the carried cache -> (y, out_cache)."""
     if "global_cmvn.mean" in sd:                                             # cmvn.py:45-48
         x = x - sd["global_cmvn.mean"]
         if cfg.get("cmvn", {}).get("norm_var", True):
             x = x * sd["global_cmvn.istd"]
     h = F.relu(F.linear(x, sd["preprocessing.out.0.weight"], sd["preprocessing.out.0.bias"]))   # subsampling.py:53-57
-    h = h.transpose(1, 2)                                                    # tcn.py:153 ; mdtc.py:249
     bb = cfg["backbone"]
+    if bb["type"] == "gru":                                                  # kws_model.py:128-133, forward :70-74
+        out, hn = _gru(cfg, sd, h.size(2))(h) if in_cache is None else _gru(cfg, sd, h.size(2))(h, in_cache)
+        y = F.linear(out, sd["classifier.linear.weight"], sd["classifier.linear.bias"])
+        if "classifier" not in cfg and cfg.get("activation", {}).get("type") != "identity":
+            y = torch.sigmoid(y)
+        return y, hn
+    h = h.transpose(1, 2)                                                    # tcn.py:153 ; mdtc.py:249
     caches = []
+    off = 0
     if bb["type"] == "tcn":
         k, C = bb.get("kernel_size", 8), h.size(1)
         for i in range(bb["num_layers"]):                                    # tcn.py:155-163
             d = 2 ** i
             pad = (k - 1) * d
-            u = _left_pad(h, pad)
+            u = _left_ctx(h, pad, in_cache, off)
+            off += pad
             caches.append(u[:, :, -pad:])
             p = "backbone.network.%d.cnn." % i
             if bb.get("ds", False):                                          # tcn.py:101-114
@@ -54,8 +81,10 @@ def forward(cfg, sd, x):
         k, C = bb["kernel_size"], h.size(1)
 
         def block(h, p, d):                                                  # mdtc.py:95-121, 55-59
+            nonlocal off
             pad = (k - 1) * d
-            u = _left_pad(h, pad)
+            u = _left_ctx(h, pad, in_cache, off)
+            off += pad
             caches.append(u[:, :, -pad:])
             a = F.conv1d(u, sd[p + "conv1.conv.weight"], sd[p + "conv1.conv.bias"], dilation=d, groups=C)
             a = _bn(a, sd, p + "conv1.bn")

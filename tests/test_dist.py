@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the utterance-parallel plumbing used by bench.py --gpus N -- contiguous
-sharding, the one-time broadcast of the folded weight blob from the rank that holds the checkpoint, and the
+sharding, the one-time broadcast of the weights from the rank that holds the checkpoint, and the
 optional score gather.  (The forward itself has no collective.)"""
 import os
 import socket
@@ -43,7 +43,11 @@ def _worker(rank, world, port, q):
         sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     parallel.broadcast_weights(model, src=0, device=torch.device("cpu"))
-    blob = model._packed_blob
+    blob = model.packed()[1]     # every rank now holds rank 0's tensors in its module and packs them itself
+    # a checkpoint loaded AFTER the broadcast must win (a broadcast blob used to shadow it for ever)
+    sd2 = synth.synth_state_dict(pack.model_spec(cfg), 99)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    assert np.array_equal(model.packed()[1], pack.pack(cfg, sd2)[1])
     # shard a global batch and "score" it with a stand-in (the HIP forward needs a GPU): gather must restore order
     lo, hi = parallel.shard_range(11, rank, world)
     y_local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, 3, 2)
@@ -70,3 +74,42 @@ def test_two_rank_weight_broadcast_and_gather():
     for rank, s, n, y in res:
         assert n == want.size and abs(s - float(np.abs(want.astype(np.float64)).sum())) < 1e-9
     assert res[0][3] == [float(i) for i in range(11)] and res[1][3] is None
+
+
+def test_load_packed_is_superseded_by_later_weight_changes():
+    """load_packed() installs a folded blob; load_state_dict or an in-place edit afterwards must be honoured, and
+    packed() must describe what is actually running."""
+    cfg = synth.MODEL_CONFIGS["ds_tcn_h64"]
+    m = init_model(cfg)
+    _, blob_a = pack.pack(cfg, synth.synth_state_dict(pack.model_spec(cfg), 5))
+    m.load_packed(blob_a)
+    assert np.array_equal(m.packed()[1], blob_a)
+    sd_b = synth.synth_state_dict(pack.model_spec(cfg), 6)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_b.items()})
+    assert np.array_equal(m.packed()[1], pack.pack(cfg, sd_b)[1])
+    m.load_packed(blob_a)
+    with torch.no_grad():
+        m.classifier.linear.bias.add_(1.0)       # in-place edit after load_packed: the module's tensors win again
+    assert not np.array_equal(m.packed()[1], blob_a)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher must spawn the two ranks itself (what the driver's own
+    torch.distributed.run line does) and print ONE line with n_gpus = 2 and the MAX-over-ranks time.  CPU ranks over gloo
+    with the forward stubbed (WEKWS_BENCH_STUB: the launcher / rendezvous / broadcast / timing plumbing is what is under
+    test; the GPU path of the same file runs on the GPU box)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WEKWS_BENCH_STUB="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["weights_identical_on_all_ranks"]
+    assert out["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: the line carries the slowest rank

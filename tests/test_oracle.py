@@ -72,3 +72,30 @@ def test_oracle_matches_scale_sweep_golden(case, scale_golden):
     gy = scale_golden[name + "/y"]
     assert y.shape == gy.shape
     assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+
+
+TORCH_REF_STREAM = [c for c in CASES if c.get("chunks") and not c.get("softmax")
+                    and c["model"] in ("ds_tcn_h256", "ds_tcn_h64", "tcn_h64", "mdtc_h64", "mdtc_small", "gru_2x128")]
+
+
+@pytest.mark.parametrize("case", TORCH_REF_STREAM, ids=[c["name"] for c in TORCH_REF_STREAM])
+def test_torch_cpu_restatement_streams_like_the_reference(case, golden):
+    """oracle/torch_ref.py with a carried cache (bench.py's CPU per-frame-latency baseline) against the streaming traces
+    recorded from the live reference, GRU included."""
+    import torch
+    from oracle import torch_ref
+    cfg, sd = case_weights(case)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    x = torch.from_numpy(case_input(case))
+    c0 = case_in_cache(case, cfg)
+    cache = None if c0 is None else torch.from_numpy(c0)
+    ys, t = [], 0
+    for n in case["chunks"]:
+        y, cache = torch_ref.forward(cfg, tsd, x[:, t:t + n], cache)
+        ys.append(y)
+        t += n
+    y = torch.cat(ys, dim=1).numpy()
+    gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
+    assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+    c = cache.numpy() if cfg["backbone"]["type"] == "gru" else cache.numpy()[:1]
+    assert max_abs(c, gc) <= CACHE_TOL * max(1.0, float(np.abs(gc).max()))

@@ -46,6 +46,9 @@ SIGNATURES = {
     "wekws_hip_splice_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "wekws_hip_dct_lifter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "wekws_hip_softmax_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wekws_hip_score_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wekws_hip_det_false_alarms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p]),
     "wekws_hip_splice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
 }

@@ -291,12 +291,18 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #define GRU_PUT(BUF)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < IT; ++i)                                                         \
       *reinterpret_cast<gru_u32x4*>((BUF) + (i * kThreads + tid) * 16) = stage[i];
+      // 1 / scale of each step's input planes, a chunk ahead like the planes themselves (layer 0: per step, from pass P)
+      float scur[CS], snext[CS];
+#pragma unroll
+      for (int dt = 0; dt < CS; ++dt) scur[dt] = l == 0 ? sc[min(tb + dt, T - 1)] : inv_in;
       GRU_FETCH(tb)
       GRU_PUT(gru16_lds)
       __syncthreads();
       for (int t0 = tb, c = 0; t0 < te; t0 += CS, ++c) {
         const char* cur = gru16_lds + (c & 1) * CHUNK;
         GRU_FETCH(t0 + CS)                                   // clamped to the last step: harmless past the end
+#pragma unroll
+        for (int dt = 0; dt < CS; ++dt) snext[dt] = l == 0 ? sc[min(t0 + CS + dt, T - 1)] : inv_in;
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) {
           const int t = t0 + dt;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
                 for (int g = 0; g < 3; ++g) gru_mfma1(acc[g][nn], wi[g][ks], bh, bl);
               }
             float* go = gi + size_t(t) * G::GI_STEP;
-            const float cin = (l == 0 ? sc[t] : inv_in) * Q.ih_inv_s[l];
+            const float cin = scur[dt] * Q.ih_inv_s[l];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -326,6 +332,8 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
           }
         }
         GRU_PUT(gru16_lds + ((c + 1) & 1) * CHUNK)
+#pragma unroll
+        for (int dt = 0; dt < CS; ++dt) scur[dt] = snext[dt];
         __syncthreads();
       }
 #undef GRU_FETCH

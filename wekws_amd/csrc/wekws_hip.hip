@@ -29,6 +29,7 @@
 #include "mfcc.hip.h"
 #include "splice.hip.h"
 #include "topk.hip.h"
+#include "det.hip.h"
 
 namespace {
 
@@ -954,6 +955,31 @@ int wekws_hip_softmax_topk(const float* logits, int64_t rows, int K, int k, floa
   if ((rows + 3) / 4 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "softmax_topk: too many rows for one launch");
   const int rc = wekws::launch_softmax_topk(logits, rows, K, k, probs, idx, static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "softmax_topk launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+// --------------------------------------------- DET scoring ---------------------------------------------
+int wekws_hip_score_maxpool(const float* scores, int B, int T, int K, const int32_t* lengths, float* max_out,
+                            int32_t* argmax_out, void* stream_) {
+  if (!scores || !max_out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || T <= 0 || K <= 0) return fail(WEKWS_HIP_EINVAL, "B=%d T=%d K=%d", B, T, K);
+  if (B == 0) return WEKWS_HIP_OK;
+  if ((int64_t(B) * K + 3) / 4 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "score_maxpool: too many rows for one launch");
+  const int rc = wekws::launch_det_maxpool(scores, B, T, K, lengths, max_out, argmax_out, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "det_maxpool launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+int wekws_hip_det_false_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                               const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream_) {
+  if (!scores || !thresholds || !alarms) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || T <= 0 || K <= 0 || keyword < 0 || keyword >= K || n_thr <= 0 || window_shift <= 0)
+    return fail(WEKWS_HIP_EINVAL, "B=%d T=%d K=%d keyword=%d n_thr=%d window_shift=%d", B, T, K, keyword, n_thr, window_shift);
+  if (B == 0) return WEKWS_HIP_OK;
+  if ((int64_t(B) * n_thr + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "det_false_alarms: too many items for one launch");
+  const int rc = wekws::launch_det_alarms(scores, B, T, K, keyword, lengths, thresholds, n_thr, window_shift, alarms,
+                                          static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "det_alarm launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }
 

@@ -107,6 +107,8 @@ class KWSModel(nn.Module):
         self._handle_key = None
         self._tlist = None
         self._frozen = False
+        self._packed_blob = None
+        self._packed_versions = None
 
     # ------------------------------------------------------------------ weights -> device library
     def _apply(self, fn, *args, **kwargs):
@@ -121,6 +123,7 @@ class KWSModel(nn.Module):
         self._frozen = False
         self._tlist = None
         self._handle = None
+        self._packed_blob = None          # a blob installed by load_packed() is superseded by the new tensors
         return super().load_state_dict(*args, **kwargs)
 
     def freeze(self) -> "KWSModel":
@@ -146,10 +149,20 @@ class KWSModel(nn.Module):
         if blob.size != pack.blob_elems(desc):
             raise ValueError(f"blob has {blob.size} floats, config needs {pack.blob_elems(desc)}")
         self._packed_blob = blob
+        self._packed_versions = self._versions()   # in-place edits of the module's tensors after this point supersede it
         self._handle = None
         self._frozen = False
 
+    def _versions(self):
+        if self._tlist is None:
+            self._tlist = list(self.state_dict(keep_vars=True).values())
+        return tuple(t._version for t in self._tlist)
+
     def _get_handle(self, device: torch.device) -> _HipHandle:
+        if getattr(self, "_packed_blob", None) is not None and not self._frozen and \
+                self._versions() != self._packed_versions:
+            self._packed_blob = None      # the module's own weights were modified after load_packed(): they win
+            self._handle = None
         if getattr(self, "_packed_blob", None) is not None:
             if self._handle is None or self._handle_key != ("packed", device.index):
                 desc = {k: int(self._d[k]) for k in pack.DESC_FIELDS}
@@ -180,6 +193,8 @@ class KWSModel(nn.Module):
     def packed(self) -> Tuple[dict, np.ndarray]:
         """(descriptor, folded float32 blob) -- what wekws_hip_create consumes; used by the multi-GPU
         weight broadcast (wekws_amd/parallel.py) and the model-file writer."""
+        if getattr(self, "_packed_blob", None) is not None and self._versions() == self._packed_versions:
+            return {k: int(self._d[k]) for k in pack.DESC_FIELDS}, self._packed_blob     # what is actually running
         sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
         return pack.pack(self._cfg, sd)
 

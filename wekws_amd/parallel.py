@@ -5,7 +5,7 @@ collective is DDP's gradient all-reduce in training (wekws/bin/train.py:190-195)
 utterances / streams have no cross term anywhere in the forward (eval BatchNorm is per-channel affine,
 GlobalClassifier's mean is within an utterance), so the batch axis is split contiguously across ranks
 and each rank holds a full (<1.2 MB) weight replica.  The only communication is ONE broadcast of the
-folded weight blob from the rank that loaded the checkpoint -- RCCL over xGMI when the backend is
+weights from the rank that loaded the checkpoint -- RCCL over xGMI when the backend is
 "nccl", gloo in the CPU tests -- plus an optional gather of the scores for a single consumer.
 """
 from __future__ import annotations
@@ -61,13 +61,29 @@ def broadcast_blob(blob: Optional[np.ndarray], n_elems: int, src: int = 0,
 
 
 def broadcast_weights(model, src: int = 0, device: Optional[torch.device] = None) -> None:
-    """Rank `src` folds + packs its weights; every rank (src included) then runs from that blob."""
-    from wekws_amd import pack
-    desc = {k: int(model._d[k]) for k in pack.DESC_FIELDS}
-    n = pack.blob_elems(desc)
-    is_src = (not dist.is_initialized()) or dist.get_rank() == src
-    blob = model.packed()[1] if is_src else None
-    model.load_packed(broadcast_blob(blob, n, src, device))
+    """Every rank ends up holding rank `src`'s weights IN ITS MODULE (parameters and buffers, reference names), so that
+    state_dict() / save_checkpoint / a later load_state_dict behave the same on every rank; each rank then folds and
+    packs locally (deterministic, identical blobs).  One broadcast of the flattened float tensors (< 1.2 MB for every
+    recipe) -- RCCL over xGMI when the backend is nccl; integer bookkeeping buffers (num_batches_tracked) are not
+    inference state and stay local."""
+    tensors = [t for t in model.state_dict(keep_vars=True).values() if t.is_floating_point()]
+    n = sum(int(t.numel()) for t in tensors)
+    if not dist.is_initialized() or dist.get_world_size() == 1 or n == 0:
+        return
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_rank() == src:
+        flat = torch.cat([t.detach().reshape(-1).to(device=device, dtype=torch.float32) for t in tensors])
+    else:
+        flat = torch.empty(n, dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src)
+    if dist.get_rank() != src:
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                k = int(t.numel())
+                t.copy_(flat[off:off + k].reshape(t.shape).to(dtype=t.dtype))     # in place: bumps the version -> re-pack
+                off += k
 
 
 def gather_scores(y_local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:

@@ -15,8 +15,10 @@
  *   - plain C, no torch / STL types; all tensors are caller-owned DEVICE pointers (float32,
  *     contiguous unless a stride is given); the library owns only its device copy of the
  *     weights and scratch workspaces (one per model and calling stream, grown on demand).
- *   - every call is asynchronous on the hipStream_t passed as `void* stream` (NULL = default
- *     stream); no hidden synchronisation.
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (NULL = the default stream of the
+ *     object's device); no hidden synchronisation except when a scratch buffer has to grow (wekws_hip_reserve).
+ *   - an object lives on the device it was created for; calls make that device current for their duration and
+ *     restore the caller's current device before returning.
  *   - return value: 0 on success, a negative WEKWS_HIP_E* code on failure; the message is
  *     available from wekws_hip_last_error() (thread-local).  Nothing throws across the ABI.
  *   - a model is immutable after create: wekws_hip_forward is re-entrant across streams as
@@ -79,9 +81,14 @@ enum wekws_hip_activation {
  * opt-in reduced-precision mode of BASELINE.json's "fp16 weights + fp16 MFMA pointwise conv" configuration. */
 enum wekws_hip_precision {
   WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 */
-  WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32 math */
-  WEKWS_HIP_PRECISION_F16X3 = 2,   /* operands split into fp16 hi + lo, three fp16 matrix products per term (fp32-level
-                                      accuracy, ~5x the matrix rate); needs |activation| < 65504 */
+  WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32
+                                      math (conv backbones, GRU; FSMN has the F16X3 kernel only and serves this request
+                                      with it) */
+  WEKWS_HIP_PRECISION_F16X3 = 2,   /* operands split into fp16 hi + lo, three fp16 matrix products per term, with BLOCK
+                                      FLOATING POINT: every weight matrix and every operand tile carries an exact
+                                      power-of-two scale chosen from its magnitude, so the accuracy is fp32-level (~2^-22
+                                      of the tile maximum) at ANY operand scale -- no overflow at 65504, no loss below
+                                      fp16's normal range (csrc/conv_stack_f16.hip.h); ~5x the f32 matrix rate */
   WEKWS_HIP_PRECISION_F16 = 3      /* weights and activations rounded to fp16 where they enter a pointwise-conv / input
                                       Linear product, ONE matrix product per term, fp32 accumulate; depthwise taps,
                                       biases, residuals and the classifier stay fp32.  Posterior error vs the fp32
@@ -171,6 +178,34 @@ size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B);
 size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T);
 
 /*
+ * Kernel selection.  A model picks its kernels from its shape (DESIGN.md 3.1 "which kernel runs"); these options override
+ * the choice -- for A/B measurements and for the tests that keep every kernel family parity-green.  They change speed,
+ * never results beyond rounding (all families meet the same parity bar).  No environment variable is read anywhere.
+ */
+enum wekws_hip_option {
+  WEKWS_HIP_OPT_W16 = 0,        /* DS-TCN hidden 256: 1 (default) the 16-wave kernel, 0 the generic 8-wave kernel */
+  WEKWS_HIP_OPT_MDTC16 = 1,     /* MDTC hidden 64: 1 (default) the 16-wave kernel, 0 the generic 8-wave kernel */
+  WEKWS_HIP_OPT_STREAM = 2,     /* chunks of <= 16 frames: 1 (default) the kernels with the LDS-resident cache, 0 the batch kernels */
+  WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
+  WEKWS_HIP_OPT_HEAD_SLICES = 4 /* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
+};
+int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
+
+/*
+ * Scratch memory.  Inputs longer than one LDS tile (WEKWS_HIP_TILE_FRAMES frames; FSMN: 64) and every GRU call take
+ * scratch from a grow-only buffer owned by (model, stream).  Growing it allocates, and frees the previous buffer behind
+ * ONE synchronisation of that stream -- the only synchronisation the library ever performs on a caller's stream.  To keep
+ * calls free of it (latency-critical loops; required before capturing a stream into a HIP graph, where a call that
+ * would have to grow fails with WEKWS_HIP_EINVAL instead), size the buffer up front:
+ *   wekws_hip_workspace_bytes  bytes a forward of (B, T) needs (0: none)
+ *   wekws_hip_reserve          make the stream's buffer at least that large now
+ *   wekws_hip_release          free the stream's buffer (e.g. before destroying the stream)
+ */
+size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T);
+int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream);
+int wekws_hip_release(wekws_hip_model* m, void* stream);
+
+/*
  * Replaces: KWSModel.forward(x, in_cache) -> (y, out_cache)   (kws_model.py:65-76) and the body
  * of KeywordSpotting::Forward (keyword_spotting.cc:63-94, one ORT Run with the carried cache).
  *   x          (B, T, idim) device, contiguous
@@ -196,7 +231,7 @@ enum wekws_hip_window {
 typedef struct wekws_hip_fbank_cfg {
   int32_t num_bins;     /* 40 (or 80) */
   int32_t sample_rate;  /* 16000 */
-  int32_t frame_length; /* samples, 400 */
+  int32_t frame_length; /* samples, 400; 257..512 (one 512-point FFT per frame, fbank.h:43; else EUNSUPPORTED) */
   int32_t frame_shift;  /* samples, 160 */
   int32_t window;       /* enum wekws_hip_window */
   int32_t reserved[3];
@@ -215,6 +250,15 @@ int wekws_hip_fbank_num_frames(const wekws_hip_fbank* f, int nsamp);
  */
 int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsamp, float* feats,
                             void* stream);
+/*
+ * The same extractor on int16 PCM in device memory  --  the input of
+ * FeaturePipeline::AcceptWaveform(const std::vector<int16_t>&) (feature_pipeline.cc:49-55): samples are widened to float
+ * in registers (no /32768), so a caller that owns int16 audio uploads and reads 2 bytes per sample.  Bit-identical
+ * features to wekws_hip_fbank_compute on the widened samples.
+ *   pcm    (B, nsamp) device int16
+ */
+int wekws_hip_fbank_compute_i16(wekws_hip_fbank* f, const int16_t* pcm, int B, int nsamp, float* feats,
+                                void* stream);
 
 /*
  * Context expansion + frame skip  --  replaces context_expansion / frame_skip of the data pipeline

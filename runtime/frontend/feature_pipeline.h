@@ -29,7 +29,10 @@ struct FeaturePipelineConfig {
 
 class FeaturePipeline {
  public:
-  explicit FeaturePipeline(const FeaturePipelineConfig& config);
+  // device / stream: where the extractor runs (the reference's class has neither: CPU); stream = a hipStream_t, nullptr =
+  // the device's default stream.  Uploads, the kernel and the read-back are issued on it; AcceptWaveform returns after
+  // the frames have reached the host queue, like the reference's.
+  explicit FeaturePipeline(const FeaturePipelineConfig& config, int device = 0, void* stream = nullptr);
   ~FeaturePipeline();
   FeaturePipeline(const FeaturePipeline&) = delete;
   FeaturePipeline& operator=(const FeaturePipeline&) = delete;
@@ -49,11 +52,16 @@ class FeaturePipeline {
 
  private:
   const FeaturePipelineConfig config_;
+  void Extract(const void* host_pcm, size_t bytes_per_sample, int n);   // upload + fbank + frames into the queue
   wekws_hip_fbank* fbank_ = nullptr;
-  float* d_pcm_ = nullptr;
+  const int device_;
+  void* const stream_;
+  void* d_pcm_ = nullptr;                // float or int16 samples, as pushed
   float* d_feats_ = nullptr;
-  size_t cap_samples_ = 0, cap_frames_ = 0;
-  std::vector<float> remained_wav_;
+  size_t cap_pcm_bytes_ = 0, cap_frames_ = 0;
+  std::vector<float> remained_wav_;      // leftover samples (feature_pipeline.cc:41-44); int16 values are exact in float
+  bool remained_integral_ = true;        // every leftover sample came from an int16 push -> the next int16 push can
+                                         // upload 2 bytes per sample
   int num_frames_ = 0;
   bool input_finished_ = false;
   mutable std::mutex mutex_;

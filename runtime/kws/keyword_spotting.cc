@@ -14,7 +14,8 @@
 namespace wekws {
 
 
-KeywordSpotting::KeywordSpotting(const std::string& model_path) {
+KeywordSpotting::KeywordSpotting(const std::string& model_path, int device, void* stream)
+    : device_(device), stream_(stream) {
   // model_path: what the reference's constructor takes (the exporter's .onnx / an ORT-format .ort,
   // keyword_spotting.cc:28-45) or a packed file of wekws_amd.bin.export_packed -- kws/model_file.h
   wekws_hip_desc desc;
@@ -24,8 +25,9 @@ KeywordSpotting::KeywordSpotting(const std::string& model_path) {
   } catch (const std::exception& e) {
     WEKWS_CHECK(false) << e.what();
   }
-  WEKWS_CHECK(wekws_hip_create(&desc, blob.data(), blob.size(), /*device=*/0, &model_) == WEKWS_HIP_OK)
+  WEKWS_CHECK(wekws_hip_create(&desc, blob.data(), blob.size(), device_, &model_) == WEKWS_HIP_OK)
       << wekws_hip_last_error();
+  WEKWS_CHECK(hipSetDevice(device_) == hipSuccess);
   WEKWS_CHECK(desc.head == WEKWS_HIP_HEAD_LINEAR || desc.head == WEKWS_HIP_HEAD_IDENTITY)
       << "the streaming runtime needs a per-frame head";
   idim_ = desc.idim;
@@ -35,6 +37,7 @@ KeywordSpotting::KeywordSpotting(const std::string& model_path) {
 }
 
 KeywordSpotting::~KeywordSpotting() {
+  (void)hipSetDevice(device_);
   if (d_x_) (void)hipFree(d_x_);
   if (d_y_) (void)hipFree(d_y_);
   for (float* c : d_cache_) if (c) (void)hipFree(c);
@@ -45,6 +48,7 @@ void KeywordSpotting::Reset() { have_cache_ = false; }
 
 void KeywordSpotting::EnsureCapacity(int frames) {
   if (frames <= cap_frames_) return;
+  (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_));   // (nothing of ours is in flight: Forward ends with a sync)
   if (d_x_) (void)hipFree(d_x_);
   if (d_y_) (void)hipFree(d_y_);
   WEKWS_CHECK(hipMalloc(reinterpret_cast<void**>(&d_x_), size_t(frames) * idim_ * sizeof(float)) == hipSuccess);
@@ -62,14 +66,17 @@ void KeywordSpotting::Forward(const std::vector<std::vector<float>>& feats, std:
     WEKWS_CHECK(static_cast<int>(feats[t].size()) == idim_) << "frame " << t << " has " << feats[t].size() << " dims";
     std::memcpy(h_x_.data() + size_t(t) * idim_, feats[t].data(), idim_ * sizeof(float));
   }
-  WEKWS_CHECK(hipMemcpyAsync(d_x_, h_x_.data(), h_x_.size() * sizeof(float), hipMemcpyHostToDevice, nullptr) == hipSuccess);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  WEKWS_CHECK(hipSetDevice(device_) == hipSuccess);
+  WEKWS_CHECK(hipMemcpyAsync(d_x_, h_x_.data(), h_x_.size() * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess);
   WEKWS_CHECK(wekws_hip_forward(model_, d_x_, /*B=*/1, T, have_cache_ ? d_cache_[cur_] : nullptr, d_y_,
-                                d_cache_[cur_ ^ 1], /*softmax=*/0, /*stream=*/nullptr) == WEKWS_HIP_OK)
+                                d_cache_[cur_ ^ 1], /*softmax=*/0, stream_) == WEKWS_HIP_OK)
       << wekws_hip_last_error();
   cur_ ^= 1;  // keyword_spotting.cc:82: r_cache becomes the next call's cache
   have_cache_ = true;
   h_y_.resize(size_t(T) * odim_);
-  WEKWS_CHECK(hipMemcpy(h_y_.data(), d_y_, h_y_.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+  WEKWS_CHECK(hipMemcpyAsync(h_y_.data(), d_y_, h_y_.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
+  WEKWS_CHECK(hipStreamSynchronize(st) == hipSuccess);   // the caller reads *prob next (the one sync of a Forward)
   prob->resize(T);  // keyword_spotting.cc:89-94
   for (int t = 0; t < T; ++t) (*prob)[t].assign(h_y_.begin() + size_t(t) * odim_, h_y_.begin() + size_t(t + 1) * odim_);
 }

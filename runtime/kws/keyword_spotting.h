@@ -15,7 +15,10 @@ namespace wekws {
 
 class KeywordSpotting {
  public:
-  explicit KeywordSpotting(const std::string& model_path);
+  // device / stream: the GPU and the hipStream_t (nullptr = the device's default stream) every call of this instance
+  // works on -- the reference's constructor has no such arguments (ORT on CPU); with the defaults the class is
+  // source-compatible with it.  Instances on different streams / devices run concurrently.
+  explicit KeywordSpotting(const std::string& model_path, int device = 0, void* stream = nullptr);
   ~KeywordSpotting();
   KeywordSpotting(const KeywordSpotting&) = delete;
   KeywordSpotting& operator=(const KeywordSpotting&) = delete;
@@ -37,6 +40,8 @@ class KeywordSpotting {
   void EnsureCapacity(int frames);
 
   wekws_hip_model* model_ = nullptr;
+  const int device_;
+  void* const stream_;
   int idim_ = 0, odim_ = 0;
   float* d_x_ = nullptr;
   float* d_y_ = nullptr;

@@ -54,3 +54,23 @@ def test_short_and_empty():
     assert fb(torch.zeros(0, 16000, device="cuda")).shape == (0, 98, 40)
     with pytest.raises(ValueError):
         fb(torch.zeros(2, 16000))
+
+
+def test_int16_input_equals_widened_float_input():
+    """wekws_hip_fbank_compute_i16 (int16 PCM, widened in registers) == wekws_hip_fbank_compute on the same samples as
+    float32, bit for bit -- including an odd sample count (unpaired loads) and the full int16 range."""
+    fb = Fbank(40)
+    for n, kind in ((16000, "noise"), (16000 + 97, "noise"), (16000, "ramp")):
+        pcm = synth.synth_pcm(3, n, seed=7, kind=kind)
+        i16 = np.clip(np.round(pcm), -32768, 32767).astype(np.int16)
+        a = fb(torch.from_numpy(i16.astype(np.float32)).cuda()).cpu().numpy()
+        b = fb(torch.from_numpy(i16).cuda()).cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_short_frames_are_refused():
+    """frame_length <= 256 samples would need the reference's 256-point FFT (fbank.h:43), which is not built: the
+    library says so instead of computing other features."""
+    from wekws_amd import _capi
+    with pytest.raises(_capi.HipLibraryError, match="512-point"):
+        Fbank(40, sample_rate=8000)          # 25 ms at 8 kHz = 200 samples

@@ -177,7 +177,7 @@ def test_forward_stream_is_forward_with_cache():
         assert max_abs(cache.cpu().numpy(), cfull.cpu().numpy()) <= 2e-5 * max(1.0, float(cfull.abs().max()))
 
 
-def test_streaming_kernel_equals_batch_kernel(monkeypatch):
+def test_streaming_kernel_equals_batch_kernel():
     """ds256_stream.hip.h (chunks of <= 16 frames, the stream's cache resident in LDS, coalesced cache I/O) against the
     batch kernel fed the same chunks: same arithmetic in the same order -> bit-identical posteriors and caches.  With
     and without an input cache, T = 1 .. 16, ragged batch sizes, both matrix precisions, several output widths."""
@@ -188,10 +188,8 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
             cfg["output_dim"] = K
         sd = synth.synth_state_dict(packer.model_spec(cfg), 77)
         for prec in ("default", "f16"):
-            monkeypatch.setenv("WEKWS_HIP_STREAM", "0")
-            ref = build(cfg, sd).set_precision(prec)
-            monkeypatch.setenv("WEKWS_HIP_STREAM", "1")
-            got = build(cfg, sd).set_precision(prec)
+            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0)      # the batch kernel fed the same chunks
+            got = build(cfg, sd).set_precision(prec).set_option("stream", 1)
             for B, T in ((5, 10), (3, 16), (2, 1), (300, 7)):
                 x = torch.from_numpy(synth.synth_feats(B, 3 * T, 40, seed=B)).cuda()
                 cr = cg = None
@@ -205,10 +203,8 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(packer.model_spec(cfg), 78)
         for prec in ("default", "f16"):
-            monkeypatch.setenv("WEKWS_HIP_STREAM", "0")
-            ref = build(cfg, sd).set_precision(prec)
-            monkeypatch.setenv("WEKWS_HIP_STREAM", "1")
-            got = build(cfg, sd).set_precision(prec)
+            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0)      # the batch kernel fed the same chunks
+            got = build(cfg, sd).set_precision(prec).set_option("stream", 1)
             for B, T in ((5, 10), (2, 16), (1, 1), (301, 7)):
                 x = torch.from_numpy(synth.synth_feats(B, 3 * T, cfg["input_dim"], seed=B)).cuda()
                 cr = cg = None
@@ -241,18 +237,16 @@ def test_streaming_kernel_equals_batch_kernel(monkeypatch):
         assert max_abs(y, ry) <= POSTERIOR_TOL
 
 
-def test_fsmn_head_slices_equal_single_workgroup(monkeypatch):
+def test_fsmn_head_slices_equal_single_workgroup():
     """Small FSMN-CTC calls split the vocabulary layer over several workgroups per tile (each recomputes the backbone,
     each writes its own o-tiles of y): the same numbers as one workgroup per tile, caches included."""
     from wekws_amd import pack as packer
     for name in ("fsmn_ctc300", "fsmn_ctc"):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(packer.model_spec(cfg), 5)
-        monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", "0")
-        ref = build(cfg, sd)
-        for sl in ("-1", "3", "8"):
-            monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", sl)
-            got = build(cfg, sd)
+        ref = build(cfg, sd).set_option("head_slices", 0)
+        for sl in (-1, 3, 8):
+            got = build(cfg, sd).set_option("head_slices", sl)
             for B, T in ((1, 10), (5, 10), (3, 32), (40, 7)):
                 x = torch.from_numpy(synth.synth_feats(B, 2 * T, cfg["input_dim"], seed=B)).cuda()
                 yr, cr = ref(x[:, :T])
@@ -263,16 +257,14 @@ def test_fsmn_head_slices_equal_single_workgroup(monkeypatch):
                 assert torch.equal(yr, yg) and torch.equal(cr, cg), (name, sl, B, T)
 
 
-def test_ds_tcn_ctc_head_slices_equal_single_workgroup(monkeypatch):
+def test_ds_tcn_ctc_head_slices_equal_single_workgroup():
     """The same split for the DS-TCN CTC recipe's 2599-token head (ds256_mm.hip.h)."""
     from wekws_amd import pack as packer
     cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256_ctc"])
     sd = synth.synth_state_dict(packer.model_spec(cfg), 5)
-    monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", "0")
-    ref = build(cfg, sd)
-    for sl in ("-1", "3", "8"):
-        monkeypatch.setenv("WEKWS_HIP_FSMN_SLICES", sl)
-        got = build(cfg, sd)
+    ref = build(cfg, sd).set_option("head_slices", 0)
+    for sl in (-1, 3, 8):
+        got = build(cfg, sd).set_option("head_slices", sl)
         for B, T in ((1, 10), (5, 16), (2, 98)):
             x = torch.from_numpy(synth.synth_feats(B, T + 10, 40, seed=B)).cuda()
             yr, cr = ref(x[:, :T])
@@ -394,17 +386,14 @@ def test_same_model_on_two_streams():
                 assert torch.equal(y, serial[i][0]) and torch.equal(c, serial[i][1]), name
 
 
-def test_generic_kernels_behind_the_specialised_ones(golden, monkeypatch):
-    """WEKWS_HIP_W16=0 / WEKWS_HIP_MDTC16=0 / WEKWS_HIP_MM=0 route the headline shapes through the generic 8-wave kernel
-    (and CTC heads through the vector-ALU classifier): still the same goldens."""
-    monkeypatch.setenv("WEKWS_HIP_W16", "0")
-    monkeypatch.setenv("WEKWS_HIP_MDTC16", "0")
-    monkeypatch.setenv("WEKWS_HIP_MM", "0")
+def test_generic_kernels_behind_the_specialised_ones(golden):
+    """Options w16 = 0 / mdtc16 = 0 / mm = 0 (wekws_hip_set_option) route the headline shapes through the generic 8-wave
+    kernel (and CTC heads through the vector-ALU classifier): still the same goldens."""
     for case in CASES:
         if case["model"] not in ("ds_tcn_h256", "mdtc_h64", "ds_tcn_h256_ctc300") or case.get("odim"):
             continue
         cfg, sd = case_weights(case)
-        model = build(cfg, sd)
+        model = build(cfg, sd).set_option("w16", 0).set_option("mdtc16", 0).set_option("mm", 0)
         y, cache = run(model, case_input(case), case_in_cache(case, cfg), softmax=case.get("softmax", False),
                        chunks=case.get("chunks"))
         gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
@@ -412,15 +401,14 @@ def test_generic_kernels_behind_the_specialised_ones(golden, monkeypatch):
         assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
 
 
-def test_ds256_matrix_core_depthwise_variant(golden, monkeypatch):
-    """WEKWS_HIP_MM=1 selects the experimental DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores
-    (ds256_mm.hip.h): same goldens, same tolerance, including streaming and carried caches."""
-    monkeypatch.setenv("WEKWS_HIP_MM", "1")
+def test_ds256_matrix_core_depthwise_variant(golden):
+    """Option mm = 1 selects the DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores (ds256_mm.hip.h)
+    for keyword heads too: same goldens, same tolerance, including streaming and carried caches."""
     for case in CASES:
         if case["model"] != "ds_tcn_h256" or case.get("odim"):
             continue
         cfg, sd = case_weights(case)
-        model = build(cfg, sd)                      # the switch is read when the library builds its model
+        model = build(cfg, sd).set_option("mm", 1)
         y, cache = run(model, case_input(case), case_in_cache(case, cfg), chunks=case.get("chunks"))
         gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
         assert max_abs(y, gy) <= tol_for(gy), case["name"]

@@ -16,6 +16,7 @@ from wekws_amd.utils import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KWS_MAIN = os.path.join(ROOT, "runtime", "build", "kws_main")
 MODEL_CONVERT = os.path.join(ROOT, "runtime", "build", "model_convert")
+FP_TEST = os.path.join(ROOT, "runtime", "build", "feature_pipeline_test")
 REF_ORT = "/root/reference/runtime/android/app/src/main/assets/kws.ort"
 
 
@@ -187,3 +188,39 @@ def test_exported_onnx_to_kws_main(tmp_path):
     r2 = subprocess.run([KWS_MAIN, "40", str(chunk), src, wav], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0, r2.stderr
     assert r2.stdout == r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "i16", "mixed"])
+def test_feature_pipeline_uneven_pushes(tmp_path, mode):
+    """SURVEY.md row a21: the framing / leftover rule of FeaturePipeline::AcceptWaveform (feature_pipeline.cc:30-47)
+    through the HIP pipeline under uneven pushes, through the float overload, the int16 overload (int16 upload, widened
+    on the GPU) and a mix of both.  Every push pattern must give the frames of the whole signal -- the goldens recorded
+    from the compiled reference, one of them with the reference itself fed in two pushes -- and the SAME bits whatever
+    the pattern and overload (frames are functions of the same samples)."""
+    from tests.golden.fbank_cases import FBANK_CASES, fbank_input
+    build_runtime()
+    assert os.path.exists(FP_TEST)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "fbank_golden.npz"))
+    first = None
+    for cname, patterns in (("noise_1s_two_pushes", [[16000], [5000, 11000], [1, 399, 160, 161, 7000, 3], [240, 160], [399, 1, 15600]]),
+                            ("noise_ragged_tail", [[16097], [400, 15697], [16096, 1], [777]]),
+                            ("noise_exactly_one_frame", [[400], [399, 1], [1]])):
+        case = [c for c in FBANK_CASES if c["name"] == cname][0]
+        pcm = fbank_input(case)[0]
+        i16 = np.clip(np.round(pcm), -32768, 32767).astype("<i2")
+        assert np.array_equal(i16.astype(np.float32), pcm)          # the synthetic PCM is integral
+        raw = str(tmp_path / (cname + ".raw"))
+        i16.tofile(raw)
+        ref = gold[cname][0]
+        first = None
+        for sizes in patterns:
+            out = str(tmp_path / "o.f32")
+            r = subprocess.run([FP_TEST, "40", mode, raw, out] + [str(v) for v in sizes], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            got = np.fromfile(out, np.float32).reshape(-1, 40)
+            assert got.shape == ref.shape, (cname, sizes, got.shape)
+            assert float(np.abs(got - ref).max()) <= 1e-4, (cname, sizes)
+            if first is None:
+                first = got
+            assert np.array_equal(got, first), (cname, sizes)       # push pattern / overload do not change a bit

@@ -103,15 +103,12 @@ def main():
         print(json.dumps(out[-1]), flush=True)
     # streaming THROUGHPUT with many concurrent streams (10-frame chunks, caches carried): stream-chunks per second;
     # lds_cache = the streaming kernel that keeps each stream's cache in LDS (ds256_stream.hip.h, the default for
-    # chunks of <= 16 frames); False = WEKWS_HIP_STREAM=0, the batch kernel fed the same chunks
+    # chunks of <= 16 frames); False = option stream = 0, the batch kernel fed the same chunks
     if only in "manystreams":
         for mname, B in [("ds_tcn_h256", b) for b in (1, 256, 1024, 4096, 16384)] + [("mdtc_h64", b) for b in (1, 256, 4096)]:
             for packed in (True, False):
-                if packed:
-                    os.environ.pop("WEKWS_HIP_STREAM", None)
-                else:
-                    os.environ["WEKWS_HIP_STREAM"] = "0"
                 cfg, m = build(mname)
+                m.set_option("stream", 1 if packed else 0).freeze()
                 x = torch.from_numpy(synth.synth_feats(B, 10, 40, seed=2)).cuda()
                 _, cache = m(x)
                 state = {"c": cache}
@@ -122,7 +119,6 @@ def main():
                 out.append(dict(kind="manystreams", model=mname, B=B, chunk=10, lds_cache=packed, ms=round(med, 4),
                                 chunks_per_s=round(B / med * 1e3, 1), frames_per_s=round(B * 10 / med * 1e3, 1)))
                 print(json.dumps(out[-1]), flush=True)
-        os.environ.pop("WEKWS_HIP_STREAM", None)
     # end-to-end on the device, PCM resident in HBM: (a) fbank40 -> DS-TCN h256 posteriors; (b) fbank80 -> context
     # expansion(2, 2) / skip 3 -> FSMN-CTC logits -> fused softmax + top-3 (what stream_kws_ctc.py's decoder consumes)
     if only in "e2e":

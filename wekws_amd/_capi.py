@@ -37,12 +37,17 @@ SIGNATURES = {
     "wekws_hip_cache_len": (C.c_int, [C.c_void_p]),
     "wekws_hip_cache_elems": (C.c_size_t, [C.c_void_p, C.c_int]),
     "wekws_hip_output_elems": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "wekws_hip_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "wekws_hip_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "wekws_hip_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "wekws_hip_release": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wekws_hip_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_void_p]),
     "wekws_hip_fbank_create": (C.c_int, [C.POINTER(FbankCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "wekws_hip_fbank_destroy": (None, [C.c_void_p]),
     "wekws_hip_fbank_num_frames": (C.c_int, [C.c_void_p, C.c_int]),
     "wekws_hip_fbank_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wekws_hip_fbank_compute_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wekws_hip_splice_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "wekws_hip_dct_lifter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "wekws_hip_softmax_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -52,6 +57,8 @@ SIGNATURES = {
     "wekws_hip_splice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),
 }
+
+OPTIONS = {"w16": 0, "mdtc16": 1, "stream": 2, "mm": 3, "head_slices": 4}   # enum wekws_hip_option
 
 _lib: Optional[C.CDLL] = None
 

@@ -30,24 +30,33 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 namespace wekws {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is needed once per (kernel, device).  A launcher keeps one static
+// DynLdsGrant: the bytes already granted per device ordinal.  Thread-safe (two racing first calls both set the same
+// attribute, which is idempotent) and correct for a process that drives several GPUs -- a plain `static bool` is neither.
+constexpr int kMaxDevices = 64;
+struct DynLdsGrant {
+  std::atomic<int> bytes[kMaxDevices];
+};
+template <class K>
+inline int grant_dynamic_lds(K kern, int bytes, DynLdsGrant& g) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -3;
+  if (g.bytes[dev].load(std::memory_order_acquire) >= bytes) return 0;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return -3;
+  g.bytes[dev].store(bytes, std::memory_order_release);
+  return 0;
+}
+
 enum : int { KIND_DS = 0, KIND_TCN = 1, KIND_MDTC = 2 };
 enum : int { HEAD_LINEAR = 0, HEAD_GLOBAL = 1, HEAD_LAST = 2, HEAD_IDENTITY = 3 };
-
-// Development-only ablation switch (tools/ablate.sh): 0 = product.  1: no producer in the chunk loop,
-// 2: no MFMAs, 3: neither, 4: no per-chunk barrier; 5-9 = 3 plus: 5 no x staging, 6 no cache write, 7 no head,
-// 8 no block epilogue, 9 all of 5-8.  Results are WRONG for any value but 0.
-#ifndef WEKWS_ABLATE
-#define WEKWS_ABLATE 0
-#endif
-#ifndef WEKWS_SETPRIO
-#define WEKWS_SETPRIO 0
-#endif
 
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;
@@ -153,7 +162,6 @@ template <int OW, int NT, int SS, int NG>
 __device__ __forceinline__ void mfma_groups(f32x4 (&acc)[OW][NT], const float4 (&a)[NG][OW], const float* bl) {
   constexpr int STEPS = NG * 4;
   float b[2][NT];
-  if (WEKWS_SETPRIO) __builtin_amdgcn_s_setprio(WEKWS_SETPRIO);
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) b[0][tt] = bl[tt * 16];
 #pragma unroll
@@ -175,7 +183,6 @@ __device__ __forceinline__ void mfma_groups(f32x4 (&acc)[OW][NT], const float4 (
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (WEKWS_SETPRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // runtime group count (preprocessing GEMM: K = idim rounded up to 16)
@@ -211,8 +218,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
   const int T = A.T;
   const float* __restrict__ W = P.w;
   const int K = P.odim;
-  if (WEKWS_ABLATE == 7 || WEKWS_ABLATE == 9) {
-  } else if (P.head == HEAD_LINEAR) {
+  if (P.head == HEAD_LINEAR) {
     // y[t][k] = act(sum_c Wc[k][c] h[c][t] + bc[k])                         (classifier.py:63-67)
     // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
     const bool staged = K * (C + 1) <= G::S_FLOATS;
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
       const int rows = min(R, P.kpre - k0);
       __syncthreads();
       // slab[u][k][t] = x[b0+u][t][k0+k]  (zero beyond idim / T / B): one frame per wave per step, lanes along k
-      for (int u = 0; u < U && !(WEKWS_ABLATE == 5 || WEKWS_ABLATE == 9); ++u) {
+      for (int u = 0; u < U; ++u) {
         const bool ok = (b0 + u) < A.B;
         const float* xu = A.x + int64_t(b0 + u) * A.xs_b + k0;
         constexpr int FPW = (16 * NT + kWaves - 1) / kWaves;  // frames per wave
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     }                                                                                    \
     fv_;                                                                                 \
   })
-        if (A.out_cache && uok && j0 == 0 && !(WEKWS_ABLATE == 6 || WEKWS_ABLATE == 9)) {
+        if (A.out_cache && uok && j0 == 0) {
           for (int p = tl; p < pad; p += 16) {
             const int src = T + p - pad;  // index into h (negative: still inside the old cache)
             float cv = hbuf[hoff + max(src, 0)];
@@ -543,9 +549,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     // Measured on MI355X (tools/ablate.sh): the f32 MFMA stream and the VALU/LDS producer do NOT overlap on a
     // SIMD even when they come from different waves (time = MFMA + producer, also with the two waves of a SIMD
     // staggered into different phases), so the producer is kept short instead of hidden.
-    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
-    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
-    constexpr bool kBarrier = WEKWS_ABLATE != 4;
     zero_acc(acc);
     produce(0, 0);
     load_dw(1);
@@ -555,18 +558,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     // are UNCONDITIONAL (chunk index clamped): a branch around a load makes the compiler's s_waitcnt placement
     // fall back to the conservative count at the join and drain the prefetch queue in front of the MFMAs.
     for (int n = 0; n < nch; n += 2) {
-      if (kProduce) produce(n + 1, 1);
+      produce(n + 1, 1);
       load_a<OW, NG>(a1, ap1 + (n + 1) * NG * 64, ot_stride1);
       load_dw(min(n + 2, nch - 1));
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMA block
-      if (kMfma) mfma_groups<OW, NT, SS, NG>(acc, a0, slab_w);
-      if (kBarrier) __syncthreads();
-      if (kProduce && n + 2 < nch) produce(n + 2, 0);
+      mfma_groups<OW, NT, SS, NG>(acc, a0, slab_w);
+      __syncthreads();
+      if (n + 2 < nch) produce(n + 2, 0);
       load_a<OW, NG>(a0, ap1 + min(n + 2, nch - 1) * NG * 64, ot_stride1);
       load_dw(min(n + 3, nch - 1));
       __builtin_amdgcn_sched_barrier(0);
-      if (kMfma) mfma_groups<OW, NT, SS, NG>(acc, a1, slab_w + KC * SS);
-      if (kBarrier) __syncthreads();
+      mfma_groups<OW, NT, SS, NG>(acc, a1, slab_w + KC * SS);
+      __syncthreads();
     }
 
     if constexpr (KIND == KIND_MDTC) {
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
 
     // ---- epilogue: bias (+ReLU) + residual, in place into h
 #pragma unroll
-    for (int ow = 0; ow < ((WEKWS_ABLATE == 8 || WEKWS_ABLATE == 9) ? 0 : OW); ++ow) {
+    for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
       const float4 bias = ebias[ow];
 #pragma unroll
@@ -685,14 +688,9 @@ inline int launch_one(const StackParams& P, const CallArgs& A, hipStream_t strea
   using G = Geom<KIND, C, NT>;
   constexpr int KS = (KIND == KIND_MDTC) ? 5 : 8;  // the kernel sizes of the reference recipes (tcn.yaml / mdtc.yaml)
   if (P.ksize != KS) return -4;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = conv_stack_kernel<KIND, C, NT, KS>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(G::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   const int grid = (A.B + G::U - 1) / G::U;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;

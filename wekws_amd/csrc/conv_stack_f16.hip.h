@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
         sxu[u] = pow2_scale(amax_read(amax_cells + u * kAmaxCells), &inv_unused);
       }
       // item = (utterance, step, k-octet, frame): 8 consecutive features of one frame -> one 16-byte hi + lo store
-      for (int e = tid; e < ((WEKWS_ABLATE == 5 || WEKWS_ABLATE == 9) ? 0 : U * steps * 4 * TT); e += kThreads) {
+      for (int e = tid; e < U * steps * 4 * TT; e += kThreads) {
         const int t = e % TT;
         int q = e / TT;
         const int oct = q & 3; q >>= 2;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
           const int c = n * KC + r;
           const int hoff = (u * C + c) * SS;
           const int64_t gbase = (int64_t(uok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
-          if (A.out_cache && uok && !(WEKWS_ABLATE == 6 || WEKWS_ABLATE == 9)) {
+          if (A.out_cache && uok) {
             for (int p = tl; p < pad; p += 16) {
               const int src = T + p - pad;
               float cv = hbuf[hoff + max(src, 0)];
@@ -500,25 +500,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     };
 
     // ---- GEMM 1 over K: one MFMA K step per chunk, double-buffered planes, one barrier per chunk
-    constexpr bool kProduce = !(WEKWS_ABLATE == 1 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
-    constexpr bool kMfma = !(WEKWS_ABLATE == 2 || (WEKWS_ABLATE >= 3 && WEKWS_ABLATE != 4));
     zero_acc(acc);
     produce(0, 0);
     load_dw(min(1, nch - 1));
     __syncthreads();
     if constexpr (NBUF == 2) {
       for (int n = 0; n < nch; n += 2) {
-        if (kProduce) produce(n + 1, 1);
+        produce(n + 1, 1);
         load_a16<OW>(a1, ap1 + (n + 1) * 128, ot_stride1);
         load_dw(min(n + 2, nch - 1));
         __builtin_amdgcn_sched_barrier(0);
-        if (kMfma) mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
+        mfma16_step<OW, NT>(acc, a0, slab_u + frag_off, slab_u + PB + frag_off);
         __syncthreads();
-        if (kProduce && n + 2 < nch) produce(n + 2, 0);
+        if (n + 2 < nch) produce(n + 2, 0);
         load_a16<OW>(a0, ap1 + min(n + 2, nch - 1) * 128, ot_stride1);
         load_dw(min(n + 3, nch - 1));
         __builtin_amdgcn_sched_barrier(0);
-        if (kMfma) mfma16_step<OW, NT>(acc, a1, slab_u + 2 * PB + frag_off, slab_u + 3 * PB + frag_off);
+        mfma16_step<OW, NT>(acc, a1, slab_u + 2 * PB + frag_off, slab_u + 3 * PB + frag_off);
         __syncthreads();
       }
     } else {
@@ -568,7 +566,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     // ---- epilogue: bias (+ReLU) + residual, in place into h
     float hmax = 0.f;
 #pragma unroll
-    for (int ow = 0; ow < ((WEKWS_ABLATE == 8 || WEKWS_ABLATE == 9) ? 0 : OW); ++ow) {
+    for (int ow = 0; ow < OW; ++ow) {
       const int o = o_base + ow * 16 + lq * 4;
       const float4 bias = ebias[ow];
 #pragma unroll
@@ -624,14 +622,9 @@ inline int launch_one_f16(const StackParams& P, const CallArgs& A, hipStream_t s
   if constexpr (KIND == KIND_TCN && C < 64) {
     return -4;  // K = 8*C needs a double-buffered slab that does not fit Geom<> at C = 32; served by dense_stack_f16
   } else {
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = conv_stack_f16_kernel<KIND, C, NT, KS>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(G::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   const int grid = (A.B + G::U - 1) / G::U;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -431,14 +431,9 @@ inline int launch_dense_one(const DenseParams& P, const CallArgs& A, hipStream_t
   constexpr int KS = 8;
   if (P.ksize != KS) return -4;
   if (D::LDS_BYTES > 160 * 1024) return -4;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = dense_stack_f16_kernel<KIND, C, NT, KS>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(D::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(D::LDS_BYTES), grant)) return -3;
   const int grid = (A.B + D::U - 1) / D::U;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), D::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -446,14 +446,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
 template <int NT, bool HAS_CACHE>
 inline int launch_ds256_mm_ntc(const StackParams& P, const CallArgs& A, uint32_t head_a16, hipStream_t stream) {
   using G = MmGeom<NT>;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = ds256_mm_kernel<NT, HAS_CACHE>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(G::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(A.B, A.head_slices > 1 ? A.head_slices : 1), dim3(kW16Threads), G::LDS_BYTES, stream, P, A,
                      head_a16);
   return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -221,15 +221,10 @@ inline size_t ds256_stream_lds_bytes(int cache_len) {       // slab 16 KB + chun
 
 template <bool SPLIT>
 inline int launch_ds256_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  static size_t attr_set = 0;
+  static DynLdsGrant grant;
   const size_t lds = ds256_stream_lds_bytes(P.cache_len);
   auto kern = ds256_stream_kernel<SPLIT>;
-  if (attr_set < lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) !=
-        hipSuccess)
-      return -3;
-    attr_set = lds;
-  }
+  if (grant_dynamic_lds(kern, int(lds), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), lds, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -281,14 +281,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
 template <int NT, bool HAS_CACHE, bool SPLIT>
 inline int launch_ds256_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   using G = W16Geom<NT>;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = ds256_w16_kernel<NT, HAS_CACHE, SPLIT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(G::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -148,8 +148,11 @@ __device__ __forceinline__ int pz(int e) { return e + (e >> 2); }   // padded po
 
 constexpr int kFbankStrip = 832;   // floats per wave: 320 complex (padded 256) + 192 slot sums
 
-template <int ROUNDS>
-__global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankParams P, const float* __restrict__ pcm,
+// S: sample type of the PCM in device memory -- float (int16 scale, what wav.h:98-102 hands over) or int16_t (what
+// FeaturePipeline::AcceptWaveform(const std::vector<int16_t>&), feature_pipeline.cc:49-55, receives: converted here,
+// in registers, so the upload and the HBM read are 2 bytes per sample)
+template <int ROUNDS, typename S>
+__global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
                                                                  int B, int nsamp, int nframes,
                                                                  float* __restrict__ feats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -206,20 +209,26 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
   const int64_t stride = int64_t(gridDim.x) * kFbankWaves;
   // the sample pairs of a wave's NEXT frame are requested before the current frame is processed
   float2 vn[4];
-  const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % 8 == 0);
+  const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % (2 * sizeof(S)) == 0);
   auto fetch = [&](int64_t f) __attribute__((always_inline)) {
     const int64_t b = f / nframes;
     const int fr = int(f - b * nframes);
-    const float* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
+    const S* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int i = 2 * (lane + 64 * m);
       float2 v = make_float2(0.f, 0.f);
       if (f < total) {
-        if (pair_ok && i + 1 < FL) v = *reinterpret_cast<const float2*>(src + i);
-        else {
-          if (i < FL) v.x = src[i];
-          if (i + 1 < FL) v.y = src[i + 1];
+        if (pair_ok && i + 1 < FL) {
+          if constexpr (sizeof(S) == 4) {
+            v = *reinterpret_cast<const float2*>(src + i);
+          } else {
+            const short2 q = *reinterpret_cast<const short2*>(src + i);
+            v = make_float2(float(q.x), float(q.y));
+          }
+        } else {
+          if (i < FL) v.x = float(src[i]);
+          if (i + 1 < FL) v.y = float(src[i + 1]);
         }
       }
       vn[m] = v;
@@ -334,26 +343,32 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
   }
 }
 
-inline int launch_fbank(const FbankParams& P, const float* pcm, int B, int nsamp, int nframes, float* feats,
+// persistent waves: exactly one resident round (a second, partly filled round costs a whole wave lifetime).  The number
+// of resident workgroups is a property of (kernel, device): looked up by the caller once per extractor (fbank_create).
+template <typename S>
+inline int fbank_resident_groups(const FbankParams& P) {
+  const int rounds = (P.nslots + 63) / 64;
+  if (rounds < 1 || rounds > 3) return 0;
+  const size_t lds = size_t(kFbankWaves * kFbankStrip) * sizeof(float);
+  auto kern = rounds == 1 ? fbank_kernel<1, S> : rounds == 2 ? fbank_kernel<2, S> : fbank_kernel<3, S>;
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kFbankWaves, lds) == hipSuccess &&
+      hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0)
+    return per_cu * prop.multiProcessorCount;
+  return 256 * 4;
+}
+
+template <typename S>
+inline int launch_fbank(const FbankParams& P, const S* pcm, int B, int nsamp, int nframes, float* feats, int resident,
                         hipStream_t stream) {
   const int rounds = (P.nslots + 63) / 64;
   if (rounds < 1 || rounds > 3) return -4;
   const size_t lds = size_t(kFbankWaves * kFbankStrip) * sizeof(float);
   const int64_t total = int64_t(B) * nframes;
   int64_t grid = (total + kFbankWaves - 1) / kFbankWaves;
-  // persistent waves: exactly one resident round (a second, partly filled round costs a whole wave lifetime)
-  static int resident[4] = {0, 0, 0, 0};
-  auto kern = rounds == 1 ? fbank_kernel<1> : rounds == 2 ? fbank_kernel<2> : fbank_kernel<3>;
-  if (!resident[rounds]) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * kFbankWaves, lds) == hipSuccess &&
-        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0)
-      resident[rounds] = per_cu * prop.multiProcessorCount;
-    else
-      resident[rounds] = 256 * 4;
-  }
-  if (grid > resident[rounds]) grid = resident[rounds];
+  auto kern = rounds == 1 ? fbank_kernel<1, S> : rounds == 2 ? fbank_kernel<2, S> : fbank_kernel<3, S>;
+  if (resident > 0 && grid > resident) grid = resident;
   hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(64 * kFbankWaves), lds, stream, P, pcm, B, nsamp, nframes, feats);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -491,14 +491,9 @@ template <int NT, int U>
 inline int launch_fsmn_nt(const FsmnParams& P, const FsmnArgs& A, hipStream_t stream) {
   const int lds = FsmnLds::make(P, 16 * NT, U).bytes();
   if (lds > kFsmnLdsLimit) return -4;
-  static int attr_bytes = 0;
+  static DynLdsGrant grant;
   auto kern = fsmn_f16_kernel<NT, U>;
-  if (lds > attr_bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return -3;
-    attr_bytes = lds;
-  }
+  if (grant_dynamic_lds(kern, lds, grant)) return -3;
   hipLaunchKernelGGL(kern, dim3((A.B + U - 1) / U, A.head_slices > 1 ? A.head_slices : 1), dim3(kFsmnThreads), lds, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -499,14 +499,9 @@ inline int launch_gru_f16_mode(const GruF16Params& Q, const GruF16Workspace& ws,
                                hipStream_t stream) {
   using G = GruF16Geom<NN>;
   const int tiles = (B + G::MB - 1) / G::MB;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = gru_f16_kernel<NN, MODE>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            G::LDS_BYTES) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(tiles, nchunks), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn, lsel,
                      tchunk);
   return hipGetLastError() == hipSuccess ? 0 : -3;

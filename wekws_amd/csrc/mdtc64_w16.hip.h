@@ -380,14 +380,9 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 template <int NT, bool HAS_CACHE, bool SPLIT>
 inline int launch_mdtc64_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   using G = Geom<KIND_MDTC, 64, NT>;
-  static bool attr_set = false;
+  static DynLdsGrant grant;
   auto kern = mdtc64_w16_kernel<NT, HAS_CACHE, SPLIT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(G::LDS_BYTES)) != hipSuccess)
-      return -3;
-    attr_set = true;
-  }
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3((A.B + 1) / 2), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -405,15 +400,10 @@ inline size_t mdtc64_stream_lds_bytes(int cache_len) { return Geom<KIND_MDTC, 64
 
 template <bool SPLIT>
 inline int launch_mdtc64_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  static size_t attr_set = 0;
+  static DynLdsGrant grant;
   const size_t lds = mdtc64_stream_lds_bytes(P.cache_len);
   auto kern = mdtc64_w16_kernel<1, false, SPLIT, true>;
-  if (attr_set < lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) !=
-        hipSuccess)
-      return -3;
-    attr_set = lds;
-  }
+  if (grant_dynamic_lds(kern, int(lds), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3((A.B + 1) / 2), dim3(kW16Threads), lds, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -55,6 +55,23 @@ int fail(int code, const char* fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Makes `device` current for the scope and restores the caller's device afterwards: the library never changes the
+// calling thread's current device behind its back (a Python __del__ may run at any time).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    else prev = -1;                       // already current: nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // s = 2^(14 - floor(log2 bound)): bound * s in [2^14, 2^15); *inv = 1 / s.
 // (host twin of pow2_scale in conv_stack_f16.hip.h)
 inline float pow2_scale_host(float bound, float* inv) {
@@ -226,14 +243,17 @@ struct wekws_hip_model {
   wekws::DenseBlock* d_dblocks = nullptr;
   wekws::StackParams sp{};
   wekws::DenseParams dp{};
-  bool mm_ok = false;     // DS-TCN h256 + per-frame linear head: all-matrix-core kernel (ds256_mm.hip.h).  Default for
-                          // CTC-sized heads (odim > 16); opt-in (WEKWS_HIP_MM=1) for keyword heads, where the
-                          // 16-wave kernel is 12 % faster
-  bool mdtc16_ok = false; // MDTC h64: use the 16-wave kernel (WEKWS_HIP_MDTC16=0 selects the 8-wave one; experiments)
-  bool w16_ok = true;     // DS-TCN h256: use the 16-wave kernel (WEKWS_HIP_W16=0 selects the 8-wave one; experiments)
-  int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, WEKWS_HIP_FSMN_SLICES=0|n forces (tests)
+  // kernel selection (defaults = the product choice; wekws_hip_set_option overrides, for A/B measurements and the tests
+  // that keep every kernel family parity-green)
+  bool mm_eligible = false; // DS-TCN h256 + per-frame linear head: the all-matrix-core kernel (ds256_mm.hip.h) can serve it
+  bool mm_ok = false;     // ... and does: default for CTC-sized heads (odim > 16); WEKWS_HIP_OPT_MM forces it on / off
+                          // (keyword heads: the 16-wave kernel is 12 % faster)
+  bool mdtc16_eligible = false;
+  bool mdtc16_ok = false; // MDTC h64: the 16-wave kernel (WEKWS_HIP_OPT_MDTC16 = 0: the generic 8-wave one)
+  bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
+  int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, 0 / 1 off, n forces n
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
-                          // (WEKWS_HIP_STREAM=0 keeps the batch kernel; tests)
+                          // (WEKWS_HIP_OPT_STREAM = 0 keeps the batch kernel)
   bool dense_ok = false;  // plain TCN whose paddings fit the dense-stack kernel's halo
   wekws::GruParams gp{};
   wekws::GruF16Params gq{};
@@ -252,7 +272,14 @@ static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t nee
   for (auto& e : m->ws) if (e.stream == stream) sb = &e;
   if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->ws.back(); }
   if (sb->bytes < need) {
-    if (hipSetDevice(m->device) != hipSuccess) { fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device); return nullptr; }
+    // Growing frees the old buffer behind a stream synchronisation -- which a stream that is being captured into a HIP
+    // graph cannot do: such a call fails and names wekws_hip_reserve (no hidden synchronisation inside a capture).
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      fail(WEKWS_HIP_EINVAL, "this call needs %zu bytes of workspace on a stream that is being captured: call "
+                             "wekws_hip_reserve(model, B, T, stream) before the capture begins", need);
+      return nullptr;
+    }
     if (sb->ptr) {
       (void)hipStreamSynchronize(stream);                     // earlier calls on this stream may still use the old buffer
       (void)hipFree(sb->ptr);
@@ -273,6 +300,7 @@ struct wekws_hip_fbank {
   wekws::FbankParams fp{};
   int device = 0;
   float* d_tables = nullptr;
+  int resident_f32 = 0, resident_i16 = 0;   // workgroups of one resident round, per sample type (fbank.hip.h)
 };
 
 // FSMN: validate, zero-pad every channel count to a multiple of 32, pre-split + pre-pack the six kinds of dense
@@ -298,7 +326,8 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", device);
 
   Image img;
   img.reserve(4);
@@ -360,7 +389,6 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->fsmn_cus = prop.multiProcessorCount;
-    if (const char* e = std::getenv("WEKWS_HIP_FSMN_SLICES")) m->fsmn_slices = std::atoi(e);
   }
   hipError_t e = hipMalloc(&m->d_w, img.data.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(m->d_w, img.data.data(), img.data.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -375,6 +403,28 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   return WEKWS_HIP_OK;
 }
 
+// Scratch bytes one wekws_hip_forward(m, B, T) takes from its stream's workspace (0: none) -- the single source for the
+// forward paths below and for wekws_hip_reserve.
+static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
+  const wekws_hip_desc& d = m->desc;
+  if (B <= 0 || T <= 0) return 0;
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+    const int TILE = 16 * m->fsmn_max_nt;
+    if (T <= TILE) return 0;
+    return 2 * size_t(B) * d.num_stack * m->cache_len * d.num_layers * sizeof(float);
+  }
+  if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
+    if (d.precision == WEKWS_HIP_PRECISION_F32 || !wekws::gru_f16_supported(m->gq)) return 0;
+    size_t seq_b = 0, gi_b = 0, sc_b = 0;
+    wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b, &sc_b);
+    return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + sc_b;
+  }
+  if (T <= WEKWS_HIP_TILE_FRAMES) return 0;
+  const size_t ce = size_t(B) * d.hdim * m->cache_len;
+  const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * d.hdim : 0;
+  return (2 * ce + ge) * sizeof(float);
+}
+
 // The frames of one FSMN call, cut into LDS tiles chained through ping-pong workspace caches
 static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
                         float* out_cache, hipStream_t stream) {
@@ -384,7 +434,7 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
   float* ws_cache[2] = {nullptr, nullptr};
   if (ntiles > 1) {
     const size_t ce = size_t(B) * d.num_stack * m->cache_len * d.num_layers;
-    char* base = stream_workspace(m, stream, 2 * ce * sizeof(float));
+    char* base = stream_workspace(m, stream, workspace_need(m, B, T));
     if (!base) return WEKWS_HIP_ENOMEM;
     ws_cache[0] = reinterpret_cast<float*>(base);
     ws_cache[1] = ws_cache[0] + ce;
@@ -462,7 +512,8 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", device);
 
   wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
   if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
@@ -624,20 +675,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     int max_pad = 0;
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
-    if (const char* e = std::getenv("WEKWS_HIP_W16")) m->w16_ok = std::atoi(e) != 0;
-    if (const char* e = std::getenv("WEKWS_HIP_STREAM")) m->stream_ok = std::atoi(e) != 0;
-    m->mdtc16_ok = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
-    if (const char* e = std::getenv("WEKWS_HIP_MDTC16")) m->mdtc16_ok = m->mdtc16_ok && std::atoi(e) != 0;
-    m->mm_ok = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
-               d.head == WEKWS_HIP_HEAD_LINEAR;
-    {
-      // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword
-      // heads (the 16-wave kernel is 12 % faster there); WEKWS_HIP_MM=0 / 1 forces it off / on where eligible
-      if (const char* es = std::getenv("WEKWS_HIP_FSMN_SLICES")) m->fsmn_slices = std::atoi(es);   // also the DS-TCN CTC head
-      const char* e = std::getenv("WEKWS_HIP_MM");
-      const bool want = e ? std::atoi(e) != 0 : K > 16;
-      m->mm_ok = m->mm_ok && want;
-    }
+    m->mdtc16_eligible = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
+    m->mdtc16_ok = m->mdtc16_eligible;
+    m->mm_eligible = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
+                     d.head == WEKWS_HIP_HEAD_LINEAR;
+    // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword heads
+    // (the 16-wave kernel is 12 % faster there)
+    m->mm_ok = m->mm_eligible && K > 16;
   } else {
     wekws::GruParams& gp = m->gp;
     gp.idim = d.idim;
@@ -716,7 +760,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
 
 void wekws_hip_destroy(wekws_hip_model* m) {
   if (!m) return;
-  (void)hipSetDevice(m->device);
+  DeviceGuard guard(m->device);
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
@@ -743,6 +787,47 @@ size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T) {
   return size_t(B) * T * m->desc.odim;
 }
 
+int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  switch (option) {
+    case WEKWS_HIP_OPT_W16: m->w16_ok = value != 0; break;
+    case WEKWS_HIP_OPT_MDTC16: m->mdtc16_ok = m->mdtc16_eligible && value != 0; break;
+    case WEKWS_HIP_OPT_STREAM: m->stream_ok = value != 0; break;
+    case WEKWS_HIP_OPT_MM: m->mm_ok = m->mm_eligible && (value < 0 ? m->desc.odim > 16 : value != 0); break;
+    case WEKWS_HIP_OPT_HEAD_SLICES: m->fsmn_slices = value; break;
+    default: return fail(WEKWS_HIP_EINVAL, "unknown option %d", option);
+  }
+  return WEKWS_HIP_OK;
+}
+
+size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T) { return m ? workspace_need(m, B, T) : 0; }
+
+int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream_) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  const size_t need = workspace_need(m, B, T);
+  if (!need) return WEKWS_HIP_OK;
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
+  return stream_workspace(m, static_cast<hipStream_t>(stream_), need) ? WEKWS_HIP_OK : WEKWS_HIP_ENOMEM;
+}
+
+int wekws_hip_release(wekws_hip_model* m, void* stream_) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(m->device);
+  std::lock_guard<std::mutex> lk(m->ws_mu);
+  for (size_t i = 0; i < m->ws.size(); ++i)
+    if (m->ws[i].stream == stream) {
+      if (m->ws[i].ptr) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(m->ws[i].ptr);
+      }
+      m->ws.erase(m->ws.begin() + i);
+      break;
+    }
+  return WEKWS_HIP_OK;
+}
+
 int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
                       float* out_cache, int softmax, void* stream_) {
   if (!m || !x || !y) return fail(WEKWS_HIP_EINVAL, "NULL argument");
@@ -750,6 +835,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   if (B == 0) return WEKWS_HIP_OK;
   if (in_cache && in_cache == out_cache) return fail(WEKWS_HIP_EINVAL, "in_cache and out_cache must not alias");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // the kernels go to the model's device whatever the calling thread's current device is (a default stream, NULL, means
+  // that device's default stream); the caller's device is current again on return
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
   const wekws_hip_desc& d = m->desc;
   const bool per_frame = d.head == WEKWS_HIP_HEAD_LINEAR || d.head == WEKWS_HIP_HEAD_IDENTITY;
 
@@ -765,8 +854,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       size_t seq_b = 0, gi_b = 0, sc_b = 0;
       wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b, &sc_b);
       const size_t seq_al = (seq_b + 255) / 256 * 256, gi_al = (gi_b + 255) / 256 * 256;
-      const size_t need = 2 * seq_al + gi_al + sc_b;
-      char* base = stream_workspace(m, stream, need);
+      char* base = stream_workspace(m, stream, workspace_need(m, B, T));
       if (!base) return WEKWS_HIP_ENOMEM;
       wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al),
                                 reinterpret_cast<float*>(base + 2 * seq_al + gi_al)};
@@ -785,7 +873,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       // long input: tiles hand the causal context over through ping-pong caches in the stream's workspace
       const size_t ce = size_t(B) * C * m->cache_len;
       const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * C : 0;
-      char* base = stream_workspace(m, stream, (2 * ce + ge) * sizeof(float));
+      char* base = stream_workspace(m, stream, workspace_need(m, B, T));
       if (!base) return WEKWS_HIP_ENOMEM;
       ws_cache[0] = reinterpret_cast<float*>(base);
       ws_cache[1] = ws_cache[0] + ce;
@@ -869,10 +957,16 @@ int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip
     return fail(WEKWS_HIP_EINVAL, "fbank cfg out of range");
   if (cfg->window != WEKWS_HIP_WINDOW_HAMMING && cfg->window != WEKWS_HIP_WINDOW_POVEY)
     return fail(WEKWS_HIP_EINVAL, "fbank window %d", cfg->window);
+  if (cfg->frame_length <= wekws::kFbankMaxFft / 2)
+    // the reference pads a frame to UpperPowerOfTwo(frame_length) (fbank.h:43,117-119): 256 points or fewer here, i.e.
+    // other bin widths and mel weights than the 512-point transform this kernel implements
+    return fail(WEKWS_HIP_EUNSUPPORTED, "fbank frame_length %d: only the 512-point FFT (257..512 samples per frame) is built",
+                cfg->frame_length);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", device);
   wekws_hip_fbank* f = new (std::nothrow) wekws_hip_fbank();
   if (!f) return fail(WEKWS_HIP_ENOMEM, "host allocation");
   f->device = device;
@@ -887,13 +981,15 @@ int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip
     return fail(WEKWS_HIP_EDEVICE, "fbank table upload: %s", hipGetErrorString(e));
   }
   f->fp.tables = f->d_tables;
+  f->resident_f32 = wekws::fbank_resident_groups<float>(f->fp);
+  f->resident_i16 = wekws::fbank_resident_groups<int16_t>(f->fp);
   *out = f;
   return WEKWS_HIP_OK;
 }
 
 void wekws_hip_fbank_destroy(wekws_hip_fbank* f) {
   if (!f) return;
-  (void)hipSetDevice(f->device);
+  DeviceGuard guard(f->device);
   if (f->d_tables) (void)hipFree(f->d_tables);
   delete f;
 }
@@ -908,7 +1004,19 @@ int wekws_hip_fbank_compute(wekws_hip_fbank* f, const float* pcm, int B, int nsa
   if (B < 0 || nsamp < 0) return fail(WEKWS_HIP_EINVAL, "B=%d nsamp=%d", B, nsamp);
   const int nf = wekws_hip_fbank_num_frames(f, nsamp);
   if (B == 0 || nf == 0) return WEKWS_HIP_OK;
-  const int rc = wekws::launch_fbank(f->fp, pcm, B, nsamp, nf, feats, static_cast<hipStream_t>(stream_));
+  DeviceGuard guard(f->device);
+  const int rc = wekws::launch_fbank<float>(f->fp, pcm, B, nsamp, nf, feats, f->resident_f32, static_cast<hipStream_t>(stream_));
+  if (rc) return fail(rc, "fbank launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
+int wekws_hip_fbank_compute_i16(wekws_hip_fbank* f, const int16_t* pcm, int B, int nsamp, float* feats, void* stream_) {
+  if (!f || !pcm || !feats) return fail(WEKWS_HIP_EINVAL, "NULL argument");
+  if (B < 0 || nsamp < 0) return fail(WEKWS_HIP_EINVAL, "B=%d nsamp=%d", B, nsamp);
+  const int nf = wekws_hip_fbank_num_frames(f, nsamp);
+  if (B == 0 || nf == 0) return WEKWS_HIP_OK;
+  DeviceGuard guard(f->device);
+  const int rc = wekws::launch_fbank<int16_t>(f->fp, pcm, B, nsamp, nf, feats, f->resident_i16, static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "fbank launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }

@@ -52,16 +52,19 @@ class Fbank:
         return int(self._lib.wekws_hip_fbank_num_frames(self._ptr, int(nsamp)))
 
     def __call__(self, pcm: torch.Tensor) -> torch.Tensor:
-        if pcm.dim() != 2 or not pcm.is_cuda or pcm.dtype != torch.float32:
-            raise ValueError("pcm must be a (B, nsamp) float32 tensor on a ROCm device")
+        """(B, nsamp) PCM on a ROCm device -> (B, frames, num_bins) log-mel.  float32 in int16 scale (wav.h:98-102), or
+        int16 as FeaturePipeline::AcceptWaveform(std::vector<int16_t>) receives it (feature_pipeline.cc:49-55): widened
+        in the kernel's registers -- 2 bytes per sample over PCIe and HBM, the same features bit for bit."""
+        if pcm.dim() != 2 or not pcm.is_cuda or pcm.dtype not in (torch.float32, torch.int16):
+            raise ValueError("pcm must be a (B, nsamp) float32 or int16 tensor on a ROCm device")
         pcm = pcm.contiguous()
         B, n = int(pcm.size(0)), int(pcm.size(1))
         nf = self.num_frames(n)
         feats = torch.empty((B, nf, self.num_bins), dtype=torch.float32, device=pcm.device)
         if B and nf:
             stream = torch.cuda.current_stream(pcm.device).cuda_stream
-            _capi.check(self._lib.wekws_hip_fbank_compute(self._ptr, pcm.data_ptr(), B, n, feats.data_ptr(),
-                                                          ctypes.c_void_p(stream)), "wekws_hip_fbank_compute")
+            fn = self._lib.wekws_hip_fbank_compute if pcm.dtype == torch.float32 else self._lib.wekws_hip_fbank_compute_i16
+            _capi.check(fn(self._ptr, pcm.data_ptr(), B, n, feats.data_ptr(), ctypes.c_void_p(stream)), "wekws_hip_fbank_compute")
         return feats
 
     def leftover(self, nsamp: int) -> Tuple[int, int]:

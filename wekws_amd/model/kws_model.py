@@ -62,7 +62,7 @@ class _Holder(nn.Module):
 class _HipHandle:
     """Owns one wekws_hip_model*; destroyed with the Python object."""
 
-    def __init__(self, desc_fields: dict, blob: np.ndarray, device_index: int):
+    def __init__(self, desc_fields: dict, blob: np.ndarray, device_index: int, options: Optional[dict] = None):
         lib = _capi.load()
         self._lib = lib
         self.ptr = ctypes.c_void_p()
@@ -73,6 +73,8 @@ class _HipHandle:
                                         f"{_capi.last_error()}")
         _capi.check(lib.wekws_hip_create(ctypes.byref(desc), blob.ctypes.data, blob.size, device_index,
                                          ctypes.byref(self.ptr)), "wekws_hip_create")
+        for name, value in (options or {}).items():
+            _capi.check(lib.wekws_hip_set_option(self.ptr, _capi.OPTIONS[name], int(value)), "wekws_hip_set_option")
 
     def __del__(self):
         try:
@@ -109,6 +111,7 @@ class KWSModel(nn.Module):
         self._frozen = False
         self._packed_blob = None
         self._packed_versions = None
+        self._options = {}
 
     # ------------------------------------------------------------------ weights -> device library
     def _apply(self, fn, *args, **kwargs):
@@ -166,7 +169,8 @@ class KWSModel(nn.Module):
         if getattr(self, "_packed_blob", None) is not None:
             if self._handle is None or self._handle_key != ("packed", device.index):
                 desc = {k: int(self._d[k]) for k in pack.DESC_FIELDS}
-                self._handle = _HipHandle(desc, self._packed_blob, device.index if device.index is not None else 0)
+                self._handle = _HipHandle(desc, self._packed_blob, device.index if device.index is not None else 0,
+                                          self._options)
                 self._handle_key = ("packed", device.index)
             return self._handle
         if self._frozen and self._handle is not None and self._handle_key and self._handle_key[0] == device.index:
@@ -175,7 +179,7 @@ class KWSModel(nn.Module):
         if self._handle is None or key != self._handle_key:
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
             desc, blob = pack.pack(self._cfg, sd)
-            self._handle = _HipHandle(desc, blob, device.index if device.index is not None else 0)
+            self._handle = _HipHandle(desc, blob, device.index if device.index is not None else 0, self._options)
             self._handle_key = key
         return self._handle
 
@@ -188,6 +192,25 @@ class KWSModel(nn.Module):
         self._d["precision"] = pack.PRECISION[mode]
         self._handle = None
         self._frozen = False
+        return self
+
+    def set_option(self, name: str, value: int) -> "KWSModel":
+        """Kernel-selection override (enum wekws_hip_option: 'w16', 'mdtc16', 'stream', 'mm', 'head_slices') -- for A/B
+        measurements and the tests that keep every kernel family parity-green; defaults are the product choice."""
+        if name not in _capi.OPTIONS:
+            raise ValueError(f"option must be one of {sorted(_capi.OPTIONS)}")
+        self._options[name] = int(value)
+        self._handle = None
+        self._frozen = False
+        return self
+
+    def reserve(self, B: int, T: int, device: Optional[torch.device] = None) -> "KWSModel":
+        """Size the scratch buffer of the current stream for calls of up to (B, T) now (wekws_hip_reserve): later calls
+        then never allocate or synchronise -- required before capturing them into a HIP graph."""
+        dev = device or next(self.parameters()).device
+        h = self._get_handle(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(_capi.load().wekws_hip_reserve(h.ptr, int(B), int(T), ctypes.c_void_p(stream)), "wekws_hip_reserve")
         return self
 
     def packed(self) -> Tuple[dict, np.ndarray]:

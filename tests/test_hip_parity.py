@@ -611,3 +611,74 @@ def test_precision_f16_mode(name, B, T):
     yb, cb = model(xt[:, 40:], ca)
     if y16.ndim == 3:
         assert max_abs(torch.cat([ya, yb], 1).cpu().numpy(), y16) <= 2e-3 * scale
+
+
+def test_executor_test_loop_on_the_global_head():
+    """BASELINE config 1's caller shape: the batch-dict loop of Executor.cv / Executor.test (wekws/utils/executor.py:70-115,
+    driven by wekws/bin/compute_accuracy.py:92-98) with the 'ce' criterion of the speech-commands recipes
+    (wekws/model/loss.py:167-180 cross_entropy, :91-99 acc_frame) -- restated here on the HIP MDTC + GlobalClassifier(12) models, B = 256 per batch --
+    must report the loss and accuracy the oracle's logits give."""
+    import torch.nn.functional as F
+    from wekws_amd import pack
+
+    def executor_test(forward, loader):           # executor.py:70-115 (num_seen_utts starts at 1: appendix B.10)
+        num_seen_utts, total_loss, total_acc = 1, 0.0, 0.0
+        with torch.no_grad():
+            for batch_dict in loader:
+                feats, target = batch_dict["feats"], batch_dict["target"]
+                target = target[:, 0] if target.shape[1] == 1 else target
+                num_utts = batch_dict["feats_lengths"].size(0)
+                if num_utts == 0:
+                    continue
+                logits = forward(feats)
+                loss = F.cross_entropy(logits, target.type(torch.int64))                    # loss.py:178
+                pred = logits.max(1, keepdim=True)[1]                                       # loss.py:97-99
+                acc = pred.eq(target.long().view_as(pred)).sum().item() * 100.0 / logits.size(0)
+                if torch.isfinite(loss):
+                    num_seen_utts += num_utts
+                    total_loss += loss.item() * num_utts
+                    total_acc += acc * num_utts
+        return total_loss / num_seen_utts, total_acc / num_seen_utts
+
+    for name in ("mdtc_small_global12", "mdtc_h64_global12"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+        model = build(cfg, sd)
+        g = np.random.default_rng(3)
+        loader = []
+        for i, B in enumerate((256, 256, 97)):                                              # last batch ragged
+            feats = synth.synth_feats(B, 98, cfg["input_dim"], seed=20 + i)
+            loader.append(dict(keys=[f"utt{i}_{j}" for j in range(B)], feats=torch.from_numpy(feats),
+                               target=torch.from_numpy(g.integers(0, 12, size=(B, 1))),
+                               feats_lengths=torch.full((B,), 98, dtype=torch.int32),
+                               target_lengths=torch.ones(B, dtype=torch.int32)))
+        got = executor_test(lambda f: model(f.cuda())[0].cpu(), loader)
+        ref = executor_test(lambda f: torch.from_numpy(kws_oracle.forward(cfg, sd, f.numpy(), None)[0]), loader)
+        assert abs(got[0] - ref[0]) <= 1e-5 * max(1.0, abs(ref[0])) and got[1] == ref[1], (name, got, ref)
+
+
+def test_reserve_makes_long_inputs_capturable():
+    """a call that needs scratch memory (inputs longer than one LDS tile, every GRU call) used to grow its
+    workspace -- synchronise, free, allocate -- inside wekws_hip_forward, which breaks HIP graph capture.  Now: a capture
+    without a reservation fails cleanly and names wekws_hip_reserve; after model.reserve(B, T) the call records and
+    replays bit-identically."""
+    from wekws_amd import _capi, pack
+    for name, T in (("ds_tcn_h64", 300), ("gru_2x128", 20)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234)).freeze()
+        x = torch.from_numpy(synth.synth_feats(3, T, cfg["input_dim"], seed=8)).cuda()
+        y_ref, c_ref = model(x)                       # default stream: its own workspace
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model.reserve(3, T)                       # sizes the workspace of stream s, outside any capture
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y_static, c_static = model(x)
+        y_static.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), name
+        assert _capi.load().wekws_hip_workspace_bytes(model._get_handle(x.device).ptr, 3, T) > 0

@@ -210,10 +210,11 @@ __device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q
 // ---------------------------------------------------------------------------------------------
 // Classifier head on the resident tile (shared by the f32 and the split-fp16 kernels).  `slab` is free scratch.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int C, int NT, int NTHR = kThreads>
+// SSX: row stride of the resident tile when the caller lays it out itself (0: Geom's)
+template <int KIND, int C, int NT, int NTHR = kThreads, int SSX = 0>
 __device__ __forceinline__ void conv_stack_head(const StackParams& P, const CallArgs& A, float* hbuf, float* slab, int b0) {
   using G = Geom<KIND, C, NT>;
-  constexpr int U = G::U, SS = G::SS;
+  constexpr int U = G::U, SS = SSX ? SSX : G::SS;
   const int tid = threadIdx.x;
   const int T = A.T;
   const float* __restrict__ W = P.w;

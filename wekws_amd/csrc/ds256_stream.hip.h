@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   const int b = blockIdx.x;                                  // one stream per workgroup
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
-  const int pg = tid >> 4, tl = tid & 15;
+  const int pg = w16_row(tid >> 4), tl = tid & 15;           // (row permutation: ds256_w16.hip.h)
   const int o0 = wave * 16 + lq * 4;
   const int frag_off = (lq * TT + l15) * 16;
   const int n4 = (C * Pc) >> 2;                              // float4 items of one stream's cache (C * Pc % 4 == 0)
@@ -61,15 +61,39 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
-  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  const int nk = P.kpre16 / 32;
+  const bool one_trip = nk <= 2;                             // 40-d fbank: the features pass through registers once
+  W16XItem xi;
+  if (one_trip) {
+    xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+    amax_publish(amax_cells, w16_x_amax(xi));
+  } else {
+    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  }
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
-    const int nk = P.kpre16 / 32;
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
     float sx = 1.f, cpre = 1.f;
+    if (one_trip) {
+      F16Frag a[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {                       // in flight over the barriers (nk = 1: the same step twice)
+        const uint4* q = ap + min(st, nk - 1) * 128;
+        a[st].h = __builtin_bit_cast(f16x8, q[0]);
+        a[st].l = __builtin_bit_cast(f16x8, q[64]);
+      }
+      __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
+      w16_store_x<PB, SPLIT>(xi, sx, slab);
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st)                         // (compile-time indices: a runtime-indexed fragment array spills)
+        if (st < nk)
+          mfma16_step_nb<NT, SPLIT>(acc[0], a[st], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
+    } else
     for (int k0 = 0; k0 < nk; k0 += 2) {
       const int steps = min(2, nk - k0);
       __syncthreads();
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b) * C * Pc);
     for (int e = tid; e < n4; e += kW16Threads) __builtin_nontemporal_store(src[e], dst + e);
   }
-  conv_stack_head<KIND_DS, 256, 1, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
+  conv_stack_head<KIND_DS, 256, 1, kW16Threads, SS>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
 }
 
 inline size_t ds256_stream_lds_bytes(int cache_len) {       // slab 16 KB + chunk 16 KB + cache

@@ -39,11 +39,74 @@ __device__ __forceinline__ void mfma16_step_nb(f32x4 (&acc)[NT], const F16Frag& 
 constexpr int kW16Threads = 1024;
 constexpr int kW16Waves = 16;
 
+// Preprocessing input of one utterance for feature dims up to 64 (two K steps = one slab fill): every thread owns at most
+// ONE item (step, k-octet, frame) = 8 consecutive features of a frame.  The features make one trip from memory: they are
+// loaded into registers, their maximum is published (block floating point), and after the barrier the same registers are
+// scaled, split and stored as operand planes.  Returns the thread's 8 features (zeros where there are none).
+typedef float w16_f32x8 __attribute__((ext_vector_type(8)));   // (a plain float[8] member ends up in scratch)
+struct W16XItem {
+  w16_f32x8 v;
+  int dst;                                                   // byte offset of the item's hi slot in the slab, -1: no item
+};
+template <int TT, int PB>
+__device__ __forceinline__ W16XItem w16_load_x(const float* __restrict__ xb, int T, int idim, int nk) {
+  W16XItem it;
+  const int e = threadIdx.x;
+  const int t = e % TT, q = e / TT;
+  const int oct = q & 3, st = q >> 2;
+  const int kf = st * 32 + oct * 8;
+  const bool has = e < nk * 4 * TT;
+  it.dst = has ? st * 2 * PB + (oct * TT + t) * 16 : -1;
+  const float* xr = xb + int64_t(t) * idim + kf;
+  const bool row = has && t < T;
+  if (row && kf + 8 <= idim && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(xr), c = *reinterpret_cast<const float4*>(xr + 4);
+    it.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  } else {
+    w16_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (row && kf + i < idim) ? xr[i] : 0.f;
+    it.v = v;
+  }
+  return it;
+}
+__device__ __forceinline__ float w16_x_amax(const W16XItem& it) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(it.v[i]));
+  return m;
+}
+template <int PB, bool SPLIT>
+__device__ __forceinline__ void w16_store_x(const W16XItem& it, float sx, char* slab) {
+  if (it.dst < 0) return;
+  f16x8 vh, vl;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 h, l;
+    split16s(it.v[i], sx, h, l);
+    vh[i] = h; vl[i] = l;
+  }
+  *reinterpret_cast<f16x8*>(slab + it.dst) = vh;
+  if constexpr (SPLIT) *reinterpret_cast<f16x8*>(slab + it.dst + PB) = vl;
+}
+
+// Which of the 64 channel rows of a K interval lane-group pg (= tid >> 4) produces.  A wave's four lane-groups are the
+// two 32-lane halves LDS instructions are serviced in; the permutation makes the two groups of a half produce rows 4
+// apart -- different dwords of the operand planes (rows r, r + 1 share one: their 2-byte stores collided) and 16 banks
+// apart in the f32 tile.  Within an octet: groups (0,1 | 2,3) of the even wave -> rows (0,4 | 1,5), odd wave -> (2,6 | 3,7).
+__device__ __forceinline__ int w16_row(int pg) { return (pg & ~7) | (((pg & 1) << 2) + ((pg >> 1) & 1) + ((pg >> 2) & 1) * 2); }
+
 template <int NT>
 struct W16Geom {
   static constexpr int C = 256;
   static constexpr int TT = 16 * NT;
-  static constexpr int SS = (NT % 2) ? 16 * NT : 16 * NT + 16;
+  // Row stride of the f32 tile: TT + 4.  LDS banks of 4-byte accesses are (a / 4) mod 32, serviced per 32-lane half:
+  //   epilogue   a half = 16 frames x 2 row groups FOUR rows apart: 4 * SS == 16 (mod 32) -> 32 distinct banks
+  //   producer   a half = 2 lane-groups; w16_row() puts them four channel rows apart as well (same 16-bank offset), and
+  //              the 16 lanes of a group walk strided frame runs that cover 16 distinct banks for every dilation
+  // (TT itself, == 16 mod 32, made the epilogue 2-way and the producer's 2-byte plane stores 4-way conflicted:
+  // profiles/r01f: 22 % of the LDS cycles)
+  static constexpr int SS = 16 * NT + 4;
   static constexpr int PB = Plane<32, TT>::BYTES;            // one hi (or lo) plane of one 32-channel K step
   static constexpr int SLAB = 4 * PB;                        // [kstep 0 hi | kstep 0 lo | kstep 1 hi | kstep 1 lo]
   static constexpr int H_FLOATS = C * SS;
@@ -68,7 +131,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   const int b = blockIdx.x;                                  // one utterance per workgroup
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
-  const int pg = tid >> 4, tl = tid & 15;                    // producer: 64 lane-groups x 16 lanes
+  const int pg = w16_row(tid >> 4), tl = tid & 15;           // producer: 64 lane-groups x 16 lanes; pg = the row it makes
   const int o0 = wave * 16 + lq * 4;                         // this lane's 4 output channels (o-tile = wave)
   const int frag_off = (lq * TT + l15) * 16;
 
@@ -80,17 +143,41 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
-  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  const int nk = P.kpre16 / 32;
+  const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads;    // 40-d fbank: the features pass through registers once
+  W16XItem xi;
+  if (one_trip) {
+    xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+    amax_publish(amax_cells, w16_x_amax(xi));
+  } else {
+    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  }
   if constexpr (HAS_CACHE)
     amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
-    const int nk = P.kpre16 / 32;
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
     float sx = 1.f, cpre = 1.f;
+    if (one_trip) {
+      F16Frag a[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {                       // in flight over the barriers (nk = 1: the same step twice)
+        const uint4* q = ap + min(st, nk - 1) * 128;
+        a[st].h = __builtin_bit_cast(f16x8, q[0]);
+        a[st].l = __builtin_bit_cast(f16x8, q[64]);
+      }
+      __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
+      w16_store_x<PB, SPLIT>(xi, sx, slab);
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st)                         // (compile-time indices: a runtime-indexed fragment array spills)
+        if (st < nk)
+          mfma16_step_nb<NT, SPLIT>(acc[0], a[st], slab + st * 2 * PB + frag_off, slab + st * 2 * PB + PB + frag_off);
+    } else
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the slab)
       const int steps = min(2, nk - k0);
       __syncthreads();
@@ -137,7 +224,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     amax_publish(amax_cells + 2, hmax);
     __syncthreads();
   }
-
   // ======================================= residual blocks =======================================
   constexpr int NIV = C / 64;                                // K intervals per layer
   constexpr int OTS = (C / 32) * 128;                        // uint4 per o-tile (8 K steps)
@@ -191,17 +277,39 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     }                                                                                    \
     fv_;                                                                                 \
   })
-      if (A.out_cache) {
-        for (int p = tl; p < pad; p += 16) {
-          const int src = T + p - pad;   // index into h (negative: still inside the old cache)
-          float cv = hbuf[hoff + max(src, 0)];
-          if constexpr (HAS_CACHE) {
+      // the row's new streaming-cache slice = last `pad` frames of [old slice | h]
+      if constexpr (HAS_CACHE) {
+        // (with an incoming cache the kernel sits at the 128-register budget of four waves per SIMD: element by element)
+        if (A.out_cache) {
+          for (int p = tl; p < pad; p += 16) {
+            const int src = T + p - pad;   // index into h (negative: still inside the old cache)
+            const float hv = hbuf[hoff + max(src, 0)];
             const float g = A.in_cache[gbase + pad + min(src, -1)];
-            cv = src >= 0 ? cv : g;
-          } else {
-            cv = src >= 0 ? cv : 0.f;
+            A.out_cache[gbase + p] = src >= 0 ? hv : g;
           }
-          A.out_cache[gbase + p] = cv;
+        }
+      } else if (A.out_cache) {
+        // lane tl hands over columns 4 tl .. 4 tl + 3 (pad <= 64: one pass) with ONE 16-byte store where the four exist
+        // -- rows of the (B, C, 105) cache are only 4-byte aligned, so through a 4-byte-aligned type -- instead of four
+        // 4-byte stores in four passes
+        struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
+        const int p0 = 4 * tl;
+        if (p0 < pad) {
+          float cv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int src = T + p0 + k - pad;   // index into h (negative: left of the first frame -> zero context)
+            const float v = hbuf[hoff + max(src, 0)];
+            cv[k] = src >= 0 ? v : 0.f;
+          }
+          float* dst = A.out_cache + gbase + p0;
+          if (p0 + 4 <= pad) {
+            *reinterpret_cast<V4*>(dst) = V4{{cv[0], cv[1], cv[2], cv[3]}};
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (p0 + k < pad) dst[k] = cv[k];
+          }
         }
       }
       // row r -> K step r>>5, k-octet (r&31)>>3, half (r&7) of the [k-octet][frame][8] planes
@@ -275,7 +383,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     __syncthreads();
   }
 
-  conv_stack_head<KIND_DS, 256, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
+  conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
+
 }
 
 template <int NT, bool HAS_CACHE, bool SPLIT>

@@ -18,6 +18,18 @@
 
 namespace wekws {
 
+// Geometry: the planes of Geom<KIND_MDTC, 64, NT>, the f32 tile with the conflict-free row stride of ds256_w16.hip.h
+// (16 NT + 4: epilogue rows four apart and the producer's row pairs land 16 banks apart; the lane-groups' channel rows are
+// permuted with w16_row so that the two groups of a 32-lane half write different dwords of the operand planes).
+template <int NT>
+struct M16Geom {
+  using G = Geom<KIND_MDTC, 64, NT>;
+  static constexpr int SS = 16 * NT + 4;
+  static constexpr int S_FLOATS = G::S_FLOATS;
+  static constexpr int H_FLOATS = 2 * 64 * SS;
+  static constexpr size_t LDS_BYTES = size_t(S_FLOATS + H_FLOATS) * 4;
+};
+
 // LCACHE (streaming steps, NT = 1): both streams' whole caches (64 x 244 floats each) live in LDS behind the tile --
 // one coalesced load at entry, taps through a selected LDS address, every slice shifted in place after its block's
 // depthwise conv has read it, one coalesced store at the end -- instead of 17 blocks x 64 short strided runs in and
@@ -25,12 +37,12 @@ namespace wekws {
 // behind this).  HAS_CACHE is ignored then (a missing input cache is a zero-filled one).
 template <int NT, bool HAS_CACHE, bool SPLIT, bool LCACHE = false>
 __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackParams P, const CallArgs A) {
-  using G = Geom<KIND_MDTC, 64, NT>;
+  using G = M16Geom<NT>;
   constexpr int C = 64, U = 2, SS = G::SS, TT = 16 * NT, KS = 5;
   constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of a 64-channel operand
   constexpr int UB = 2 * MPB;                                // bytes of one utterance's planes
   constexpr int NTW = NT < 4 ? NT : 4;                       // frame tiles per wave (frame half fh: tiles 4 fh ..)
-  static_assert(U == G::U && U * UB <= G::S_FLOATS * 4, "planes must fit the shared geometry");
+  static_assert(U == G::G::U && U * UB <= G::S_FLOATS * 4, "planes must fit the shared geometry");
   extern __shared__ __attribute__((aligned(16))) float mdtc16_lds[];
   char* const slab = reinterpret_cast<char*>(mdtc16_lds);    // [utt][hi | lo][8 oct][TT][8 halves]
   float* const hbuf = mdtc16_lds + G::S_FLOATS;              // [utt][64][SS] f32 resident activations
@@ -43,7 +55,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   const int b0 = blockIdx.x * U;
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
-  const int pg = tid >> 4, tl = tid & 15;                    // producer: 64 lane-groups x 16 lanes; group = channel
+  const int pg = w16_row(tid >> 4), tl = tid & 15;           // producer: 64 lane-groups x 16 lanes; pg = the group's channel
   const int wu = wave >> 3, ot = (wave >> 1) & 3, fh = wave & 1;
   const int ft0 = fh * 4;                                    // first frame tile of this wave
   const bool uok = (b0 + wu) < A.B;
@@ -374,12 +386,12 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       for (int e = tid; e < tot; e += kW16Threads) __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(cch)[e], dst + e);
     }
   }
-  conv_stack_head<KIND_MDTC, 64, NT, kW16Threads>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
+  conv_stack_head<KIND_MDTC, 64, NT, kW16Threads, SS>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
 }
 
 template <int NT, bool HAS_CACHE, bool SPLIT>
 inline int launch_mdtc64_w16_ntc(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  using G = Geom<KIND_MDTC, 64, NT>;
+  using G = M16Geom<NT>;
   static DynLdsGrant grant;
   auto kern = mdtc64_w16_kernel<NT, HAS_CACHE, SPLIT>;
   if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
@@ -396,7 +408,7 @@ inline int launch_mdtc64_w16_nt(bool split, const StackParams& P, const CallArgs
                     : launch_mdtc64_w16_ntc<NT, false, false>(P, A, stream);
 }
 
-inline size_t mdtc64_stream_lds_bytes(int cache_len) { return Geom<KIND_MDTC, 64, 1>::LDS_BYTES + size_t(2) * 64 * cache_len * 4; }
+inline size_t mdtc64_stream_lds_bytes(int cache_len) { return M16Geom<1>::LDS_BYTES + size_t(2) * 64 * cache_len * 4; }
 
 template <bool SPLIT>
 inline int launch_mdtc64_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {

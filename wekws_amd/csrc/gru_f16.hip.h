@@ -348,14 +348,9 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wh[g][ks] = load_frag(ahh + (g * 8 + wave) * OTS + ks * 128);
       const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
-      // (a barrier either way: pass I is done with the staging buffers)
-      float hb;
-      if (MODE == 0 && (h0vec || !h0)) {
-        __syncthreads();
-        hb = fmaxf(1.f, amax_read(gru_cells + l));
-      } else {
-        hb = h_bound(l);
-      }
+      // single-launch mode: every layer's cell was published behind pass P's barrier (pass I's last chunk ended with a
+      // barrier too, so the staging buffers are free); otherwise reduce h0[l] now
+      const float hb = (MODE == 0 && (h0vec || !h0)) ? fmaxf(1.f, amax_read(gru_cells + l)) : h_bound(l);
       float chh;
       const float shl = pow2_scale(hb, &chh);
       chh *= Q.hh_inv_s[l];

@@ -11,10 +11,4 @@ int launch_mdtc64_w16(int nt, bool split, const StackParams& P, const CallArgs& 
     default: return -1;
   }
 }
-int launch_mdtc64_stream(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  if (P.ksize != 5 || A.T > 16 || (64 * P.cache_len) % 4 != 0 || mdtc64_stream_lds_bytes(P.cache_len) > 160 * 1024) return -4;
-  for (int i = 0; i < P.nblocks; ++i)
-    if (P.blocks[i].pad > 32) return -4;                      // the in-place slice update moves two floats per lane
-  return split ? launch_mdtc64_stream_s<true>(P, A, stream) : launch_mdtc64_stream_s<false>(P, A, stream);
-}
 }  // namespace wekws

@@ -25,28 +25,27 @@ template <int NT>
 struct M16Geom {
   using G = Geom<KIND_MDTC, 64, NT>;
   static constexpr int SS = 16 * NT + 4;
-  static constexpr int S_FLOATS = G::S_FLOATS;
+  // short tiles (streaming steps) keep the mid tile's planes beside the depthwise planes: GEMM 1's readers and the mid
+  // writers then never meet, which takes one of the four barriers out of every block of the latency chain
+  static constexpr bool kMidOwn = NT <= 2;
+  static constexpr int S_FLOATS = G::S_FLOATS * (kMidOwn ? 2 : 1);
   static constexpr int H_FLOATS = 2 * 64 * SS;
   static constexpr size_t LDS_BYTES = size_t(S_FLOATS + H_FLOATS) * 4;
 };
 
-// LCACHE (streaming steps, NT = 1): both streams' whole caches (64 x 244 floats each) live in LDS behind the tile --
-// one coalesced load at entry, taps through a selected LDS address, every slice shifted in place after its block's
-// depthwise conv has read it, one coalesced store at the end -- instead of 17 blocks x 64 short strided runs in and
-// out per stream with a global-memory latency exposed in every block (see ds256_stream.hip.h for the measurements
-// behind this).  HAS_CACHE is ignored then (a missing input cache is a zero-filled one).
-template <int NT, bool HAS_CACHE, bool SPLIT, bool LCACHE = false>
+// (Streaming steps of <= 16 frames with the caches resident in LDS have their own kernel: mdtc64_stream.hip.h.)
+template <int NT, bool HAS_CACHE, bool SPLIT>
 __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackParams P, const CallArgs A) {
   using G = M16Geom<NT>;
   constexpr int C = 64, U = 2, SS = G::SS, TT = 16 * NT, KS = 5;
   constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of a 64-channel operand
   constexpr int UB = 2 * MPB;                                // bytes of one utterance's planes
   constexpr int NTW = NT < 4 ? NT : 4;                       // frame tiles per wave (frame half fh: tiles 4 fh ..)
-  static_assert(U == G::G::U && U * UB <= G::S_FLOATS * 4, "planes must fit the shared geometry");
+  constexpr bool kMidOwn = G::kMidOwn;
+  static_assert(U == G::G::U && U * UB * (kMidOwn ? 2 : 1) <= G::S_FLOATS * 4, "planes must fit the shared geometry");
   extern __shared__ __attribute__((aligned(16))) float mdtc16_lds[];
   char* const slab = reinterpret_cast<char*>(mdtc16_lds);    // [utt][hi | lo][8 oct][TT][8 halves]
   float* const hbuf = mdtc16_lds + G::S_FLOATS;              // [utt][64][SS] f32 resident activations
-  float* const cch = hbuf + G::H_FLOATS;                     // LCACHE: [utt][64][Pc] the streams' caches
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,6 +65,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   const bool active = ntw > 0;
   const int o0 = ot * 16 + lq * 4;                           // this lane's 4 output channels
   char* const slab_u = slab + wu * UB;
+  char* const mid_u = kMidOwn ? slab + U * UB + wu * UB : slab_u;   // planes of the mid tile (M16Geom::kMidOwn)
   float* const h_w = hbuf + wu * C * SS;
   const int frag_off = (lq * TT + ft0 * 16 + l15) * 16;      // B item of this wave's first tile, K step 0
 
@@ -80,30 +80,44 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   amax_zero<kW16Threads>(amax_cells, U * kAmaxCells);
   stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
+  // Features.  Short tiles of 40-d input (<= 2 K steps, one 8-feature item per thread: NT <= 4) pass through registers
+  // ONCE: loaded here, their maximum published, scaled / split / stored behind the barrier of the preprocessing; a second
+  // trip to memory for the same 3 KB would be step time on the streaming path.  Item = (utt, K step, k-octet, frame); a
+  // wave's items belong to one utterance (2 * 4 * TT is a multiple of 64), so the publishing cell is wave-uniform.
+  const int nk = P.kpre16 / 32;                              // K steps of the input (40-d: 2, 80-d MFCC: 3)
+  const bool one_trip = nk <= 2 && U * 8 * TT <= kW16Threads;
+  W16XItem xi;
+  xi.dst = -1;
+  auto load_item = [&]() __attribute__((always_inline)) {
+    const int t = tid % TT;
+    int q = tid / TT;
+    const int oct = q & 3; q >>= 2;
+    const int st = q % nk, u = q / nk;
+    if (u >= U) return;                                      // (wave-uniform)
+    const int kf = st * 32 + oct * 8;
+    const bool row = (b0 + u) < A.B && t < T;
+    const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
+    xi.dst = u * UB + ((st * 4 + oct) * TT + t) * 16;
+    if (row && kf + 8 <= P.idim && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(xr), c = *reinterpret_cast<const float4*>(xr + 4);
+      xi.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    } else {
+      w16_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (row && kf + i < P.idim) ? xr[i] : 0.f;
+      xi.v = v;
+    }
+    amax_publish(amax_cells + u * kAmaxCells, w16_x_amax(xi));
+  };
+
+  if (one_trip) load_item();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
-      amax_publish(amax_cells + u * kAmaxCells, amax_span<kW16Threads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
-      if (!LCACHE && HAS_CACHE)
+      if (!one_trip)
+        amax_publish(amax_cells + u * kAmaxCells, amax_span<kW16Threads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      if (HAS_CACHE)
         amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
     }
-
-  if constexpr (LCACHE) {                                    // the two streams' caches are contiguous in global memory
-    static_assert(NT == 1, "the LDS-resident cache is for single-tile streaming steps");
-    const int nu = min(U, A.B - b0);
-    const int n4 = (C * Pc) >> 2, tot = U * n4;              // C * Pc % 4 == 0 (host checks)
-    const f32x4* src = reinterpret_cast<const f32x4*>(A.in_cache + int64_t(b0) * C * Pc);
-    float cm[U] = {0.f, 0.f};
-    for (int e = tid; e < tot; e += kW16Threads) {
-      const f32x4 q =                                      // streamed once: non-temporal, the weights stay in L2
-          (A.in_cache && e < nu * n4) ? __builtin_nontemporal_load(src + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-      reinterpret_cast<f32x4*>(cch)[e] = q;
-      const float qm = fmaxf(fmaxf(fabsf(q[0]), fabsf(q[1])), fmaxf(fabsf(q[2]), fabsf(q[3])));
-      if (e < n4) cm[0] = fmaxf(cm[0], qm); else cm[1] = fmaxf(cm[1], qm);
-    }
-    amax_publish(amax_cells + 1, cm[0]);
-    amax_publish(amax_cells + kAmaxCells + 1, cm[1]);
-    // visible to the producers: the preprocessing below ends with a barrier
-  }
 
   // weight fragments of one GEMM (2 K steps, hi | lo)
   auto load_frags = [](F16Frag (&a)[2], const uint4* __restrict__ ap) __attribute__((always_inline)) {
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   // BOTH GEMMs' fragments are requested at the top of the block and arrive behind the depthwise producer (32 registers,
   // free at NT <= 2); long tiles load them at the GEMM, where seven tiles of MFMAs cover the latency.
   constexpr bool kPrefetchW = NT <= 2;
-  auto gemm = [&](const F16Frag (&a)[2]) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes of slab_u
+  auto gemm = [&](const F16Frag (&a)[2], const char* planes) __attribute__((always_inline)) {   // acc = A (2 K steps) x planes
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt)
         if (tt < ntw) {
-          const char* q = slab_u + ks * 4 * TT * 16 + frag_off + tt * 256;
+          const char* q = planes + ks * 4 * TT * 16 + frag_off + tt * 256;
           const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks].h, vh, acc[tt], 0, 0, 0);
           if constexpr (SPLIT) {                             // !SPLIT = WEKWS_HIP_PRECISION_F16: hi halves only
@@ -133,13 +147,66 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         }
   };
 
+  // The vector-side constants of a block: taps + bias of channel pg (8-float record) and the two folded BN biases of this
+  // lane's output channels.
+  struct BlkConst { float4 q0, q1, b1, b2; };
+  auto load_consts = [&](int bi) __attribute__((always_inline)) {
+    const BlockDesc& nb = blk[bi];
+    const float4* src = reinterpret_cast<const float4*>(W + nb.dw_pk + pg * 8);
+    BlkConst k;
+    k.q0 = src[0]; k.q1 = src[1];
+    k.b1 = *reinterpret_cast<const float4*>(W + nb.b1 + o0);
+    k.b2 = *reinterpret_cast<const float4*>(W + nb.b2 + o0);
+    return k;
+  };
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
-    const int nk = P.kpre16 / 32;                            // K steps of the input (40-d: 2, 80-d MFCC: 3)
     const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(ot) * nk * 128 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (one_trip) {
+      F16Frag a[2];
+      if (active) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {                     // in flight over the barriers (nk = 1: the same step twice)
+          const uint4* q = ap + min(st, nk - 1) * 128;
+          a[st].h = __builtin_bit_cast(f16x8, q[0]);
+          a[st].l = __builtin_bit_cast(f16x8, q[64]);
+        }
+      }
+      __syncthreads();                                       // the feature maxima are published
+      if (xi.dst >= 0) {
+        float inv_unused;
+        const float sx = pow2_scale(amax_read(amax_cells + (xi.dst >= UB ? kAmaxCells : 0)), &inv_unused);
+        f16x8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          _Float16 h, l;
+          split16s(xi.v[i], sx, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        *reinterpret_cast<f16x8*>(slab + xi.dst) = vh;
+        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(slab + xi.dst + MPB) = vl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        if (st < nk) {
+#pragma unroll
+          for (int tt = 0; tt < NTW; ++tt)
+            if (tt < ntw) {
+              const char* q = slab_u + st * 4 * TT * 16 + frag_off + tt * 256;
+              const f16x8 vh = *reinterpret_cast<const f16x8*>(q);
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[st].h, vh, acc[tt], 0, 0, 0);
+              if constexpr (SPLIT) {
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(q + MPB);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[st].h, vl, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[st].l, vh, acc[tt], 0, 0, 0);
+              }
+            }
+        }
+    } else
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass (= the planes of an utterance)
       const int steps = min(2, nk - k0);
       __syncthreads();                                       // (first pass: the feature maxima are published)
@@ -212,15 +279,9 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     const int d = bd.dil, pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(ot) * 256 + lane;
     const uint4* ap2 = reinterpret_cast<const uint4*>(W + bd.a2_16) + size_t(ot) * 256 + lane;
-    // taps + bias of channel pg (8-float record)
-    float dww[KS + 1];
-    {
-      const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + pg * 8);
-      const float4 q0 = src[0], q1 = src[1];
-      dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w; dww[4] = q1.x; dww[5] = q1.y;
-    }
-    const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (in flight over the producer)
-    const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0);
+    const BlkConst kc = load_consts(bi);                     // (in flight over the producer's LDS trips)
+    const float dww[KS + 1] = {kc.q0.x, kc.q0.y, kc.q0.z, kc.q0.w, kc.q1.x, kc.q1.y};
+    const float4 bias1 = kc.b1, bias2 = kc.b2;
     F16Frag g1[2], g2[2];
     if constexpr (kPrefetchW) {
       if (active) {
@@ -228,8 +289,10 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         load_frags(g2, ap2);
       }
     }
-    const bool slide = d <= 16 && (16 % d) == 0;
-    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+    // lane tl owns the NT outputs fbase + m d (a run at stride d: the taps slide over NT + KS - 1 register-resident
+    // inputs); one tile: that is frame tl for every dilation, and the division is not worth its 40 instructions
+    const bool slide = NT == 1 || (d <= 16 && (16 % d) == 0);
+    const int fbase = (NT > 1 && slide) ? (tl / d) * NT * d + (tl % d) : tl;
     // operand scales of the depthwise rows, per utterance (bound through the maxima of the input tile and the cache)
     // mid tile: the bound chained behind the depthwise one (BlockDesc::mid_alpha)
     float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;
@@ -246,33 +309,32 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       }
     }
     // ---- producer: lane-group pg makes channel pg of both utterances: depthwise dilated conv + folded BN
-    //      (mdtc.py:55-58, no ReLU), split to fp16 hi/lo planes, and hands the channel's streaming cache over
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    //      (mdtc.py:55-58, no ReLU), split to fp16 hi/lo planes, and hands the channel's streaming cache over.
+    //      NU = utterances this workgroup really has (a compile-time 1 or 2 per call of the lambda: a run-time skip
+    //      inside the loop would fence the two utterances' LDS round trips off from each other).  Single tiles read
+    //      everything of BOTH utterances before the first write: the plane writes of one utterance would otherwise order
+    //      the other's reads behind them.
+    auto produce = [&](auto nu_c) __attribute__((always_inline)) {
+      constexpr int NU = decltype(nu_c)::value;
+      constexpr bool kTwoPhase = NT == 1;
       const int c = pg;
-      const int hoff = (u * C + c) * SS;
-      const bool pok = (b0 + u) < A.B;
-      if (!pok) continue;                                    // (workgroup-uniform: no such utterance)
-      const int64_t gbase = (int64_t(pok ? b0 + u : 0) * C + c) * Pc + bd.cache_off;
-#define fetch(idx_)                                                                      \
+#define fetch(u_, idx_)                                                                  \
   ({                                                                                     \
     const int ix_ = (idx_);                                                              \
-    float fv_;                                                                           \
-    if constexpr (LCACHE) {                                                              \
-      fv_ = *(ix_ >= 0 ? hbuf + hoff + ix_ : crow + pad + ix_);                          \
-    } else {                                                                             \
-    fv_ = hbuf[hoff + ix_];                                                              \
+    const int hoff_ = ((u_) * C + c) * SS;                                               \
+    float fv_ = hbuf[hoff_ + ix_];                                                       \
     if constexpr (HAS_CACHE) {                                                           \
-      const float fg_ = A.in_cache[gbase + pad + min(ix_, -1)];                          \
-      fv_ = ix_ >= 0 ? fv_ : (pok ? fg_ : 0.f);                                          \
+      const float fg_ = A.in_cache[(int64_t(b0 + (u_)) * C + c) * Pc + bd.cache_off + pad + min(ix_, -1)]; \
+      fv_ = ix_ >= 0 ? fv_ : fg_;                                                        \
     } else {                                                                             \
       fv_ = ix_ >= 0 ? fv_ : 0.f;                                                        \
     }                                                                                    \
-    }                                                                                    \
     fv_;                                                                                 \
   })
-      float* const crow = cch + (u * C + c) * Pc + bd.cache_off;   // LCACHE: this block's slice of (stream u, channel c)
-      if (!LCACHE && A.out_cache && pok) {
+      auto hand_over = [&](int u) __attribute__((always_inline)) {   // batch path: the new cache slice goes to global memory
+        if (!A.out_cache) return;
+        const int hoff = (u * C + c) * SS;
+        const int64_t gbase = (int64_t(b0 + u) * C + c) * Pc + bd.cache_off;
         for (int p = tl; p < pad; p += 16) {
           const int src = T + p - pad;   // index into h (negative: still inside the old cache)
           float cv = hbuf[hoff + max(src, 0)];
@@ -284,57 +346,64 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
           }
           A.out_cache[gbase + p] = cv;
         }
-      }
-      _Float16* ph = reinterpret_cast<_Float16*>(slab + u * UB) + ((c >> 3) * TT) * 8 + (c & 7);
-      _Float16* pl = reinterpret_cast<_Float16*>(slab + u * UB + MPB) + ((c >> 3) * TT) * 8 + (c & 7);
+      };
+      auto emit = [&](int u, int t, float o) __attribute__((always_inline)) {
+        _Float16* ph = reinterpret_cast<_Float16*>(slab + u * UB) + ((c >> 3) * TT) * 8 + (c & 7);
+        _Float16 h, l;
+        split16s(o, sa[u], h, l);
+        ph[t * 8] = h;
+        if constexpr (SPLIT) ph[t * 8 + MPB / 2] = l;
+      };
       if (slide) {
-        float v[NT + KS - 1];
+        float v[kTwoPhase ? NU : 1][NT + KS - 1];
+        auto load = [&](int u, int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NT + KS - 1; ++q) {
-          if (q >= KS - 1) v[q] = hbuf[hoff + fbase + (q - (KS - 1)) * d];
-          else v[q] = fetch(fbase + (q - (KS - 1)) * d);
-        }
+          for (int q = 0; q < NT + KS - 1; ++q) {
+            if (q >= KS - 1) v[s][q] = hbuf[(u * C + c) * SS + fbase + (q - (KS - 1)) * d];
+            else v[s][q] = fetch(u, fbase + (q - (KS - 1)) * d);
+          }
+        };
+        auto store = [&](int u, int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < NT; ++m) {
-          float o = dww[KS];
+          for (int m = 0; m < NT; ++m) {
+            float o = dww[KS];
 #pragma unroll
-          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[m + j], o);
-          const int t = fbase + m * d;
-          _Float16 h, l;
-          split16s(o, sa[u], h, l);
-          ph[t * 8] = h;
-          if constexpr (SPLIT) pl[t * 8] = l;
+            for (int j = 0; j < KS; ++j) o = fmaf(dww[j], v[s][m + j], o);
+            emit(u, fbase + m * d, o);
+          }
+        };
+        if constexpr (kTwoPhase) {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) { hand_over(u); load(u, u); }
+#pragma unroll
+          for (int u = 0; u < NU; ++u) store(u, u);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) { hand_over(u); load(u, 0); store(u, 0); }
         }
       } else {
-#pragma unroll 1
-        for (int m = 0; m < NT; ++m) {
-          const int t = tl + 16 * m;
-          float o = dww[KS];
 #pragma unroll
-          for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(t - (KS - 1 - j) * d), o);
-          _Float16 h, l;
-          split16s(o, sa[u], h, l);
-          ph[t * 8] = h;
-          if constexpr (SPLIT) pl[t * 8] = l;
+        for (int u = 0; u < NU; ++u) {
+          hand_over(u);
+#pragma unroll 1
+          for (int m = 0; m < NT; ++m) {
+            const int t = tl + 16 * m;
+            float o = dww[KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) o = fmaf(dww[j], fetch(u, t - (KS - 1 - j) * d), o);
+            emit(u, t, o);
+          }
         }
       }
-      if constexpr (LCACHE) {
-        // new slice = last pad frames of [slice | chunk] (mdtc.py:111), in place: the reads above and these reads
-        // precede every write of the group (same wave, LDS in order); pad <= 32 -> two per lane
-        float nv[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) nv[k] = fetch(min(tl + 16 * k, pad - 1) + T - pad);
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if (tl + 16 * k < pad) crow[tl + 16 * k] = nv[k];
-      }
 #undef fetch
-    }
+    };
+    if (b0 + 1 < A.B) produce(std::integral_constant<int, 2>{});
+    else produce(std::integral_constant<int, 1>{});
     __syncthreads();
     // ---- GEMM 1 (pointwise) over the full K
     if constexpr (!kPrefetchW) { if (active) load_frags(g1, ap1); }
-    if (active) gemm(g1);
-    __syncthreads();                                         // every wave is done reading the depthwise planes
+    if (active) gemm(g1, slab_u);
+    if constexpr (!kMidOwn) __syncthreads();                 // every wave is done reading the depthwise planes
     // ---- mid = ReLU(BN1(pointwise)) written in operand order over them (mdtc.py:113-114)
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -342,7 +411,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
         const int t = (ft0 + tt) * 16 + l15;
         const f32x4 v = __builtin_elementwise_max(acc[tt] * c1 + f32x4{bias1.x, bias1.y, bias1.z, bias1.w}, f32x4{0.f, 0.f, 0.f, 0.f}) * sm;
         const f16x4 vh = __builtin_convertvector(v, f16x4);
-        char* dst = slab_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
+        char* dst = mid_u + (((o0 >> 3) * TT + t) * 8 + (o0 & 7)) * 2;   // 4 consecutive channels = 8 bytes
         *reinterpret_cast<f16x4*>(dst) = vh;
         if constexpr (SPLIT)
           *reinterpret_cast<f16x4*>(dst + MPB) = __builtin_convertvector(v - __builtin_convertvector(vh, f32x4), f16x4);
@@ -350,7 +419,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     __syncthreads();
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), in place into h
     if constexpr (!kPrefetchW) { if (active) load_frags(g2, ap2); }
-    if (active) gemm(g2);
+    if (active) gemm(g2, mid_u);
     float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -379,13 +448,6 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       for (int r = 0; r < 4; ++r) h_w[(o0 + r) * SS + t] = zsum[tt][r];
     }
   __syncthreads();
-  if constexpr (LCACHE) {
-    if (A.out_cache) {
-      const int n4 = (C * Pc) >> 2, tot = min(U, A.B - b0) * n4;
-      f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b0) * C * Pc);
-      for (int e = tid; e < tot; e += kW16Threads) __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(cch)[e], dst + e);
-    }
-  }
   conv_stack_head<KIND_MDTC, 64, NT, kW16Threads, SS>(P, A, hbuf, reinterpret_cast<float*>(slab), b0);
 }
 
@@ -408,21 +470,7 @@ inline int launch_mdtc64_w16_nt(bool split, const StackParams& P, const CallArgs
                     : launch_mdtc64_w16_ntc<NT, false, false>(P, A, stream);
 }
 
-inline size_t mdtc64_stream_lds_bytes(int cache_len) { return M16Geom<1>::LDS_BYTES + size_t(2) * 64 * cache_len * 4; }
-
-template <bool SPLIT>
-inline int launch_mdtc64_stream_s(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  static DynLdsGrant grant;
-  const size_t lds = mdtc64_stream_lds_bytes(P.cache_len);
-  auto kern = mdtc64_w16_kernel<1, false, SPLIT, true>;
-  if (grant_dynamic_lds(kern, int(lds), grant)) return -3;
-  hipLaunchKernelGGL(kern, dim3((A.B + 1) / 2), dim3(kW16Threads), lds, stream, P, A);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
 // usable when: hidden_dim 64, kernel size 5 (host checks); split as in launch_ds256_w16
 int launch_mdtc64_w16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
-// streaming step (A.T <= 16) with both streams' caches resident in LDS; needs the caches to fit (host checks)
-int launch_mdtc64_stream(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

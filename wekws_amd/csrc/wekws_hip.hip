@@ -22,6 +22,7 @@
 #include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
 #include "mdtc64_w16.hip.h"
+#include "mdtc64_stream.hip.h"
 #include "fbank.hip.h"
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
@@ -249,6 +250,7 @@ struct wekws_hip_model {
   bool mm_ok = false;     // ... and does: default for CTC-sized heads (odim > 16); WEKWS_HIP_OPT_MM forces it on / off
                           // (keyword heads: the 16-wave kernel is 12 % faster)
   bool mdtc16_eligible = false;
+  bool mdtc_stream_eligible = false;   // mdtc64_stream.hip.h: dilations 1 / 2 / 4 / 8, the two streams' caches fit into LDS
   bool mdtc16_ok = false; // MDTC h64: the 16-wave kernel (WEKWS_HIP_OPT_MDTC16 = 0: the generic 8-wave one)
   bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
   int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, 0 / 1 off, n forces n
@@ -677,6 +679,10 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     m->mdtc16_eligible = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
     m->mdtc16_ok = m->mdtc16_eligible;
+    m->mdtc_stream_eligible = m->mdtc16_eligible && sp.kpre16 <= 128 && (64 * off) % 4 == 0 &&
+                              wekws::mdtc64_stream_lds_bytes(off) <= 158 * 1024;
+    for (const auto& bb : blocks)
+      if (!(bb.dil == 1 || bb.dil == 2 || bb.dil == 4 || bb.dil == 8) || bb.pad != 4 * bb.dil) m->mdtc_stream_eligible = false;
     m->mm_eligible = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
                      d.head == WEKWS_HIP_HEAD_LINEAR;
     // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword heads
@@ -928,8 +934,8 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           // LDS-resident caches cost the second workgroup per CU: clear win while the call fits one round of workgroups
           // (0.058 vs 0.081 ms at 256 streams, 0.060 vs 0.094 at 512), within +-5 % up to 2048 streams (0.111 / 0.104 at
           // 768, 0.170 / 0.193 at 1536), a tie beyond -- where the batch kernel is kept
-          rc = (f16 && m->mdtc16_ok && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) && cache16 && d.stack_size <= 4 &&
-                B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256) && wekws::mdtc64_stream_lds_bytes(m->cache_len) <= 160 * 1024)
+          rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
+                cache16 && B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256))
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

@@ -210,9 +210,30 @@ __device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q
 // ---------------------------------------------------------------------------------------------
 // Classifier head on the resident tile (shared by the f32 and the split-fp16 kernels).  `slab` is free scratch.
 // ---------------------------------------------------------------------------------------------
-// SSX: row stride of the resident tile when the caller lays it out itself (0: Geom's)
-template <int KIND, int C, int NT, int NTHR = kThreads, int SSX = 0>
-__device__ __forceinline__ void conv_stack_head(const StackParams& P, const CallArgs& A, float* hbuf, float* slab, int b0) {
+// The classifier of a small linear head, one value per thread, requested EARLY by the latency kernels (streaming steps) so
+// that the head does not start with a trip to L2; conv_stack_head() takes it instead of staging the weights itself.
+struct HeadPre {
+  float w, b;
+  bool valid;
+};
+template <int KIND, int C, int NT, int NTHR>
+__device__ __forceinline__ HeadPre conv_stack_head_prefetch(const StackParams& P) {
+  using G = Geom<KIND, C, NT>;
+  HeadPre hp = {0.f, 0.f, false};
+  const int K = P.odim, tid = threadIdx.x;
+  if (P.head == HEAD_LINEAR && K * (C + 1) <= G::S_FLOATS && K * C <= NTHR) {
+    hp.valid = true;
+    if (tid < K * C) hp.w = P.w[P.head_w + tid];
+    if (tid < K) hp.b = P.w[P.head_b + tid];
+  }
+  return hp;
+}
+
+// SSX: row stride of the resident tile when the caller lays it out itself (0: Geom's).  SWZ: row c starts at
+// c * SS + (c & 3) (ds256_stream.hip.h: the skew spreads four-row groups over the LDS banks).
+template <int KIND, int C, int NT, int NTHR = kThreads, int SSX = 0, bool SWZ = false>
+__device__ __forceinline__ void conv_stack_head(const StackParams& P, const CallArgs& A, float* hbuf, float* slab, int b0,
+                                                const HeadPre* pre = nullptr) {
   using G = Geom<KIND, C, NT>;
   constexpr int U = G::U, SS = SSX ? SSX : G::SS;
   const int tid = threadIdx.x;
@@ -224,15 +245,21 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     // small heads: classifier weights staged in the (now free) slab, read back as LDS broadcasts
     const bool staged = K * (C + 1) <= G::S_FLOATS;
     if (staged) {
-      for (int e = tid; e < K * C; e += NTHR) slab[e] = W[P.head_w + e];
-      for (int e = tid; e < K; e += NTHR) slab[K * C + e] = W[P.head_b + e];
+      if (pre && pre->valid) {
+        if (tid < K * C) slab[tid] = pre->w;
+        if (tid < K) slab[K * C + tid] = pre->b;
+      } else {
+        for (int e = tid; e < K * C; e += NTHR) slab[e] = W[P.head_w + e];
+        for (int e = tid; e < K; e += NTHR) slab[K * C + e] = W[P.head_b + e];
+      }
       __syncthreads();
     }
     const float* wsrc = staged ? slab : W + P.head_w;
     const float* bsrc = staged ? slab + K * C : W + P.head_b;
     const int nout = U * K * T;
     // few outputs (K = 1..2 keywords): split the channel sum over PARTS threads per output and combine through the
-    // slab tail, so that all eight waves work instead of the first three
+    // slab tail, so that all eight waves work instead of the first three.  (16 parts on a 10-frame streaming step
+    // measured slower than 4: the second stage's serial sum grows faster than the first stage shrinks.)
     const int PARTS = (staged && nout * 4 <= NTHR && K * (C + 1) + 4 * nout <= G::S_FLOATS) ? 4
                     : (staged && nout * 2 <= NTHR && K * (C + 1) + 2 * nout <= G::S_FLOATS) ? 2 : 1;
     float* part = slab + K * (C + 1);
@@ -248,10 +275,10 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
 #pragma unroll 4
       for (int c = c0; c < c1; c += 4) {
         const float4 w4 = *reinterpret_cast<const float4*>(wk + c);
-        s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);
-        s1 = fmaf(w4.y, hc[(c + 1) * SS], s1);
-        s2 = fmaf(w4.z, hc[(c + 2) * SS], s2);
-        s3 = fmaf(w4.w, hc[(c + 3) * SS], s3);
+        s0 = fmaf(w4.x, hc[(c + 0) * SS], s0);               // (c % 4 == 0: the skew of row c + i is i)
+        s1 = fmaf(w4.y, hc[(c + 1) * SS + (SWZ ? 1 : 0)], s1);
+        s2 = fmaf(w4.z, hc[(c + 2) * SS + (SWZ ? 2 : 0)], s2);
+        s3 = fmaf(w4.w, hc[(c + 3) * SS + (SWZ ? 3 : 0)], s3);
       }
       const float sum = (s0 + s1) + (s2 + s3);
       if (PARTS > 1) {
@@ -281,7 +308,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
       const int ut = e / C;
       const int u = ut / T, t = ut - u * T;
       if (b0 + u >= A.B) continue;
-      float v = hbuf[(u * C + c) * SS + t];
+      float v = hbuf[(u * C + c) * SS + (SWZ ? (c & 3) : 0) + t];
       if (P.sigmoid) v = sigmoidf_(v);
       A.y[int64_t(b0 + u) * A.ys_b + int64_t(t) * C + c] = v;
     }
@@ -292,7 +319,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
     const int HH = P.head_hidden;
     for (int e = tid; e < U * C; e += NTHR) {
       const int u = e / C, c = e - u * C;
-      const float* hc = hbuf + (u * C + c) * SS;
+      const float* hc = hbuf + (u * C + c) * SS + (SWZ ? (c & 3) : 0);
       float s;
       if (P.head == HEAD_GLOBAL) {
         s = 0.f;

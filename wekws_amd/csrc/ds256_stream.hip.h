@@ -14,6 +14,17 @@
 //   update each slice in place after its block's depthwise conv has read it (shift left by T, append the chunk),
 //   store  the new cache with one coalesced pass at the end.
 // Arithmetic and operation order are those of the batch kernel: bit-identical results (tests).
+//
+// Shape of a block (round 2; per-phase clock64 stamps, build/probe): with ONE output per lane and channel (lane = frame)
+// the depthwise phase was 7.3 k of a block's 10.3 k cycles -- ~300 vector instructions per wave of which 32 are the
+// taps' FMAs; the rest was per-output tap addressing, cache / tile selects and the slice shift, times four waves per
+// SIMD.  Now lane = (channel, quarter): FOUR outputs per lane as a run at stride = dilation (d = 8: two runs of two), the
+// eight taps sliding over 11 register-resident inputs, dilation a compile-time constant per switch arm (offsets are
+// instruction immediates, and for d >= 4 every left-context input is known to come from the cache: no selects).  The
+// taps of the next block are requested a block ahead.  The block's 262 KB of weights stream through the CU's 64 B/clk
+// path (4.1 k cycles, the floor of a block): K steps 0..3 behind the depthwise phase, 4..7 behind the matrix phase, through
+// the same 32 registers (all eight up front do not fit the 128-register budget of four waves per SIMD).  Tile rows are skewed (row c starts at 20 c + c % 4) so that the 8
+// channels x 4 quarters of a 32-lane half read 32 different LDS banks at d = 1.
 #pragma once
 #include "ds256_w16.hip.h"
 
@@ -36,13 +47,43 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   const int b = blockIdx.x;                                  // one stream per workgroup
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
-  const int pg = w16_row(tid >> 4), tl = tid & 15;           // (row permutation: ds256_w16.hip.h)
+  const int pc = tid >> 2, g = tid & 3;                      // producer: channel, quarter
+  auto hoff = [](int c) __attribute__((always_inline)) { return c * SS + (c & 3); };   // skewed tile rows (header)
   const int o0 = wave * 16 + lq * 4;
   const int frag_off = (lq * TT + l15) * 16;
   const int n4 = (C * Pc) >> 2;                              // float4 items of one stream's cache (C * Pc % 4 == 0)
 
+  f32x4 acc[1][NT];
+
+  // ---- block floating point (conv_stack_f16.hip.h): maximum of the chunk's features now, of the carried cache when
+  //      its registers are committed to LDS below
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  // Every load of the prologue is requested before the first barrier -- the block table, the features, the preprocessing
+  // fragments, the classifier, and LAST the cache -- so that the step starts with one trip to memory, not one per dependency.
+  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
+  const int tbl_n = P.nblocks * int(sizeof(BlockDesc) / 4);  // <= 24 x 21 dwords: one per thread
+  uint32_t tbl_v = 0;
+  if (tid < tbl_n) tbl_v = reinterpret_cast<const uint32_t*>(P.blocks)[tid];
+  const int nk = P.kpre16 / 32;
+  const bool one_trip = nk <= 2 && w16_x_vec_ok(A.x, A.xs_b, P.idim);   // 40-d fbank: the features pass through registers once
+  W16XItem xi;
+  if (one_trip) xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+  const uint4* const ap_pre = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
+  const float4 bias_pre = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+  F16Frag a_pre[2];
+  if (one_trip) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {                         // (nk = 1: the same step twice)
+      const uint4* q = ap_pre + min(st, nk - 1) * 128;
+      a_pre[st].h = __builtin_bit_cast(f16x8, q[0]);
+      a_pre[st].l = __builtin_bit_cast(f16x8, q[64]);
+    }
+  }
+  const HeadPre head_pre = conv_stack_head_prefetch<KIND_DS, 256, 1, kW16Threads>(P);
   // ---- the cache comes in with one coalesced pass (or as zeros: kws_model.py:67-69, empty cache == zero padding).
-  //      The loads are issued here and committed to LDS after the preprocessing GEMM, so their latency is covered.
+  //      The loads are issued here -- BEHIND the table, the features and the preprocessing weights, because loads return in
+  //      order and the preprocessing must not wait for this trip to HBM -- and committed to LDS after the preprocessing GEMM.
   constexpr int kCV = 7;                                     // float4 items per thread: 256 * 105 / 4 / 1024 -> 7
   const bool has_cache = A.in_cache != nullptr;              // unconditional clamped loads: the array stays in registers
   const f32x4* const csrc = has_cache ? reinterpret_cast<const f32x4*>(A.in_cache + int64_t(b) * C * Pc)
@@ -52,39 +93,19 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
   for (int k = 0; k < kCV; ++k)                              // streamed once: keep it out of the weights' way in L2
     cv[k] = __builtin_nontemporal_load(csrc + min(tid + k * kW16Threads, has_cache ? n4 - 1 : 0));
 
-  f32x4 acc[1][NT];
-
-  // ---- block floating point (conv_stack_f16.hip.h): maximum of the chunk's features now, of the carried cache when
-  //      its registers are committed to LDS below
-  __shared__ AmaxCell amax_cells[kAmaxCells];
-  __shared__ BlockDesc blk[kAmaxMaxBlocks];
-  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
-  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
+  if (tid < tbl_n) reinterpret_cast<uint32_t*>(blk)[tid] = tbl_v;
   __syncthreads();
-  const int nk = P.kpre16 / 32;
-  const bool one_trip = nk <= 2;                             // 40-d fbank: the features pass through registers once
-  W16XItem xi;
-  if (one_trip) {
-    xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
-    amax_publish(amax_cells, w16_x_amax(xi));
-  } else {
-    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
-  }
+  if (one_trip) amax_publish(amax_cells, w16_x_amax(xi));
+  else amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
     zero_acc(acc);
-    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
-    const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    const uint4* ap = ap_pre;
+    const float4 bias = bias_pre;
     float sx = 1.f, cpre = 1.f;
     if (one_trip) {
-      F16Frag a[2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {                       // in flight over the barriers (nk = 1: the same step twice)
-        const uint4* q = ap + min(st, nk - 1) * 128;
-        a[st].h = __builtin_bit_cast(f16x8, q[0]);
-        a[st].l = __builtin_bit_cast(f16x8, q[64]);
-      }
+      const F16Frag (&a)[2] = a_pre;
       __syncthreads();
       sx = pow2_scale(amax_read(amax_cells), &cpre);
       w16_store_x<PB, SPLIT>(xi, sx, slab);
@@ -130,7 +151,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     for (int r = 0; r < 4; ++r) {
       float v = fmaf(acc[0][0][r], cpre, f4c(bias, r));
       if (P.pre_relu) v = fmaxf(v, 0.f);
-      hbuf[(o0 + r) * SS + l15] = v;
+      hbuf[hoff(o0 + r) + l15] = v;
       hmax = fmaxf(hmax, fabsf(v));
     }
     amax_publish(amax_cells + 2, hmax);
@@ -149,64 +170,97 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 
   // ======================================= residual blocks =======================================
   // One 16-frame tile: the operand planes of all 256 channels fit the slab (16 KB), so a block is
-  //   [every lane-group produces 4 channel rows] barrier [8 K steps x 3 products] [epilogue] barrier
-  // -- two barriers per block instead of the batch kernel's nine; at ten frames of work per step the barriers and the
-  // latencies behind them are the step time.
+  //   [every lane makes 4 outputs of its channel] barrier [8 K steps x 3 products] [epilogue] barrier
+  // -- two barriers per block instead of the batch kernel's nine.
   constexpr int OTS = (C / 32) * 128;
   auto ldfrag = [](F16Frag& f, const uint4* __restrict__ q) __attribute__((always_inline)) {
     f.h = __builtin_bit_cast(f16x8, q[0]);
     f.l = __builtin_bit_cast(f16x8, q[64]);
   };
+  struct TapRec { float4 q0, q1, q2; };                      // taps + bias of channel pc (12-float record)
+  auto load_taps = [&](int bi) __attribute__((always_inline)) {
+    const float4* src = reinterpret_cast<const float4*>(W + blk[bi].dw_pk + pc * 12);
+    return TapRec{src[0], src[1], src[2]};
+  };
+  // Producer body for dilation D (compile time).  Lane (pc, g) makes NR runs of R outputs at stride D (R = min(4, 16 / D)):
+  // run i = g NR + r starts at frame f0 = (i / D) R D + i % D and reads the R + 7 frames f0 + (q - 7) D -- from the tile
+  // where that is >= 0, else from the block's cache slice (pad = 7 D frames, tcn.py:41-52).  Then the slice is shifted in
+  // place: new slice = last pad frames of [slice | chunk] (tcn.py:52); a row belongs to one wave and every read precedes
+  // the writes (LDS is in order within a wave).
+  auto produce = [&](auto d_c, const BlockDesc& bd, const TapRec& tc, float sa) __attribute__((always_inline)) {
+    constexpr int D = decltype(d_c)::value;
+    constexpr int R = (16 / D) < 4 ? (16 / D) : 4, NR = 4 / R, PAD = 7 * D;
+    constexpr int kMaxF0 = D == 1 ? 12 : D == 2 ? 9 : D == 4 ? 3 : 7;   // largest first frame of a run
+    const float dww[KS + 1] = {tc.q0.x, tc.q0.y, tc.q0.z, tc.q0.w, tc.q1.x, tc.q1.y, tc.q1.z, tc.q1.w, tc.q2.x};
+    const float* hrow = hbuf + hoff(pc);
+    float* crow = cch + pc * Pc + bd.cache_off;
+    char* const plane = slab + (pc >> 5) * 2 * PB;           // K step pc / 32
+    _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((pc & 31) >> 3) * TT) * 8 + (pc & 7);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {                           // (run by run: one window of registers at a time)
+      const int i = g * NR + r;
+      const int f0 = (i / D) * R * D + (i % D);
+      const float* tb = hrow + f0 - PAD;                     // tile address of input q = 0 (may lie left of the row)
+      const float* cb = crow + f0;                           // cache address of input q = 0
+      float win[R + 7];
+#pragma unroll
+      for (int q = 0; q < R + 7; ++q) {
+        if (q >= 7) win[q] = tb[q * D];
+        else if (kMaxF0 + (q - 7) * D < 0) win[q] = cb[q * D];             // (compile time: always left of the chunk)
+        else win[q] = *((f0 >= (7 - q) * D) ? tb + q * D : cb + q * D);
+      }
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        float o = dww[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) o = fmaf(dww[j], win[m + j], o);
+        o = fmaxf(o, 0.f);
+        const int t = f0 + m * D;
+        _Float16 h, l;
+        split16s(o, sa, h, l);
+        ph[t * 8] = h;
+        if constexpr (SPLIT) ph[t * 8 + PB / 2] = l;
+      }
+    }
+    // the slice moves left by T in ascending chunks of four elements per lane: element p is overwritten only after its
+    // old value has been read as the source of element p - T (an earlier or the same chunk)
+    constexpr int NS = (PAD + 3) / 4;                        // slice elements per lane: p = g + 4 k
+#pragma unroll
+    for (int k0 = 0; k0 < NS; k0 += 4) {
+      float nv[4];
+#pragma unroll
+      for (int k = k0; k < k0 + 4 && k < NS; ++k) {
+        const int sidx = T + g + 4 * k;                      // index into [slice | chunk]
+        nv[k - k0] = *(sidx < PAD ? crow + sidx : hrow + (sidx - PAD));   // (p >= PAD, last k only: read, not written)
+      }
+#pragma unroll
+      for (int k = k0; k < k0 + 4 && k < NS; ++k)
+        if (PAD % 4 == 0 || k + 1 < NS || g + 4 * k < PAD) crow[g + 4 * k] = nv[k - k0];
+    }
+  };
+
+  TapRec tnext = {};
+  if (P.nblocks > 0) tnext = load_taps(0);
   for (int bi = 0; bi < P.nblocks; ++bi) {
-    const BlockDesc bd = blk[bi];
-    const int d = bd.dil, pad = bd.pad;
+    const BlockDesc& bd = blk[bi];
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
-    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
+    const TapRec tc = tnext;
     F16Frag af[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) ldfrag(af[s4], ap1 + s4 * 128);   // K steps 0..3, in flight over the producer
+    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
     // operand scale of this block (same rule and same numbers as the batch kernel: bit-identical results)
     float c1;
     const float sa = pow2_scale(fmaf(bd.dw_alpha, fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)), bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
-
-    // ---- producer: lane-group pg makes channels pg, pg + 64, pg + 128, pg + 192; lane tl = frame tau of the chunk
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = pg + 64 * i;
-      float dww[KS + 1];
-      {
-        const float4* src = reinterpret_cast<const float4*>(W + bd.dw_pk + c * 12);
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-        dww[0] = q0.x; dww[1] = q0.y; dww[2] = q0.z; dww[3] = q0.w;
-        dww[4] = q1.x; dww[5] = q1.y; dww[6] = q1.z; dww[7] = q1.w;
-        dww[8] = q2.x;
-      }
-      const float* const hrow = hbuf + c * SS;               // frames 0..15 of the chunk
-      float* const crow = cch + c * Pc + bd.cache_off;       // this block's slice: frames -pad..-1
-      // the padded sequence [slice | chunk] at chunk-relative frame ix, one LDS read through a selected address
-      auto at = [&](int ix) __attribute__((always_inline)) -> float { return *(ix >= 0 ? hrow + ix : crow + pad + ix); };
-      float o = dww[KS];
-#pragma unroll
-      for (int j = 0; j < KS; ++j) o = fmaf(dww[j], at(tl - (KS - 1 - j) * d), o);
-      // new slice = last pad frames of [slice | chunk] (tcn.py:52), in place: every lane reads before any lane of the
-      // group writes (same wave, LDS in order)
-      float nv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) nv[k] = at(min(tl + 16 * k, pad - 1) + T - pad);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (tl + 16 * k < pad) crow[tl + 16 * k] = nv[k];
-      o = fmaxf(o, 0.f);
-      _Float16 h, l;
-      split16s(o, sa, h, l);
-      char* const plane = slab + (c >> 5) * 2 * PB;          // K step c / 32
-      _Float16* ph = reinterpret_cast<_Float16*>(plane) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
-      _Float16* pl = reinterpret_cast<_Float16*>(plane + PB) + (((c & 31) >> 3) * TT) * 8 + (c & 7);
-      ph[tl * 8] = h;
-      if constexpr (SPLIT) pl[tl * 8] = l;
+    switch (bd.dil) {
+      case 1: produce(std::integral_constant<int, 1>{}, bd, tc, sa); break;
+      case 2: produce(std::integral_constant<int, 2>{}, bd, tc, sa); break;
+      case 4: produce(std::integral_constant<int, 4>{}, bd, tc, sa); break;
+      default: produce(std::integral_constant<int, 8>{}, bd, tc, sa); break;     // (host: dilations are 1 / 2 / 4 / 8)
     }
     zero_acc(acc);
+    tnext = load_taps(min(bi + 1, P.nblocks - 1));           // (a block ahead: the producer cannot start without them)
     __syncthreads();
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -221,7 +275,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     float hmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float* hp = hbuf + (o0 + r) * SS + l15;
+      float* hp = hbuf + hoff(o0 + r) + l15;
       const float v = fmaxf(fmaf(acc[0][0][r], c1, f4c(ebias, r)), 0.f) + *hp;
       *hp = v;
       hmax = fmaxf(hmax, fabsf(v));
@@ -236,7 +290,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
     f32x4* dst = reinterpret_cast<f32x4*>(A.out_cache + int64_t(b) * C * Pc);
     for (int e = tid; e < n4; e += kW16Threads) __builtin_nontemporal_store(src[e], dst + e);
   }
-  conv_stack_head<KIND_DS, 256, 1, kW16Threads, SS>(P, A, hbuf, reinterpret_cast<float*>(slab), b);
+  conv_stack_head<KIND_DS, 256, 1, kW16Threads, SS, true>(P, A, hbuf, reinterpret_cast<float*>(slab), b, &head_pre);
 }
 
 inline size_t ds256_stream_lds_bytes(int cache_len) {       // slab 16 KB + chunk 16 KB + cache

@@ -42,12 +42,25 @@ constexpr int kW16Waves = 16;
 // Preprocessing input of one utterance for feature dims up to 64 (two K steps = one slab fill): every thread owns at most
 // ONE item (step, k-octet, frame) = 8 consecutive features of a frame.  The features make one trip from memory: they are
 // loaded into registers, their maximum is published (block floating point), and after the barrier the same registers are
-// scaled, split and stored as operand planes.  Returns the thread's 8 features (zeros where there are none).
+// scaled, split and stored as operand planes.
+// The load is UNCONDITIONAL and branch-free (an item without features reads a valid dummy address and is zeroed where it
+// is used): two control-flow arms producing the item made the compiler wait for the load right where the arms merge --
+// one exposed trip to memory at the head of every kernel.  That needs whole, 16-byte aligned items: w16_x_vec_ok().
 typedef float w16_f32x8 __attribute__((ext_vector_type(8)));   // (a plain float[8] member ends up in scratch)
 struct W16XItem {
   w16_f32x8 v;
   int dst;                                                   // byte offset of the item's hi slot in the slab, -1: no item
+  bool ok;                                                   // v holds features (else: dummy data, the item is zeros)
 };
+__device__ __forceinline__ bool w16_x_vec_ok(const float* x, int64_t xs_b, int idim) {   // (kernel-uniform)
+  return idim % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && xs_b % 4 == 0;
+}
+__device__ __forceinline__ void w16_fetch_x(W16XItem& it, const float* xr, const float* dummy, bool ok) {
+  const float* p = ok ? xr : dummy;
+  const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+  it.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  it.ok = ok;
+}
 template <int TT, int PB>
 __device__ __forceinline__ W16XItem w16_load_x(const float* __restrict__ xb, int T, int idim, int nk) {
   W16XItem it;
@@ -57,37 +70,32 @@ __device__ __forceinline__ W16XItem w16_load_x(const float* __restrict__ xb, int
   const int kf = st * 32 + oct * 8;
   const bool has = e < nk * 4 * TT;
   it.dst = has ? st * 2 * PB + (oct * TT + t) * 16 : -1;
-  const float* xr = xb + int64_t(t) * idim + kf;
-  const bool row = has && t < T;
-  if (row && kf + 8 <= idim && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
-    const float4 a = *reinterpret_cast<const float4*>(xr), c = *reinterpret_cast<const float4*>(xr + 4);
-    it.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-  } else {
-    w16_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (row && kf + i < idim) ? xr[i] : 0.f;
-    it.v = v;
-  }
+  w16_fetch_x(it, xb + int64_t(t) * idim + kf, xb, has && t < T && kf < idim);
   return it;
 }
 __device__ __forceinline__ float w16_x_amax(const W16XItem& it) {
   float m = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(it.v[i]));
-  return m;
+  return it.ok ? m : 0.f;
 }
-template <int PB, bool SPLIT>
-__device__ __forceinline__ void w16_store_x(const W16XItem& it, float sx, char* slab) {
+// scale, split and store the item at slab + dst (hi) / + lo_off (lo)
+template <bool SPLIT>
+__device__ __forceinline__ void w16_put_x(const W16XItem& it, float sx, char* slab, int lo_off) {
   if (it.dst < 0) return;
   f16x8 vh, vl;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     _Float16 h, l;
-    split16s(it.v[i], sx, h, l);
+    split16s(it.ok ? it.v[i] : 0.f, sx, h, l);
     vh[i] = h; vl[i] = l;
   }
   *reinterpret_cast<f16x8*>(slab + it.dst) = vh;
-  if constexpr (SPLIT) *reinterpret_cast<f16x8*>(slab + it.dst + PB) = vl;
+  if constexpr (SPLIT) *reinterpret_cast<f16x8*>(slab + it.dst + lo_off) = vl;
+}
+template <int PB, bool SPLIT>
+__device__ __forceinline__ void w16_store_x(const W16XItem& it, float sx, char* slab) {
+  w16_put_x<SPLIT>(it, sx, slab, PB);
 }
 
 // Which of the 64 channel rows of a K interval lane-group pg (= tid >> 4) produces.  A wave's four lane-groups are the
@@ -144,7 +152,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
   const int nk = P.kpre16 / 32;
-  const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads;    // 40-d fbank: the features pass through registers once
+  // 40-d fbank: the features pass through registers once
+  const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
   W16XItem xi;
   if (one_trip) {
     xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_stream_kernel(const StackP
   float cm[U] = {0.f, 0.f};
   W16XItem xi;
   xi.dst = -1;
+  xi.ok = true;                                              // (an item without features is loaded as zeros)
   F16Frag apre[4];
   struct TapConst { float4 q0, q1; };                        // producer: taps + bias of channel pc (8-float record)
   struct BiasConst { float4 b1, b2; };                       // matrix waves: the folded BN biases of this lane's channels

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
   // trip to memory for the same 3 KB would be step time on the streaming path.  Item = (utt, K step, k-octet, frame); a
   // wave's items belong to one utterance (2 * 4 * TT is a multiple of 64), so the publishing cell is wave-uniform.
   const int nk = P.kpre16 / 32;                              // K steps of the input (40-d: 2, 80-d MFCC: 3)
-  const bool one_trip = nk <= 2 && U * 8 * TT <= kW16Threads;
+  const bool one_trip = nk <= 2 && U * 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
   W16XItem xi;
   xi.dst = -1;
   auto load_item = [&]() __attribute__((always_inline)) {
@@ -95,18 +95,8 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     const int st = q % nk, u = q / nk;
     if (u >= U) return;                                      // (wave-uniform)
     const int kf = st * 32 + oct * 8;
-    const bool row = (b0 + u) < A.B && t < T;
-    const float* xr = A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf;
     xi.dst = u * UB + ((st * 4 + oct) * TT + t) * 16;
-    if (row && kf + 8 <= P.idim && (reinterpret_cast<uintptr_t>(xr) & 15) == 0) {
-      const float4 a = *reinterpret_cast<const float4*>(xr), c = *reinterpret_cast<const float4*>(xr + 4);
-      xi.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-    } else {
-      w16_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (row && kf + i < P.idim) ? xr[i] : 0.f;
-      xi.v = v;
-    }
+    w16_fetch_x(xi, A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf, A.x, (b0 + u) < A.B && t < T && kf < P.idim);
     amax_publish(amax_cells + u * kAmaxCells, w16_x_amax(xi));
   };
 
@@ -179,15 +169,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       if (xi.dst >= 0) {
         float inv_unused;
         const float sx = pow2_scale(amax_read(amax_cells + (xi.dst >= UB ? kAmaxCells : 0)), &inv_unused);
-        f16x8 vh, vl;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          _Float16 h, l;
-          split16s(xi.v[i], sx, h, l);
-          vh[i] = h; vl[i] = l;
-        }
-        *reinterpret_cast<f16x8*>(slab + xi.dst) = vh;
-        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(slab + xi.dst + MPB) = vl;
+        w16_put_x<SPLIT>(xi, sx, slab, MPB);
       }
       __syncthreads();
 #pragma unroll

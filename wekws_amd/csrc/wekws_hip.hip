@@ -250,6 +250,7 @@ struct wekws_hip_model {
   bool mm_ok = false;     // ... and does: default for CTC-sized heads (odim > 16); WEKWS_HIP_OPT_MM forces it on / off
                           // (keyword heads: the 16-wave kernel is 12 % faster)
   bool mdtc16_eligible = false;
+  bool ds_stream_eligible = false;     // ds256_stream.hip.h: C = 256, kernel size 8, dilations 1 / 2 / 4 / 8
   bool mdtc_stream_eligible = false;   // mdtc64_stream.hip.h: dilations 1 / 2 / 4 / 8, the two streams' caches fit into LDS
   bool mdtc16_ok = false; // MDTC h64: the 16-wave kernel (WEKWS_HIP_OPT_MDTC16 = 0: the generic 8-wave one)
   bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
@@ -678,6 +679,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
     m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
     m->mdtc16_eligible = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
+    m->ds_stream_eligible = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8;
+    for (const auto& bb : blocks)
+      if (!(bb.dil == 1 || bb.dil == 2 || bb.dil == 4 || bb.dil == 8) || bb.pad != 7 * bb.dil) m->ds_stream_eligible = false;
     m->mdtc16_ok = m->mdtc16_eligible;
     m->mdtc_stream_eligible = m->mdtc16_eligible && sp.kpre16 <= 128 && (64 * off) % 4 == 0 &&
                               wekws::mdtc64_stream_lds_bytes(off) <= 158 * 1024;
@@ -914,7 +918,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
       // (the streaming kernels move whole caches with 16-byte accesses: both cache pointers must be 16-byte aligned)
       const bool cache16 = (reinterpret_cast<uintptr_t>(in_cache) | reinterpret_cast<uintptr_t>(out_cache)) % 16 == 0;
-      const bool strm = f16 && d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && m->w16_ok && !m->mm_ok &&
+      const bool strm = f16 && m->ds_stream_eligible && m->w16_ok && !m->mm_ok &&
                         m->stream_ok && ntiles == 1 && T <= 16 && d.kernel_size == 8 && (in_cache || out_cache) && cache16 &&
                         wekws::ds256_stream_lds_bytes(m->cache_len) <= 160 * 1024;
       switch (d.backbone) {
@@ -935,7 +939,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           // (0.058 vs 0.081 ms at 256 streams, 0.060 vs 0.094 at 512), within +-5 % up to 2048 streams (0.111 / 0.104 at
           // 768, 0.170 / 0.193 at 1536), a tie beyond -- where the batch kernel is kept
           rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
-                cache16 && B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256))
+                cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0 && B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256))
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

@@ -45,7 +45,8 @@ struct GruF16Params {
 struct GruF16Workspace {
   char* seq[2];             // ping-pong layer sequences, operand planes
   float* gi;                // gate pre-activations of the layer in flight
-  float* sc;                // [stream tile][t]: 1 / scale of the preprocessing output planes of step t
+  float* sc;                // [stream tile][t][16]: 1 / scale of the preprocessing output planes of step t ([0]: the
+                            // whole tile; time-packed mode: one per stream slot)
 };
 
 template <int NN>
@@ -59,7 +60,7 @@ struct GruF16Geom {
                                                             // for its two [hi | lo] plane buffers of h
   static size_t seq_bytes(int B, int T) { return size_t((B + MB - 1) / MB) * T * SEQ_STEP; }
   static size_t gi_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * GI_STEP; }
-  static size_t sc_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T; }
+  static size_t sc_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * 16; }   // per step: 1 (tile) or 16 (columns)
 };
 
 __device__ __forceinline__ void gru_mfma1(f32x4& acc, const F16Frag& a, const f16x8& bh, const f16x8& bl) {
@@ -117,7 +118,19 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   float* const gi = WS.gi + size_t(blockIdx.x) * T * G::GI_STEP + size_t(wave) * 3 * NN * 256 + lane * 4;
   const int tb = (MODE == 0 || MODE == 3) ? 0 : int(blockIdx.y) * tchunk;       // time range of this workgroup
   const int te = (MODE == 0 || MODE == 3) ? T : min(T, tb + tchunk);
-  float* const sc = WS.sc + size_t(blockIdx.x) * T;
+  float* const sc = WS.sc + size_t(blockIdx.x) * T * 16;
+  // TIME-PACKED mode of the time-parallel passes (P, I, H) for a handful of streams: with nb <= 8 streams in the tile,
+  // an MFMA tile's 16 columns are (step, stream) pairs -- 16 / nb steps per tile -- instead of 16 stream slots of one
+  // step of which nb are real.  A 10-frame chunk of ONE stream is then 1 tile per pass instead of 10 (per-phase
+  // stamps of that chunk: passes P + I + H were 68 k of its 128 k cycles).  Columns are independent and every operand
+  // scale is an exact power of two, so the results are bit-identical to the unpacked passes; operand scales become per
+  // column (sc[t][slot]).  The recurrence (pass R) is serial in t and stays one tile per step.
+  const int nb = min(B - b0, MB);
+  const bool packed = MODE == 0 && NN == 1 && nb <= 8;
+  const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;   // log2 of the stream slots per step
+  const int TP = 16 >> psh;                                      // steps per tile
+  const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;      // this column's stream slot and step inside a tile
+  float* const gi_w = WS.gi + size_t(blockIdx.x) * T * G::GI_STEP + size_t(wave) * 3 * NN * 256;   // (wave's gates, lane 0)
 
   // bound of layer l's hidden state over this stream tile: max(1, max|h0[l]|) -- h(t) is a convex combination of a tanh
   // and h(t-1).  Called by all threads (it holds a barrier); the same number in every pass / launch that needs it.
@@ -183,6 +196,58 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
           xr[ks][nn] = v;
         }
     };
+    if (packed) {
+      for (int t0 = 0; t0 < T; t0 += TP) {
+        const int t = t0 + pdt;
+        const bool cv = t < T && pcs < nb;                    // this column exists
+        gru_f32x8 xr[4];
+        float ax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const int k0 = ks * 32 + lq * 8;
+          if (ks < nkp && cv && k0 < idim) {
+            const float* src = x + (int64_t(b0 + pcs) * T + t) * idim + k0;
+            if (xvec && k0 + 8 <= idim) {
+              const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+              v = gru_f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (k0 + j < idim) v[j] = src[j];
+            }
+          }
+          xr[ks] = v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(v[j]));
+        }
+        ax = fmaxf(ax, __shfl_xor(ax, 16));                   // the column's features are spread over the four k-octet
+        ax = fmaxf(ax, __shfl_xor(ax, 32));                   // lane groups
+        float cx, inv_s0;
+        const float sx = pow2_scale(ax, &cx);
+        const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+        cx *= Q.pre_inv_s;
+        if (wave == 0 && lq == 0 && cv) sc[t * 16 + pcs] = inv_s0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks < nkp) {
+            const gru_f32x8 xs = xr[ks] * sx;
+            const f16x8 bh = __builtin_convertvector(xs, f16x8);
+            const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
+            gru_mfma1(acc, a[ks], bh, bl);
+          }
+        f32x4 v = acc * cx + bpre;
+        if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        f16x4 vh, vl;
+        gru_split4(v * s0, vh, vl);
+        if (cv) {
+          char* dst = seq0 + size_t(t) * G::SEQ_STEP + (((u0 >> 3) * MB + pcs) * 8 + (u0 & 7)) * 2;
+          *reinterpret_cast<f16x4*>(dst) = vh;
+          *reinterpret_cast<f16x4*>(dst + PH) = vl;
+        }
+      }
+    } else {
     gru_f32x8 xc[4][NN], xn[4][NN];
     load_x(xc, tb);
     for (int t = tb; t < te; ++t) {
@@ -202,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       const float sx = pow2_scale(ax, &cx);
       const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
       cx *= Q.pre_inv_s;
-      if (tid == 0) sc[t] = inv_s0;
+      if (tid == 0) sc[t * 16] = inv_s0;
       f32x4 acc[NN];
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) acc[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -231,6 +296,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int nn = 0; nn < NN; ++nn) xc[ks][nn] = xn[ks][nn];
+    }
     }
   }
   if constexpr (MODE == 0) {
@@ -275,6 +341,31 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       }
       float inv_in;
       (void)pow2_scale(hb_prev, &inv_in);
+      if (packed) {
+        for (int t0 = 0; t0 < T; t0 += TP) {
+          const int t = t0 + pdt, tc = min(t, T - 1);
+          const bool cv = t < T && pcs < nb;
+          const char* p = sin + size_t(tc) * G::SEQ_STEP + (lq * MB + pcs) * 16;   // this column's fragment, K step 0
+          f32x4 acc[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
+          }
+          const float cin = (l == 0 ? sc[tc * 16 + pcs] : inv_in) * Q.ih_inv_s[l];
+          if (cv) {                                           // into the slot pass R's lane (stream pcs, same lq) reads
+            float* go = gi_w + size_t(t) * G::GI_STEP + (lq * 16 + pcs) * 4;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(go + g * 256) = acc[g] * cin + bias[g];
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      } else {
       // The input sequence is staged CS steps at a time through LDS (every wave needs all of it): each thread moves
       // CS*NN 16-byte items per chunk, requested one chunk ahead into registers and written to the other buffer after
       // the current chunk's products -- one barrier per chunk.
@@ -294,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       // 1 / scale of each step's input planes, a chunk ahead like the planes themselves (layer 0: per step, from pass P)
       float scur[CS], snext[CS];
 #pragma unroll
-      for (int dt = 0; dt < CS; ++dt) scur[dt] = l == 0 ? sc[min(tb + dt, T - 1)] : inv_in;
+      for (int dt = 0; dt < CS; ++dt) scur[dt] = l == 0 ? sc[min(tb + dt, T - 1) * 16] : inv_in;
       GRU_FETCH(tb)
       GRU_PUT(gru16_lds)
       __syncthreads();
@@ -302,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         const char* cur = gru16_lds + (c & 1) * CHUNK;
         GRU_FETCH(t0 + CS)                                   // clamped to the last step: harmless past the end
 #pragma unroll
-        for (int dt = 0; dt < CS; ++dt) snext[dt] = l == 0 ? sc[min(t0 + CS + dt, T - 1)] : inv_in;
+        for (int dt = 0; dt < CS; ++dt) snext[dt] = l == 0 ? sc[min(t0 + CS + dt, T - 1) * 16] : inv_in;
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) {
           const int t = t0 + dt;
@@ -338,6 +429,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       }
 #undef GRU_FETCH
 #undef GRU_PUT
+      }
     }
     // ---------------- pass R: the recurrence ----------------
     if constexpr (MODE == 0 || MODE == 3) {
@@ -457,6 +549,30 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (k0 + r < K) bc[r] = W[P.head_b + k0 + r];
+      if (packed) {
+        for (int t0 = wave * TP; t0 < T; t0 += (kThreads / 64) * TP) {
+          const int t = t0 + pdt, tc = min(t, T - 1);
+          const bool cv = t < T && pcs < nb;
+          const char* p = stop + size_t(tc) * G::SEQ_STEP + (lq * MB + pcs) * 16;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+            gru_mfma1(acc, a[ks], bh, bl);
+          }
+          if (cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (k0 + r < K) {
+                float v = fmaf(acc[r], chd, bc[r]);
+                if (P.sigmoid) v = sigmoidf_(v);
+                y[(int64_t(b0 + pcs) * T + t) * K + k0 + r] = v;
+              }
+          }
+        }
+        continue;
+      }
       for (int t = tb + wave; t < te; t += kThreads / 64) {
         const char* p = stop + size_t(t) * G::SEQ_STEP + frag;
         f32x4 acc[NN];

@@ -19,7 +19,8 @@ python tools/prof_summary.py $(find $out -path "*prof_hl32_*" -name "*_results.d
 python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl ds_tcn_h256/B1024/f32=hl32 --profile profiles/${tag}_ds_tcn_h256_w16.txt > $out/${tag}_pmc_traffic.log 2>&1
 cp profiles/r02_pmc_traffic.json $out/${tag}_pmc_traffic.json
 # streaming kernels: kernel trace of the many-streams sweep and of the GRU rows
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/prof_strm -o t -- bash -c "cd $root && python tools/bench_configs.py manystreams && python tools/bench_configs.py gru" > $out/prof_strm.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/prof_strm_a -o t -- bash -c "cd $root && python tools/bench_configs.py manystreams" > $out/prof_strm_a.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/prof_strm_b -o t -- bash -c "cd $root && python tools/bench_configs.py gru" > $out/prof_strm_b.log 2>&1)
 python tools/prof_summary.py $(find $out -path "*prof_strm*" -name "*_results.db" | sort) > $out/${tag}_stream_kernels.txt
 rm -rf $out/prof_*
 # the bench line (reads the PMC traffic file written above: same library build) and the secondary configs

@@ -935,11 +935,11 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
           break;
         default:
-          // LDS-resident caches cost the second workgroup per CU: clear win while the call fits one round of workgroups
-          // (0.058 vs 0.081 ms at 256 streams, 0.060 vs 0.094 at 512), within +-5 % up to 2048 streams (0.111 / 0.104 at
-          // 768, 0.170 / 0.193 at 1536), a tie beyond -- where the batch kernel is kept
+          // streaming chunk (T <= 16): both streams' caches live in LDS for the step (mdtc64_stream.hip.h).  The role-split
+          // kernel wins at every stream count (16384 streams: 1.28 vs 1.96 ms through the batch kernel), so there is no
+          // upper limit any more (round 1's LDS-cache variant tied with the batch kernel from 3072 streams on)
           rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
-                cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0 && B <= 8 * (m->fsmn_cus > 0 ? m->fsmn_cus : 256))
+                cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0)
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

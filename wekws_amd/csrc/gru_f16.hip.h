@@ -28,6 +28,9 @@
 #pragma once
 #include "conv_stack_f16.hip.h"
 #include "gru.hip.h"
+#ifndef WEKWS_GRU_MAX_PACKED_WGS
+#define WEKWS_GRU_MAX_PACKED_WGS 128
+#endif
 
 namespace wekws {
 
@@ -58,9 +61,9 @@ struct GruF16Geom {
   static constexpr int CS = 4;                              // steps of a layer input staged in LDS at a time (pass I)
   static constexpr int LDS_BYTES = 2 * CS * SEQ_STEP;       // pass I: two staging buffers; pass R re-uses the start
                                                             // for its two [hi | lo] plane buffers of h
-  static size_t seq_bytes(int B, int T) { return size_t((B + MB - 1) / MB) * T * SEQ_STEP; }
-  static size_t gi_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * GI_STEP; }
-  static size_t sc_floats(int B, int T) { return size_t((B + MB - 1) / MB) * T * 16; }   // per step: 1 (tile) or 16 (columns)
+  static size_t seq_bytes(int tiles, int T) { return size_t(tiles) * T * SEQ_STEP; }       // tiles = workgroups of the call
+  static size_t gi_floats(int tiles, int T) { return size_t(tiles) * T * GI_STEP; }
+  static size_t sc_floats(int tiles, int T) { return size_t(tiles) * T * 16; }             // per step: 1 (tile) or 16 (columns)
 };
 
 __device__ __forceinline__ void gru_mfma1(f32x4& acc, const F16Frag& a, const f16x8& bh, const f16x8& bl) {
@@ -96,7 +99,7 @@ template <int NN, int MODE>
 __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q, const GruF16Workspace WS,
                                                            const float* __restrict__ x, int B, int T,
                                                            const float* __restrict__ h0, float* __restrict__ y,
-                                                           float* __restrict__ hn, int lsel, int tchunk) {
+                                                           float* __restrict__ hn, int lsel, int tchunk, int spw) {
   using G = GruF16Geom<NN>;
   constexpr int MB = G::MB, H = kGruH, PH = G::PLANE_H;
   constexpr int KSB = 4 * MB * 16;                            // bytes per K step inside a plane
@@ -106,7 +109,10 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int b0 = blockIdx.x * MB;
+  // spw: streams this workgroup owns (MB, or fewer in single-launch mode when there are more CUs than stream tiles:
+  // gru_f16_spw); its MFMA tiles still have MB columns
+  const int b0 = blockIdx.x * spw;
+  const int bend = min(B, b0 + spw);                          // one past the workgroup's last stream
   const float* __restrict__ W = P.w;
   const int K = P.odim, idim = P.idim;
   const int u0 = wave * 16 + lq * 4;                        // first of this lane's 4 hidden units
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   // stamps of that chunk: passes P + I + H were 68 k of its 128 k cycles).  Columns are independent and every operand
   // scale is an exact power of two, so the results are bit-identical to the unpacked passes; operand scales become per
   // column (sc[t][slot]).  The recurrence (pass R) is serial in t and stays one tile per step.
-  const int nb = min(B - b0, MB);
+  const int nb = bend - b0;
   const bool packed = MODE == 0 && NN == 1 && nb <= 8;
   const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;   // log2 of the stream slots per step
   const int TP = 16 >> psh;                                      // steps per tile
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
     if (h0)
       for (int e = tid; e < MB * H; e += kThreads) {
         const int sidx = b0 + e / H;
-        if (sidx < B) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
+        if (sidx < bend) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
       }
     amax_publish(gru_cells + l, m);
     __syncthreads();
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
       for (int nn = 0; nn < NN; ++nn) {
         const int f = (nn * kThreads + tid) * 4, sidx = b0 + f / H;
-        h0v[l][nn] = (h0vec && l < P.nlayers && sidx < B)
+        h0v[l][nn] = (h0vec && l < P.nlayers && sidx < bend)
                          ? *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + sidx) * H + (f % H)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
         for (int nn = 0; nn < NN; ++nn) {
           gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           const int s = b0 + nn * 16 + l15, k0 = ks * 32 + lq * 8;
-          if (ks < nkp && s < B && t < T && k0 < idim) {
+          if (ks < nkp && s < bend && t < T && k0 < idim) {
             const float* src = x + (int64_t(s) * T + t) * idim + k0;
             if (xvec && k0 + 8 <= idim) {
               const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       for (int nn = 0; nn < NN; ++nn) {
         const int s = b0 + nn * 16 + l15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (h0 && s < B) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
+        if (h0 && s < bend) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
         hreg[nn] = v;
         f16x4 vh, vl;
         gru_split4(v * shl, vh, vl);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
         for (int nn = 0; nn < NN; ++nn) {
           const int s = b0 + nn * 16 + l15;
-          if (s < B) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg[nn];
+          if (s < bend) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg[nn];
         }
       }
     }
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
 #pragma unroll
         for (int nn = 0; nn < NN; ++nn) {
           const int s = b0 + nn * 16 + l15;
-          if (s < B) {
+          if (s < bend) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (k0 + r < K) {
@@ -604,17 +610,31 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
   }
 }
 
+// Streams per workgroup of a streaming chunk (T <= 16, single launch).  A workgroup's time does not depend on how many of
+// its 16 MFMA columns are real, but the time-parallel passes pack (step, stream) pairs into the columns when it owns <= 8
+// streams (gru_f16_kernel: TIME-PACKED mode) -- so with CUs to spare, fewer streams per workgroup is less work per
+// workgroup: 256 streams as 128 workgroups of 2 instead of 16 of 16.  Capped at kGruMaxPackedWgs workgroups: every one
+// streams the layers' 1.6 MB of weights from L2.
+constexpr int kGruMaxPackedWgs = WEKWS_GRU_MAX_PACKED_WGS;
+inline int gru_f16_spw(int B, int T, int cus) {
+  if (T > 16 || B <= 1) return 16;
+  const int wgs = cus < kGruMaxPackedWgs ? cus : kGruMaxPackedWgs;
+  int spw = 1;
+  while (spw < 16 && spw * wgs < B) spw *= 2;
+  return spw;
+}
+
 template <int NN, int MODE>
 inline int launch_gru_f16_mode(const GruF16Params& Q, const GruF16Workspace& ws, const float* x, int B, int T,
                                const float* h0, float* y, float* hn, int lsel, int tchunk, int nchunks,
-                               hipStream_t stream) {
+                               hipStream_t stream, int spw = GruF16Geom<NN>::MB) {
   using G = GruF16Geom<NN>;
-  const int tiles = (B + G::MB - 1) / G::MB;
+  const int tiles = (B + spw - 1) / spw;
   static DynLdsGrant grant;
   auto kern = gru_f16_kernel<NN, MODE>;
   if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(tiles, nchunks), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn, lsel,
-                     tchunk);
+                     tchunk, spw);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -637,23 +657,24 @@ inline int launch_gru_f16_nn(const GruF16Params& Q, const GruF16Workspace& ws, c
     if (!rc) rc = launch_gru_f16_mode<NN, 4>(Q, ws, x, B, T, h0, y, hn, 0, tchunk, nchunks, stream);
     return rc;
   }
-  return launch_gru_f16_mode<NN, 0>(Q, ws, x, B, T, h0, y, hn, 0, T, 1, stream);
+  return launch_gru_f16_mode<NN, 0>(Q, ws, x, B, T, h0, y, hn, 0, T, 1, stream, NN == 1 ? gru_f16_spw(B, T, cus) : G::MB);
 }
 
 inline bool gru_f16_supported(const GruF16Params& Q) { return Q.kpre16 <= 128 && Q.base.odim <= 128; }
 // stream tiles per workgroup: one (16 streams) until every CU has a workgroup, then two
 inline int gru_f16_nn(int B) { return B > 16 * 256 ? 2 : 1; }
-
 // workspace sizes of one call (bytes): each of the two sequence buffers, and the gate pre-activations
-inline void gru_f16_workspace_bytes(int B, int T, size_t* seq_bytes, size_t* gi_bytes, size_t* sc_bytes) {
+inline void gru_f16_workspace_bytes(int B, int T, int cus, size_t* seq_bytes, size_t* gi_bytes, size_t* sc_bytes) {
   if (gru_f16_nn(B) == 2) {
-    *seq_bytes = GruF16Geom<2>::seq_bytes(B, T);
-    *gi_bytes = GruF16Geom<2>::gi_floats(B, T) * sizeof(float);
-    *sc_bytes = GruF16Geom<2>::sc_floats(B, T) * sizeof(float);
+    const int tiles = (B + 31) / 32;
+    *seq_bytes = GruF16Geom<2>::seq_bytes(tiles, T);
+    *gi_bytes = GruF16Geom<2>::gi_floats(tiles, T) * sizeof(float);
+    *sc_bytes = GruF16Geom<2>::sc_floats(tiles, T) * sizeof(float);
   } else {
-    *seq_bytes = GruF16Geom<1>::seq_bytes(B, T);
-    *gi_bytes = GruF16Geom<1>::gi_floats(B, T) * sizeof(float);
-    *sc_bytes = GruF16Geom<1>::sc_floats(B, T) * sizeof(float);
+    const int spw = gru_f16_spw(B, T, cus), tiles = (B + spw - 1) / spw;
+    *seq_bytes = GruF16Geom<1>::seq_bytes(tiles, T);
+    *gi_bytes = GruF16Geom<1>::gi_floats(tiles, T) * sizeof(float);
+    *sc_bytes = GruF16Geom<1>::sc_floats(tiles, T) * sizeof(float);
   }
 }
 

@@ -419,7 +419,7 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
     if (d.precision == WEKWS_HIP_PRECISION_F32 || !wekws::gru_f16_supported(m->gq)) return 0;
     size_t seq_b = 0, gi_b = 0, sc_b = 0;
-    wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b, &sc_b);
+    wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
     return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + sc_b;
   }
   if (T <= WEKWS_HIP_TILE_FRAMES) return 0;
@@ -862,7 +862,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
       // same stream are ordered by the stream, calls on different streams never share a buffer
       size_t seq_b = 0, gi_b = 0, sc_b = 0;
-      wekws::gru_f16_workspace_bytes(B, T, &seq_b, &gi_b, &sc_b);
+      wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
       const size_t seq_al = (seq_b + 255) / 256 * 256, gi_al = (gi_b + 255) / 256 * 256;
       char* base = stream_workspace(m, stream, workspace_need(m, B, T));
       if (!base) return WEKWS_HIP_ENOMEM;

@@ -198,7 +198,7 @@ def test_streaming_kernel_equals_batch_kernel():
                     yr, cr = ref(xc) if cr is None else ref(xc, cr)
                     yg, cg = got(xc) if cg is None else got(xc, cg)
                     assert torch.equal(yr, yg) and torch.equal(cr, cg), (K, prec, B, T, t)
-    # MDTC h64 (mdtc64_w16.hip.h, LCACHE): two streams per workgroup, odd stream counts, 40-d and 80-d inputs, pooled head
+    # MDTC h64 (mdtc64_stream.hip.h): two streams per workgroup, odd stream counts, 40-d and 80-d inputs, pooled head
     for name in ("mdtc_h64", "mdtc_h64_80d", "mdtc_h64_global12"):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(packer.model_spec(cfg), 78)

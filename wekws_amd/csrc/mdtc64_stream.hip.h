@@ -1,8 +1,8 @@
 // MDTC h64, streaming step (chunks of <= 16 frames, both streams' caches resident in LDS): the latency kernel.
 //
-// Same arithmetic, operand layout and results as mdtc64_w16_kernel<1, ., ., LCACHE = true> (bit-identical: the tests
-// compare them), different division of labour.  Per-phase clock64 stamps of that kernel on a 10-frame chunk
-// (build/probe, B = 1: 88 k cycles per step) put 56 % of the step into "top of block + depthwise producer": 16 waves x
+// Same arithmetic, operand layout and results as the batch kernel mdtc64_w16_kernel<1, ...> fed the same chunks
+// (bit-identical: the tests compare them), different division of labour.  Per-phase clock64 stamps of the previous
+// streaming kernel -- the batch kernel's structure with the caches in LDS -- on a 10-frame chunk (B = 1: 88 k cycles per step) put 56 % of the step into "top of block + depthwise producer": 16 waves x
 // ~200 vector instructions of which five are the arithmetic -- every lane made ONE output, so every output paid its own
 // tap addressing, cache / tile selects and scale bookkeeping, and at four waves per SIMD and 4 cycles per wave64 vector
 // instruction that is ~2.9 k cycles of pure issue per block, 17 blocks per step.  A streaming step has so little work
@@ -17,7 +17,7 @@
 //   Three barriers per block.  Each role derives only the scales it needs from the LDS maxima cells.
 //
 // Usable when every block has dilation 1 / 2 / 4 / 8 (the reference recipes: stack_size 4, mdtc.py:181-198), kernel size
-// 5, <= 128 input features; anything else keeps the LCACHE instantiation of mdtc64_w16_kernel (host decides).
+// 5, <= 128 input features in whole 16-byte aligned octets; anything else runs the batch kernel on the chunk (host decides).
 #pragma once
 #include "mdtc64_w16.hip.h"
 

@@ -90,6 +90,12 @@ def time_steps(torch, fn, steps, warmup, group=GROUP):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if warmup:                                                        # a fresh workload: steady clocks first (--preheat)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.3:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for a, b in ev:
         a.record()
@@ -153,9 +159,11 @@ def stream_latency(torch, init_model, pack, synth, dev, name, B, chunk=10, n=100
     cfg, _, m = build_model(torch, init_model, pack, synth, name, dev)
     x = torch.from_numpy(synth.synth_feats(B, chunk, cfg["input_dim"], seed=3)).to(dev)
     y, c = m(x)
-    for _ in range(50):
-        y, c = m(x, c)
-    torch.cuda.synchronize()
+    t_pre = time.perf_counter()                                       # steady clocks first (see --preheat)
+    while time.perf_counter() - t_pre < 0.3:
+        for _ in range(50):
+            y, c = m(x, c)
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     t0 = time.perf_counter()
     for a, b in ev:

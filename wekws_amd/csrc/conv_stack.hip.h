@@ -205,6 +205,16 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[OW][NT]) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// The depthwise producers let a 16-lane group walk NT outputs per lane at stride d ("slide": the taps move over
+// register-resident inputs); possible when d divides 16, i.e. d is a power of two <= 16 -- so lane tl's first frame
+// (tl / d) NT d + tl % d is a shift and a mask.  (The division by a run-time d was ~40 vector instructions per block and
+// wave: 7 % of an MDTC block's cycles went into the block top, per-phase stamps at steady clocks.)
+__device__ __forceinline__ bool slide_ok(int d) { return d <= 16 && (d & (d - 1)) == 0; }
+__device__ __forceinline__ int slide_base(int tl, int d, int nt) {
+  const int sh = __builtin_ctz(unsigned(d));
+  return (((tl >> sh) * nt) << sh) + (tl & (d - 1));
+}
 __device__ __forceinline__ float f4c(const float4& q, int r) { return r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w; }
 
 // ---------------------------------------------------------------------------------------------
@@ -484,8 +494,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
     // issued unconditionally at a clamped index and the result selected (branch-free).
     // The same lanes also hand the row's streaming cache over: new_cache = last `pad` frames of [cache | h]
     // (tcn.py:54, mdtc.py:112) -- spread over the layer instead of one write burst per layer.
-    const bool slide = d <= 16 && (16 % d) == 0;
-    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;   // first output frame of this lane
+    const bool slide = slide_ok(d);
+    const int fbase = slide ? slide_base(tl, d, NT) : tl;   // first output frame of this lane
     const int fstep = slide ? d : 16;                             // distance between its output frames
     auto produce_impl = [&](int n, int buf, auto has_cache_tag) __attribute__((always_inline)) {
       constexpr bool HAS_CACHE = decltype(has_cache_tag)::value;

@@ -361,8 +361,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
     for (int ow = 0; ow < OW; ++ow)
       ebias[ow] = *reinterpret_cast<const float4*>(W + (KIND == KIND_MDTC ? bd.b2 : bd.b1) + o_base + ow * 16 + lq * 4);
 
-    const bool slide = d <= 16 && (16 % d) == 0;
-    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+    const bool slide = slide_ok(d);
+    const int fbase = slide ? slide_base(tl, d, NT) : tl;
 
     // ---- operand scale of this block, per utterance: the producer's rows are bounded by the maximum of the input
     //      tile (published by the epilogue that wrote it) and of the incoming cache

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
     load_a16<1>(a0, ap1, 0);
     load_a16<1>(a1, ap1 + 128, 0);
 
-    const bool slide = d <= 16 && (16 % d) == 0;
-    const int fbase = slide ? (tl / d) * NT * d + (tl % d) : tl;
+    const bool slide = slide_ok(d);
+    const int fbase = slide ? slide_base(tl, d, NT) : tl;
 
     // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
     //      by the epilogue that wrote it) and of the incoming cache

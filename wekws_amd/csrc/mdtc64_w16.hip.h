@@ -272,9 +272,9 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
       }
     }
     // lane tl owns the NT outputs fbase + m d (a run at stride d: the taps slide over NT + KS - 1 register-resident
-    // inputs); one tile: that is frame tl for every dilation, and the division is not worth its 40 instructions
-    const bool slide = NT == 1 || (d <= 16 && (16 % d) == 0);
-    const int fbase = (NT > 1 && slide) ? (tl / d) * NT * d + (tl % d) : tl;
+    // inputs); one tile: that is frame tl for every dilation
+    const bool slide = NT == 1 || slide_ok(d);
+    const int fbase = (NT > 1 && slide) ? slide_base(tl, d, NT) : tl;
     // operand scales of the depthwise rows, per utterance (bound through the maxima of the input tile and the cache)
     // mid tile: the bound chained behind the depthwise one (BlockDesc::mid_alpha)
     float sa[U], c1 = 0.f, sm = 1.f, c2 = 1.f;

@@ -29,6 +29,21 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_capi.SIGNATURES) == syms
 
 
+def test_every_entry_point_is_documented_for_integrators():
+    """INTEGRATION.md's table names, for every C entry point, the reference interface it replaces (or says that it has
+    none): a symbol added to the header without a row there is a gap in the drop-in story."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = set(re.findall(r"wekws_hip_[a-z_0-9]+", doc))
+    # the table abbreviates families as `wekws_hip_fbank_create` / `_compute` / `_compute_i16`: expand the short forms
+    for fam, rest in re.findall(r"`(wekws_hip_[a-z0-9]+(?:_[a-z0-9]+)*)`((?:\s*/\s*`_[a-z_0-9]+`)+)", doc):
+        stem = fam.rsplit("_", 1)[0]
+        for short in re.findall(r"`(_[a-z_0-9]+)`", rest):
+            names.add(stem + short)
+            names.add("wekws_hip" + short)
+    missing = [s for s in header_symbols() if s not in names]
+    assert not missing, f"not mentioned in INTEGRATION.md: {missing}"
+
+
 def test_abi_version_and_desc_layout():
     lib = _capi.load()
     assert lib.wekws_hip_abi_version() == _capi.ABI_VERSION == pack.ABI_VERSION

@@ -1,0 +1,44 @@
+"""GPU: bench.py prints the one JSON line the driver parses, with every field of the contract and the two extra objects
+(`roofline`, `cpu_baseline`) -- run small, but through the real code path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*flags):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_contract_line_small_run():
+    d = run_bench("--gpus", "1", "--steps", "4", "--warmup", "2", "--preheat", "0.05", "--no-extras")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "step_ms"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = utterances of the K timed steps / their wall time
+    assert abs(d["value"] - d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0           # only from a PMC profile of this very library build
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    # the product is (much) faster than the CPU path it replaces; not a quality claim, a sanity check of both numbers
+    assert d["value"] > 10 * c["value"]

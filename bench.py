@@ -229,6 +229,9 @@ def cpu_baseline(cfg, sd, T, idim):
             if el > budget_s or n >= cap:
                 return n, el
 
+    def bsz(threads):                                         # batch per forward: cache-sized for a few threads
+        return 128 if threads <= 4 else 1024
+
     rows = {}
     torch.set_num_threads(avail)                              # all cores torch uses by default, B = 1024 batches
     n, el = rate(1024, 4.0, 10 * 1024)
@@ -237,16 +240,16 @@ def cpu_baseline(cfg, sd, T, idim):
     n, el = rate(128, 4.0, 1024)
     rows["one_core"] = {"threads": 1, "batch": 128, "utts_per_s": round(n / el, 1), "sample_s": round(el, 1)}
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64) if t <= avail}):
+    for th in sorted({t for t in (1, 4, 8, 16, 32, 64) if t <= avail}):   # (shared hosts: more threads is often slower)
         torch.set_num_threads(th)
-        n, el = rate(1024, 1.5, 4096)
+        n, el = rate(bsz(th), 1.5, 4096)
         sweep[th] = round(n / el, 1)
     cores = max(sweep, key=sweep.get) if sweep else avail
     torch.set_num_threads(cores)
-    n, el = rate(1024, 10.0, 64 * 1024)
+    n, el = rate(bsz(cores), 10.0, 64 * 1024)
     torch.set_num_threads(avail)
     return {"value": round(n / el, 1), "unit": "utts/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} utterances (batches of 1024, T={T}) through oracle/torch_ref.py -- the reference's PyTorch CPU "
+            "sample": f"{n} utterances (batches of {bsz(cores)}, T={T}) through oracle/torch_ref.py -- the reference's PyTorch CPU "
                       f"operator sequence (F.linear / conv1d / batch_norm, fp32) -- in {el:.1f} s with {cores} threads, "
                       f"the best of a sweep {sweep}; host has {ncpu} hardware threads",
             "rows": rows}

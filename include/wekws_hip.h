@@ -187,7 +187,8 @@ enum wekws_hip_option {
   WEKWS_HIP_OPT_MDTC16 = 1,     /* MDTC hidden 64: 1 (default) the 16-wave kernel, 0 the generic 8-wave kernel */
   WEKWS_HIP_OPT_STREAM = 2,     /* chunks of <= 16 frames: 1 (default) the kernels with the LDS-resident cache, 0 the batch kernels */
   WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
-  WEKWS_HIP_OPT_HEAD_SLICES = 4 /* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
+  WEKWS_HIP_OPT_HEAD_SLICES = 4,/* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
+  WEKWS_HIP_OPT_ROLES = 5       /* DS-TCN hidden 256, 16-wave kernel: 1 the role-split kernel (8 multiplying + 8 producing waves, ds256_r16.hip.h), 0 all waves alternate */
 };
 int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "utils/check.h"
+#include "utils/device_guard.h"
 
 namespace wenet {
 
@@ -18,7 +19,7 @@ FeaturePipeline::FeaturePipeline(const FeaturePipelineConfig& config, int device
 }
 
 FeaturePipeline::~FeaturePipeline() {
-  (void)hipSetDevice(device_);
+  wekws::ScopedDevice dev(device_);
   if (d_pcm_) (void)hipFree(d_pcm_);
   if (d_feats_) (void)hipFree(d_feats_);
   wekws_hip_fbank_destroy(fbank_);
@@ -29,7 +30,8 @@ void FeaturePipeline::Extract(const void* host_pcm, size_t bytes_per_sample, int
   const int nf = wekws_hip_fbank_num_frames(fbank_, n);
   if (nf <= 0) return;
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  WEKWS_CHECK(hipSetDevice(device_) == hipSuccess);
+  wekws::ScopedDevice dev(device_);   // current for the allocations, copies and the launch; caller's device restored
+  WEKWS_CHECK(dev.ok()) << "hipSetDevice(" << device_ << ")";
   const size_t bytes = size_t(n) * bytes_per_sample;
   if (bytes > cap_pcm_bytes_) {
     if (d_pcm_) (void)hipFree(d_pcm_);

@@ -10,6 +10,7 @@
 
 #include "kws/model_file.h"
 #include "utils/check.h"
+#include "utils/device_guard.h"
 
 namespace wekws {
 
@@ -27,7 +28,8 @@ KeywordSpotting::KeywordSpotting(const std::string& model_path, int device, void
   }
   WEKWS_CHECK(wekws_hip_create(&desc, blob.data(), blob.size(), device_, &model_) == WEKWS_HIP_OK)
       << wekws_hip_last_error();
-  WEKWS_CHECK(hipSetDevice(device_) == hipSuccess);
+  ScopedDevice dev(device_);   // the buffers below belong to device_, whatever the caller's current device is
+  WEKWS_CHECK(dev.ok()) << "hipSetDevice(" << device_ << ")";
   WEKWS_CHECK(desc.head == WEKWS_HIP_HEAD_LINEAR || desc.head == WEKWS_HIP_HEAD_IDENTITY)
       << "the streaming runtime needs a per-frame head";
   idim_ = desc.idim;
@@ -37,7 +39,7 @@ KeywordSpotting::KeywordSpotting(const std::string& model_path, int device, void
 }
 
 KeywordSpotting::~KeywordSpotting() {
-  (void)hipSetDevice(device_);
+  ScopedDevice dev(device_);
   if (d_x_) (void)hipFree(d_x_);
   if (d_y_) (void)hipFree(d_y_);
   for (float* c : d_cache_) if (c) (void)hipFree(c);
@@ -46,6 +48,7 @@ KeywordSpotting::~KeywordSpotting() {
 
 void KeywordSpotting::Reset() { have_cache_ = false; }
 
+// (called with device_ current: Forward holds the guard)
 void KeywordSpotting::EnsureCapacity(int frames) {
   if (frames <= cap_frames_) return;
   (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_));   // (nothing of ours is in flight: Forward ends with a sync)
@@ -60,6 +63,10 @@ void KeywordSpotting::Forward(const std::vector<std::vector<float>>& feats, std:
   prob->clear();
   if (feats.empty()) return;  // keyword_spotting.cc:59
   const int T = static_cast<int>(feats.size());
+  // device_ becomes current BEFORE anything is allocated, freed or synchronised (EnsureCapacity does all three) and
+  // the caller's device is restored on return: two instances on two GPUs can be driven alternately from one thread
+  ScopedDevice dev(device_);
+  WEKWS_CHECK(dev.ok()) << "hipSetDevice(" << device_ << ")";
   EnsureCapacity(T);
   h_x_.resize(size_t(T) * idim_);
   for (int t = 0; t < T; ++t) {  // keyword_spotting.cc:63-68: (1, T, dim) row-major
@@ -67,7 +74,6 @@ void KeywordSpotting::Forward(const std::vector<std::vector<float>>& feats, std:
     std::memcpy(h_x_.data() + size_t(t) * idim_, feats[t].data(), idim_ * sizeof(float));
   }
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  WEKWS_CHECK(hipSetDevice(device_) == hipSuccess);
   WEKWS_CHECK(hipMemcpyAsync(d_x_, h_x_.data(), h_x_.size() * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess);
   WEKWS_CHECK(wekws_hip_forward(model_, d_x_, /*B=*/1, T, have_cache_ ? d_cache_[cur_] : nullptr, d_y_,
                                 d_cache_[cur_ ^ 1], /*softmax=*/0, stream_) == WEKWS_HIP_OK)

@@ -1,0 +1,409 @@
+// DS-TCN, hidden_dim 256, no incoming cache (whole utterances, first chunks) -- REGISTER-RESIDENT 16-wave kernel (round 3).
+// Same arithmetic and the same results bit for bit as ds256_w16.hip.h; a different home for the activations.
+//
+// What bounded ds256_w16 (round-2 counters + round-3 probes): per utterance 132 k cycles of which the LDS
+// array is busy 69 k, the matrix pipe needs 31 k and the vector units 28 k -- nine barriers per block keep the three units
+// taking turns, and most of the LDS work is the f32 activation tile going round in circles: the epilogue writes h (and
+// reads it for the residual), the depthwise producer reads every element of it twice, writes the fp16 operand planes 64
+// channels at a time, and sixteen waves read those back.  Three attempts to overlap the phases (ds256_r16: fixed roles;
+// ds256_i16: every wave multiplies K step k while it produces k + 1; o-tile pairs) ran into the same two walls: one wave
+// issues at most one vector instruction per ~8 cycles, so any arrangement that leaves the vector work to fewer waves is
+// slower, and everything that adds LDS instructions gives back what the overlap gains.
+//
+// Here the f32 residual tile h never touches LDS.  Wave w owns output channels 16 w .. 16 w + 15 for ALL frames -- the
+// accumulator layout of the 1x1 convolution (lane = 4 consecutive channels x frame 16 tt + (lane & 15)) -- and keeps h in
+// that layout in 4 NT registers for the whole kernel:
+//   * epilogue: h += ReLU(acc * c + bias), registers only;
+//   * depthwise dilated conv (tcn.py:102-109): the frames a tap needs are in the SAME registers one 16-lane row over, so
+//     x[t - s] is a DPP row shift -- v_fmac_f32_dpp row_shr:(s % 16) on tile tt - s/16 for the lanes that stay inside the
+//     row, row_shl:(16 - s % 16) on the tile before for the lanes that cross it (bound_ctrl off: a lane whose source
+//     falls outside the row is disabled), one plain FMA when 16 | s; left context = tiles < 0 = zeros = no instruction.
+//     Two vector instructions per tap instead of one FMA + an LDS read, no addressing, no selects;
+//   * the conv's output (+ folded BN, ReLU, block-floating scale, fp16 hi/lo split: v_fma_mixlo / mixhi write the two
+//     halves of a register, so four channels are two registers) goes to LDS as MFMA B-operand planes for the WHOLE K = 256
+//     -- the tile's place: 16 planes x 7 KB = 112 KB -- with 8-byte stores;
+//   * the matrix phase then runs all eight K steps back to back (168 MFMAs per wave, B fragments double-buffered).
+// Two barriers per block instead of nine; LDS instructions per block and wave: 14 stores + 112 fragment reads (was
+// 56 + 56 tile accesses in the epilogue, 72 reads + 56 two-byte stores in the producer, 112 fragment reads).
+// The streaming cache is handed over from the registers; the classifier head reads the tile from LDS as before (it is
+// written there once, after the last block).
+#pragma once
+#include "ds256_w16.hip.h"
+
+namespace wekws {
+
+#ifdef WEKWS_G16_STAMPS
+#define G16_PH_DECL long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64()
+#define G16_PH(id) do { long long now_ = clock64(); tph[id] += now_ - tlast; tlast = now_; } while (0)
+#define G16_PH_DUMP                                                                                    \
+  do {                                                                                                 \
+    __syncthreads();                                                                                   \
+    if (b == 0 && A.out_cache && lane == 0 && (wave == 0 || wave == 9))                                \
+      for (int i = 0; i < 8; ++i) A.out_cache[(wave ? 8 : 0) + i] = float(tph[i]);                     \
+  } while (0)
+#else
+#define G16_PH_DECL
+#define G16_PH(id)
+#define G16_PH_DUMP
+#endif
+
+// o += w * x[lane - S] for the lanes whose source stays inside their 16-lane row (the others keep o)
+template <int S>
+__device__ __forceinline__ void g16_fmac_shr(float& o, float x, float w) {
+  static_assert(S >= 1 && S <= 15, "row shift");
+#define G16_SHR(n) if constexpr (S == n) asm("v_fmac_f32_dpp %0, %1, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf" : "+v"(o) : "v"(x), "v"(w));
+  G16_SHR(1) G16_SHR(2) G16_SHR(3) G16_SHR(4) G16_SHR(5) G16_SHR(6) G16_SHR(7) G16_SHR(8)
+  G16_SHR(9) G16_SHR(10) G16_SHR(11) G16_SHR(12) G16_SHR(13) G16_SHR(14) G16_SHR(15)
+#undef G16_SHR
+}
+// o += w * x[lane + S] for the lanes whose source stays inside their 16-lane row
+template <int S>
+__device__ __forceinline__ void g16_fmac_shl(float& o, float x, float w) {
+  static_assert(S >= 1 && S <= 15, "row shift");
+#define G16_SHL(n) if constexpr (S == n) asm("v_fmac_f32_dpp %0, %1, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf" : "+v"(o) : "v"(x), "v"(w));
+  G16_SHL(1) G16_SHL(2) G16_SHL(3) G16_SHL(4) G16_SHL(5) G16_SHL(6) G16_SHL(7) G16_SHL(8)
+  G16_SHL(9) G16_SHL(10) G16_SHL(11) G16_SHL(12) G16_SHL(13) G16_SHL(14) G16_SHL(15)
+#undef G16_SHL
+}
+
+// One tap of the causal dilated depthwise conv on the register-resident tile: o += w * h[t - S], t = 16 TT_ + (lane & 15).
+// Tiles below 0 are the (all-zero) left context: nothing to add.
+template <int S, int TT_, int NT>
+__device__ __forceinline__ void g16_tap(float& o, const f32x4 (&hv)[NT], int r, float w) {
+  constexpr int Q = S / 16, R = S % 16;
+  constexpr int TC = TT_ - Q, TP = TC - 1;
+  if constexpr (R == 0) {
+    if constexpr (TC >= 0) o = fmaf(w, hv[TC][r], o);
+  } else {
+    if constexpr (TC >= 0) g16_fmac_shr<R>(o, hv[TC][r], w);
+    if constexpr (TP >= 0) g16_fmac_shl<16 - R>(o, hv[TP][r], w);
+  }
+}
+
+// scale + split of one depthwise output into the LOW (HI_HALF = false) or HIGH half of the packed hi / lo registers:
+// hi = fp16(v s) (one rounding of the exact product), d = v s - hi (exact), lo = fp16(d)  -- split16s(), but writing halves
+template <bool HI_HALF, bool SPLIT>
+__device__ __forceinline__ void g16_split_into(float v, float s, unsigned& ph, unsigned& pl) {
+  float d;
+  if constexpr (!HI_HALF) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(ph) : "v"(v), "v"(s));                     // (upper half: written next)
+    if constexpr (SPLIT) {
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(s), "v"(ph));
+      asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(pl) : "v"(d));
+    }
+  } else {
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(ph) : "v"(v), "v"(s));
+    if constexpr (SPLIT) {
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(s), "v"(ph));
+      asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(pl) : "v"(d));
+    }
+  }
+}
+
+// Depthwise conv + folded BN + ReLU + scale / split of channel row R_ (of the lane's four) for the tiles TT_ .. NT - 1.
+// Tap j multiplies the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
+template <int D, int R_, int TT_, int NT, bool SPLIT>
+__device__ __forceinline__ void g16_dw_row(const f32x4 (&hv)[NT], const float (&dww)[9], float sa, unsigned (&ph)[NT][2],
+                                           unsigned (&pl)[NT][2]) {
+  float o = dww[8];
+  g16_tap<7 * D, TT_, NT>(o, hv, R_, dww[0]);
+  g16_tap<6 * D, TT_, NT>(o, hv, R_, dww[1]);
+  g16_tap<5 * D, TT_, NT>(o, hv, R_, dww[2]);
+  g16_tap<4 * D, TT_, NT>(o, hv, R_, dww[3]);
+  g16_tap<3 * D, TT_, NT>(o, hv, R_, dww[4]);
+  g16_tap<2 * D, TT_, NT>(o, hv, R_, dww[5]);
+  g16_tap<1 * D, TT_, NT>(o, hv, R_, dww[6]);
+  g16_tap<0, TT_, NT>(o, hv, R_, dww[7]);
+  o = fmaxf(o, 0.f);
+  g16_split_into<(R_ & 1) != 0, SPLIT>(o, sa, ph[TT_][R_ >> 1], pl[TT_][R_ >> 1]);
+  if constexpr (TT_ + 1 < NT) g16_dw_row<D, R_, TT_ + 1, NT, SPLIT>(hv, dww, sa, ph, pl);
+}
+template <int D, int R_, int NT, bool SPLIT>
+__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
+                                            unsigned (&pl)[NT][2]) {
+  // taps + bias of channel o0 + R_ (padded 12-float record): three LDS broadcasts
+  const float4* src = reinterpret_cast<const float4*>(taps_o0 + R_ * 12);
+  const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+  const float dww[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+  g16_dw_row<D, R_, 0, NT, SPLIT>(hv, dww, sa, ph, pl);
+  if constexpr (R_ + 1 < 4) g16_dw_rows<D, R_ + 1, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+}
+
+// One 32-deep K step for one o-tile, B fragments of tile tt + 1 requested before the MFMAs of tile tt
+template <int NT, bool SPLIT>
+__device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a, const char* bh, const char* bl) {
+  f16x8 vh[2], vl[2];
+  vh[0] = *reinterpret_cast<const f16x8*>(bh);
+  if constexpr (SPLIT) vl[0] = *reinterpret_cast<const f16x8*>(bl);
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    if (tt + 1 < NT) {
+      vh[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bh + (tt + 1) * 256);
+      if constexpr (SPLIT) vl[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bl + (tt + 1) * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh[tt & 1], acc[tt], 0, 0, 0);
+    if constexpr (SPLIT) {
+      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl[tt & 1], acc[tt], 0, 0, 0);
+      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh[tt & 1], acc[tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT, bool SPLIT>
+__global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParams P, const CallArgs A) {
+  using G = W16Geom<NT>;
+  constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB, KS = 8;
+  constexpr int NKS = C / 32;                                // K steps per layer
+  constexpr int OTS = NKS * 128;                             // uint4 per o-tile
+  static_assert(size_t(2 * NKS) * PB <= G::LDS_BYTES, "the operand planes of a whole layer live where the f32 tile was");
+  extern __shared__ __attribute__((aligned(16))) float w16_lds[];
+  char* const planes = reinterpret_cast<char*>(w16_lds);     // [K step][hi | lo][k-octet][frame][8 halves]
+  float* const hbuf = w16_lds + G::SLAB / 4;                 // [256][SS] f32 tile -- only for the classifier, at the end
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b = blockIdx.x;                                  // one utterance per workgroup
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int o0 = wave * 16 + lq * 4;                         // this lane's 4 channels: rows of the o-tile AND of the tile h
+  const int frag_off = (lq * TT + l15) * 16;
+  // where this lane's 4 channels of frame 16 tt + l15 sit in a hi plane: K step wave >> 1, k-octet (wave & 1) * 2 + lq / 2,
+  // halves (lq & 1) * 4 .. + 3 of the 16-byte item
+  char* const pst = planes + (wave >> 1) * 2 * PB + ((((wave & 1) * 2 + (lq >> 1)) * TT + l15) * 16 + (lq & 1) * 8);
+
+  f32x4 acc[NT];
+  f32x4 hv[NT];                                              // the residual tile: channels o0 .. o0 + 3, frames 16 tt + l15
+  G16_PH_DECL;
+
+  // ---- block floating point (conv_stack_f16.hip.h): maximum of the feature tile
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  // depthwise taps + bias of the CURRENT block, [256][12] floats (the 12-float records of BlockDesc::dw_pk): staged for
+  // block bi + 1 behind block bi's matrix phase (block 0: during the preprocessing), read back as 16-byte broadcasts
+  __shared__ __attribute__((aligned(16))) float taps[C * 12];
+  auto stage_taps = [&](const BlockDesc& nb) __attribute__((always_inline)) {
+    if (tid < C * 3) reinterpret_cast<float4*>(taps)[tid] = reinterpret_cast<const float4*>(W + nb.dw_pk)[tid];
+  };
+  amax_zero<kW16Threads>(amax_cells, kAmaxCells);
+  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
+  __syncthreads();
+  stage_taps(blk[0]);
+  const int nk = P.kpre16 / 32;
+  // 40-d fbank: the features pass through registers once
+  const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
+  W16XItem xi;
+  if (one_trip) {
+    xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+    amax_publish(amax_cells, w16_x_amax(xi));
+  } else {
+    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  }
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
+    const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+    float sx = 1.f, cpre = 1.f;
+    if (one_trip) {
+      F16Frag a[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {                       // in flight over the barriers (nk = 1: the same step twice)
+        const uint4* q = ap + min(st, nk - 1) * 128;
+        a[st].h = __builtin_bit_cast(f16x8, q[0]);
+        a[st].l = __builtin_bit_cast(f16x8, q[64]);
+      }
+      __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
+      w16_store_x<PB, SPLIT>(xi, sx, planes);
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st)                         // (compile-time indices: a runtime-indexed fragment array spills)
+        if (st < nk)
+          g16_mfma_step<NT, SPLIT>(acc, a[st], planes + st * 2 * PB + frag_off, planes + st * 2 * PB + PB + frag_off);
+    } else
+    for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass
+      const int steps = min(2, nk - k0);
+      __syncthreads();
+      sx = pow2_scale(amax_read(amax_cells), &cpre);
+      for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, frame)
+        const int t = e % TT;
+        const int q = e / TT;
+        const int oct = q & 3, st = q >> 2;
+        const int kf = (k0 + st) * 32 + oct * 8;
+        const bool ok = t < T;
+        const float* xr = A.x + int64_t(b) * A.xs_b + int64_t(t) * P.idim + kf;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (ok && kf + i < P.idim) ? xr[i] * sx : 0.f;
+          _Float16 h, l;
+          split16(v, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        char* dst = planes + st * 2 * PB + (oct * TT + t) * 16;
+        *reinterpret_cast<f16x8*>(dst) = vh;
+        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(dst + PB) = vl;
+      }
+      __syncthreads();
+      for (int st = 0; st < steps; ++st) {
+        F16Frag a[1];
+        load_a16<1>(a, ap + (k0 + st) * 128, 0);
+        g16_mfma_step<NT, SPLIT>(acc, a[0], planes + st * 2 * PB + frag_off, planes + st * 2 * PB + PB + frag_off);
+      }
+    }
+    cpre *= P.pre_inv_s;                                     // 1 / (feature scale * weight scale)
+    float hmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaf(acc[tt][r], cpre, f4c(bias, r));
+        if (P.pre_relu) v = fmaxf(v, 0.f);
+        hv[tt][r] = v;
+        hmax = fmaxf(hmax, fabsf(v));
+      }
+    }
+    amax_publish(amax_cells + 2, hmax);
+    __syncthreads();                                         // (A) maximum published, planes free, taps staged
+  }
+  G16_PH(0);                                                 // [0] preprocessing
+  // ======================================= residual blocks =======================================
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    const BlockDesc bd = blk[bi];
+    const int pad = bd.pad;
+    const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
+    F16Frag a0, a1;                                          // weight fragments of the even / odd K steps
+    {
+      F16Frag t[1];
+      load_a16<1>(t, ap1, 0); a0 = t[0];
+      load_a16<1>(t, ap1 + 128, 0); a1 = t[0];
+    }
+    // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
+    //      by the epilogue that produced it)
+    float c1;
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1);
+    c1 *= bd.inv_s1;
+
+    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
+    //      the registers: frame t = 16 tt + l15 of channel o0 + r is column t - (T - pad).  (Measured: the same stores at
+    //      the head of the matrix phase are SLOWER -- loads and stores share one in-order counter, so the first weight
+    //      fragment re-requested behind them waits for their trip to HBM.)
+    if (A.out_cache) {
+      float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt * 16 < T && tt * 16 + 16 > T - pad) {         // (wave-uniform: the tile holds frames of the slice)
+          const int p = tt * 16 + l15 - (T - pad);
+          if (p >= 0 && p < pad) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
+          }
+        }
+      }
+      if (T < pad) {                                         // shorter than the slice: zero context in front
+        const int nz = pad - T;
+        for (int e = lane; e < 16 * nz; e += 64) {
+          const int cc = e / nz, p = e - cc * nz;
+          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+        }
+      }
+    }
+    G16_PH(1);                                               // [1] block top + cache hand-over
+
+    // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-109) of this lane's 4 channels x NT frames, from the
+    //      registers; scale, split, store as operand planes of K step wave >> 1
+    {
+      unsigned ph[NT][2], pl[NT][2];                         // packed fp16: [tile][channels (0,1) | (2,3)]
+      const float* taps_o0 = taps + o0 * 12;
+      switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
+        case 1: g16_dw_rows<1, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        case 2: g16_dw_rows<2, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        case 4: g16_dw_rows<4, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        default: g16_dw_rows<8, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        *reinterpret_cast<uint2*>(pst + tt * 256) = uint2{ph[tt][0], ph[tt][1]};
+        if constexpr (SPLIT) *reinterpret_cast<uint2*>(pst + PB + tt * 256) = uint2{pl[tt][0], pl[tt][1]};
+      }
+    }
+    G16_PH(2);                                               // [2] depthwise conv -> operand planes
+    __syncthreads();                                         // (B) the planes of all 256 channels are written
+    G16_PH(3);                                               // [3] barrier waits
+
+    // next block's taps: requested now, stored to LDS behind the matrix phase
+    float4 tap_nx = float4{0.f, 0.f, 0.f, 0.f};
+    const bool tap_ld = bi + 1 < P.nblocks && tid < C * 3;
+    if (tap_ld) tap_nx = reinterpret_cast<const float4*>(W + blk[bi + 1].dw_pk)[tid];
+
+    // ---- pointwise conv: all eight K steps back to back
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {
+      const char* bsrc = planes + ks * 2 * PB + frag_off;
+      g16_mfma_step<NT, SPLIT>(acc, a0, bsrc, bsrc + PB);
+      {
+        F16Frag t[1];
+        load_a16<1>(t, ap1 + min(ks + 2, NKS - 2) * 128, 0); a0 = t[0];
+      }
+      g16_mfma_step<NT, SPLIT>(acc, a1, bsrc + 2 * PB, bsrc + 3 * PB);
+      {
+        F16Frag t[1];
+        load_a16<1>(t, ap1 + min(ks + 3, NKS - 1) * 128, 0); a1 = t[0];
+      }
+    }
+    G16_PH(4);                                               // [4] matrix phase
+
+    // ---- epilogue: folded bias + ReLU + residual (tcn.py:60: add after the ReLU), registers only
+    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
+    float hmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaxf(fmaf(acc[tt][r], c1, f4c(ebias, r)), 0.f) + hv[tt][r];
+        hv[tt][r] = v;
+        hmax = fmaxf(hmax, fabsf(v));
+      }
+    }
+    amax_publish(amax_cells + 3 + bi, hmax);             // = the input tile of block bi + 1
+    if (tap_ld) reinterpret_cast<float4*>(taps)[tid] = tap_nx;   // (this block's taps were last read before barrier (B))
+    G16_PH(5);                                               // [5] epilogue
+    __syncthreads();                                         // (A) maximum published, planes free, taps staged
+    G16_PH(3);
+  }
+
+  // ---- the classifier reads the tile from LDS (conv_stack_head): written once, where the planes were
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hbuf[(o0 + r) * SS + tt * 16 + l15] = hv[tt][r];
+  }
+  __syncthreads();
+  conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, w16_lds, b);
+  G16_PH(7);                                                 // [7] classifier
+  G16_PH_DUMP;
+}
+
+template <int NT, bool SPLIT>
+inline int launch_ds256_g16_nts(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  using G = W16Geom<NT>;
+  static DynLdsGrant grant;
+  auto kern = ds256_g16_kernel<NT, SPLIT>;
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
+  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Calls WITHOUT an incoming cache whose blocks all have dilation 1, 2, 4 or 8 (the host checks; everything else:
+// launch_ds256_w16).  split: three fp16 products per MAC on hi/lo operands (F16X3) or one on the hi halves (F16).
+int launch_ds256_g16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
+
+}  // namespace wekws

@@ -188,7 +188,7 @@ enum wekws_hip_option {
   WEKWS_HIP_OPT_STREAM = 2,     /* chunks of <= 16 frames: 1 (default) the kernels with the LDS-resident cache, 0 the batch kernels */
   WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
   WEKWS_HIP_OPT_HEAD_SLICES = 4,/* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
-  WEKWS_HIP_OPT_ROLES = 5       /* DS-TCN hidden 256, 16-wave kernel: 1 the role-split kernel (8 multiplying + 8 producing waves, ds256_r16.hip.h), 0 all waves alternate */
+  WEKWS_HIP_OPT_G16 = 5         /* DS-TCN hidden 256, calls without an incoming cache: 1 (default) the kernel that keeps the residual tile in registers (ds256_g16.hip.h), 0 the 16-wave LDS-tile kernel */
 };
 int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
 

@@ -401,6 +401,28 @@ def test_generic_kernels_behind_the_specialised_ones(golden):
         assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
 
 
+def test_register_resident_kernel_equals_lds_tile_kernel():
+    """DS-TCN h256 calls without an incoming cache run ds256_g16 (residual tile in registers, depthwise conv through DPP row
+    shifts); option g16 = 0 sends them through ds256_w16 (tile in LDS).  Same arithmetic in the same order: outputs AND the
+    returned cache must agree bit for bit, for every tile shape (T = 1 .. 112, i.e. NT = 1 / 2 / 4 / 7), ragged T, long
+    inputs (tiles after the first carry a cache and take the w16 path either way), both precisions that have the kernel,
+    and with / without the cache being asked for."""
+    from wekws_amd import pack
+    for name in ("ds_tcn_h256",):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 77)
+        for prec in ("default", "f16"):
+            a = build(cfg, sd).set_precision(prec).set_option("g16", 1)
+            b = build(cfg, sd).set_precision(prec).set_option("g16", 0)
+            for B, T in ((3, 1), (2, 7), (1, 16), (5, 17), (2, 33), (3, 64), (2, 65), (4, 98), (1, 112), (2, 150), (1, 300)):
+                x = synth.synth_feats(B, T, cfg["input_dim"], seed=T)
+                ya, ca = run(a, x)
+                yb, cb = run(b, x)
+                assert np.array_equal(ya, yb) and np.array_equal(ca, cb), (prec, B, T)
+                xt = torch.from_numpy(x).cuda()
+                assert torch.equal(a.posteriors(xt), b.posteriors(xt)), (prec, B, T)
+
+
 def test_ds256_matrix_core_depthwise_variant(golden):
     """Option mm = 1 selects the DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores (ds256_mm.hip.h)
     for keyword heads too: same goldens, same tolerance, including streaming and carried caches."""

@@ -11,7 +11,7 @@ from tools.bench_configs import build  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 
 cfg, m = build("ds_tcn_h256")
-m.set_option("roles", 4)
+m.set_option("g16", 1)
 names = ["pre", "block top", "depthwise -> planes", "barrier waits", "matrix phase", "epilogue", "cache hand-over", "head"]
 x = torch.from_numpy(synth.synth_feats(1024, 98, 40, seed=1)).cuda()
 for _ in range(50):

@@ -24,52 +24,6 @@ namespace wekws {
 // only), one MFMA per product instead of three; the lo planes are neither written nor read.
 template <int NT, bool SPLIT = true>
 __device__ __forceinline__ void mfma16_step_nb(f32x4 (&acc)[NT], const F16Frag& a, const char* bh, const char* bl) {
-#if defined(W16_VAR) && W16_VAR == 1
-  // variant: B fragments of tile tt + 1 requested before the MFMAs of tile tt
-  f16x8 vh[2], vl[2];
-  vh[0] = *reinterpret_cast<const f16x8*>(bh);
-  if constexpr (SPLIT) vl[0] = *reinterpret_cast<const f16x8*>(bl);
-#pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
-    if (tt + 1 < NT) {
-      vh[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bh + (tt + 1) * 256);
-      if constexpr (SPLIT) vl[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bl + (tt + 1) * 256);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh[tt & 1], acc[tt], 0, 0, 0);
-    if constexpr (SPLIT) {
-      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl[tt & 1], acc[tt], 0, 0, 0);
-      acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh[tt & 1], acc[tt], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return;
-#endif
-#if defined(W16_VAR) && W16_VAR == 2
-  // variant: tiles in pairs, the two tiles' dependent chains interleaved
-  if constexpr (SPLIT && NT >= 2) {
-#pragma unroll
-    for (int tp = 0; tp < NT; tp += 2) {
-      const bool two = tp + 1 < NT;
-      const f16x8 vh0 = *reinterpret_cast<const f16x8*>(bh + tp * 256);
-      const f16x8 vl0 = *reinterpret_cast<const f16x8*>(bl + tp * 256);
-      f16x8 vh1 = vh0, vl1 = vl0;
-      if (two) {
-        vh1 = *reinterpret_cast<const f16x8*>(bh + (tp + 1) * 256);
-        vl1 = *reinterpret_cast<const f16x8*>(bl + (tp + 1) * 256);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh0, acc[tp], 0, 0, 0);
-      if (two) acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh1, acc[tp + 1], 0, 0, 0);
-      acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl0, acc[tp], 0, 0, 0);
-      if (two) acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl1, acc[tp + 1], 0, 0, 0);
-      acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh0, acc[tp], 0, 0, 0);
-      if (two) acc[tp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh1, acc[tp + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return;
-  }
-#endif
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
     const f16x8 vh = *reinterpret_cast<const f16x8*>(bh + tt * 256);

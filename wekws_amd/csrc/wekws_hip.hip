@@ -19,8 +19,6 @@
 #include "conv_stack_f16.hip.h"
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
-#include "ds256_r16.hip.h"
-#include "ds256_i16.hip.h"
 #include "ds256_g16.hip.h"
 #include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
@@ -257,7 +255,7 @@ struct wekws_hip_model {
   bool mdtc_stream_eligible = false;   // mdtc64_stream.hip.h: dilations 1 / 2 / 4 / 8, the two streams' caches fit into LDS
   bool mdtc16_ok = false; // MDTC h64: the 16-wave kernel (WEKWS_HIP_OPT_MDTC16 = 0: the generic 8-wave one)
   bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
-  int roles_ok = 0;       // ... 1: in its role-split form (ds256_r16.hip.h), 2: interleaved (ds256_i16.hip.h); WEKWS_HIP_OPT_ROLES
+  bool g16_ok = true;     // ... calls without an incoming cache: the register-resident kernel (ds256_g16.hip.h; WEKWS_HIP_OPT_G16 = 0: ds256_w16)
   int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, 0 / 1 off, n forces n
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
                           // (WEKWS_HIP_OPT_STREAM = 0 keeps the batch kernel)
@@ -809,7 +807,7 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
     case WEKWS_HIP_OPT_STREAM: m->stream_ok = value != 0; break;
     case WEKWS_HIP_OPT_MM: m->mm_ok = m->mm_eligible && (value < 0 ? m->desc.odim > 16 : value != 0); break;
     case WEKWS_HIP_OPT_HEAD_SLICES: m->fsmn_slices = value; break;
-    case WEKWS_HIP_OPT_ROLES: m->roles_ok = value; break;
+    case WEKWS_HIP_OPT_G16: m->g16_ok = value != 0; break;
     default: return fail(WEKWS_HIP_EINVAL, "unknown option %d", option);
   }
   return WEKWS_HIP_OK;
@@ -931,10 +929,8 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           rc = strm ? wekws::launch_ds256_stream(split, m->sp, a, stream)
                : !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
-               : (C == 256 && m->w16_ok && m->roles_ok == 4 && m->ds_stream_eligible && !a.in_cache)
+               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache)
                      ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream)                      // 16 waves, tile in registers
-               : (C == 256 && m->w16_ok && m->roles_ok == 2) ? wekws::launch_ds256_i16(nt, split, m->sp, a, stream)   // 16 waves, interleaved
-               : (C == 256 && m->w16_ok && m->roles_ok == 1) ? wekws::launch_ds256_r16(nt, split, m->sp, a, stream)   // 16 waves, fixed roles
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     const BlockDesc bd = blk[bi];
     const int pad = bd.pad;
     const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
+    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (requested before anything is stored)
     F16Frag a0, a1;                                          // weight fragments of the even / odd K steps
     {
       F16Frag t[1];
@@ -290,31 +291,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     const float sa = pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
 
-    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
-    //      the registers: frame t = 16 tt + l15 of channel o0 + r is column t - (T - pad).  (Measured: the same stores at
-    //      the head of the matrix phase are SLOWER -- loads and stores share one in-order counter, so the first weight
-    //      fragment re-requested behind them waits for their trip to HBM.)
-    if (A.out_cache) {
-      float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        if (tt * 16 < T && tt * 16 + 16 > T - pad) {         // (wave-uniform: the tile holds frames of the slice)
-          const int p = tt * 16 + l15 - (T - pad);
-          if (p >= 0 && p < pad) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
-          }
-        }
-      }
-      if (T < pad) {                                         // shorter than the slice: zero context in front
-        const int nz = pad - T;
-        for (int e = lane; e < 16 * nz; e += 64) {
-          const int cc = e / nz, p = e - cc * nz;
-          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
-        }
-      }
-    }
-    G16_PH(1);                                               // [1] block top + cache hand-over
+    G16_PH(1);                                               // [1] block top
 
     // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-109) of this lane's 4 channels x NT frames, from the
     //      registers; scale, split, store as operand planes of K step wave >> 1
@@ -361,8 +338,37 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     }
     G16_PH(4);                                               // [4] matrix phase
 
+    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
+    //      the registers (still the block's INPUT: the epilogue below is what changes them): frame t = 16 tt + l15 of
+    //      channel o0 + r is column t - (T - pad).  WHERE the stores are issued matters more than how many there are: loads
+    //      and stores share one in-order counter, so any load waited for behind them waits for their trip to HBM.  At the
+    //      head of the block (or of the matrix phase) that load is the next weight fragment and the matrix phase stalls;
+    //      here nothing is requested behind them until the next block's fragments, which are not needed before ITS matrix
+    //      phase -- a whole depthwise phase later.  (A detour through LDS for 16-byte row segments, 22 store instructions
+    //      instead of 48, was measured 2 % slower than the direct stores.)
+    if (A.out_cache) {
+      float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        if (tt * 16 < T && tt * 16 + 16 > T - pad) {         // (wave-uniform: the tile holds frames of the slice)
+          const int p = tt * 16 + l15 - (T - pad);
+          if (p >= 0 && p < pad) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
+          }
+        }
+      }
+      if (T < pad) {                                         // shorter than the slice: zero context in front
+        const int nz = pad - T;
+        for (int e = lane; e < 16 * nz; e += 64) {
+          const int cc = e / nz, p = e - cc * nz;
+          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+        }
+      }
+    }
+    G16_PH(6);                                               // [6] cache hand-over
+
     // ---- epilogue: folded bias + ReLU + residual (tcn.py:60: add after the ReLU), registers only
-    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
     float hmax = 0.f;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {

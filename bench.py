@@ -22,10 +22,15 @@ taken right after the timed region, each the mean of 4 back-to-back steps betwee
 every single launch adds ~7 us to it and to the job).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields:
-  roofline        dominant kernel of `value` (default precision: ds256_w16_kernel, 3 x fp16 MFMA per MAC on block-floating
+  roofline        dominant kernel of `value` (default precision: ds256_g16_kernel, 3 x fp16 MFMA per MAC on block-floating
                   hi/lo operands, so the peak for ALGORITHMIC flops is 2500 / 3 TF).  `kernel` and `traffic` (HBM bytes per
-                  launch from rocprofv3 PMC passes) are reported only when profiles/r02_pmc_traffic.json was taken with
+                  launch from rocprofv3 PMC passes) are reported only when profiles/pmc_traffic.json was taken with
                   the very library file this run loads (sha-256 match) on this workload -- else omitted.
+  value_single_output_buffer   the same steps with the result dropped at once: the caching allocator then recycles ONE
+                  110 MB cache buffer whose rewrites hit the 256 MB memory-side cache; `value` keeps the result bound
+                  across the next call (two buffers alternate), as `logits, _ = model(feats)` in score.py:125 does.
+  comm            (N > 1) what the one collective of the job cost: backend, world size as torch.distributed reports it,
+                  bytes and wall time of the weight broadcast; `per_rank_utts_per_s` min / max over the ranks.
   f32             the same batch with precision F32 (exact-f32 MFMA kernel: each product rounded once, the reference's
                   own arithmetic), with its own roofline against the 157.3 TF f32 matrix peak.
   latency         streaming, 10-frame chunks with the carried cache (stream_kws_ctc.py:482-514, keyword_spotting.cc:56-95):
@@ -35,7 +40,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields:
   rooflines_other ds256_stream_kernel at 4096 streams (HBM-bound by construction: the cache round trip) and fbank_kernel.
   also / score_only   MDTC h64 on the same batch; the DS-TCN batch with the cache hand-over dropped (score.py:125).
   cpu_baseline    the reference's CPU path (PyTorch CPU operator sequence, oracle/torch_ref.py) on this box's host cores:
-                  B = 1024 batches with all cores, with one core, and with the best thread count of a short sweep.
+                  B = 1024 batches with all hardware threads, with one core, a short sweep of thread counts, and rows
+                  with one OpenMP thread PINNED per physical core (OMP_PROC_BIND=close, OMP_PLACES=cores, affinity to one
+                  hardware thread per core; separate worker processes, because the binding is read at OpenMP start-up);
+                  `value` is the best of all of them.
 """
 import argparse
 import hashlib
@@ -128,13 +136,15 @@ def mfma_roofline(model_name, B, kern_ms, precision):
 def attach_profile(roof, model_name, B, precision):
     """`kernel` / `traffic` from the committed PMC passes -- only if they were taken on the library file loaded now."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         rec = pm.get(f"{model_name}/B{B}/{precision}")
         if rec and pm.get("lib_sha16") and pm["lib_sha16"] == lib_sha16():
             roof["kernel"] = rec["kernel"]
             roof["traffic"] = rec["traffic_bytes_per_launch"]
-            roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)"
-            roof["traffic_source"] = pm.get("profile")
+            roof["traffic_unit"] = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes: "
+                                    "FETCH corrected x2 as MI355X_MICROARCH.md prescribes for gfx950, WRITE as reported "
+                                    "(uncalibrated for partial-line writes)")
+            roof["traffic_source"] = rec.get("profile") or pm.get("profile")
             roof["kernel_avg_ms_rocprof"] = rec.get("kernel_avg_ms")
             return
     except Exception:
@@ -208,7 +218,64 @@ def cpu_stream_latency(cfg, sd, chunk=10, n=200):
     return best
 
 
-def cpu_baseline(cfg, sd, T, idim):
+def physical_cores():
+    """One hardware thread per physical core of the CPUs this process may use (sysfs thread_siblings_list)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, firsts = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return firsts
+
+
+def cpu_worker(model_name, threads, T, budget_s):
+    """Worker process of cpu_baseline's pinned rows (bench.py --cpu-worker ...): started with OMP_PROC_BIND=close,
+    OMP_PLACES=cores, OMP_NUM_THREADS=threads and its affinity already restricted to `threads` physical cores."""
+    import torch
+    from oracle import torch_ref
+    from wekws_amd import pack
+    from wekws_amd.utils import synth
+    cfg = dict(synth.MODEL_CONFIGS[model_name])
+    tsd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()}
+    torch.set_num_threads(threads)
+    nb = 128 if threads <= 4 else 1024
+    x = torch.from_numpy(synth.synth_feats(nb, T, cfg["input_dim"], seed=0))
+    torch_ref.forward(cfg, tsd, x)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        torch_ref.forward(cfg, tsd, x)
+        n += nb
+    print(json.dumps({"threads": threads, "batch": nb, "utts": n, "seconds": round(time.perf_counter() - t0, 2),
+                      "torch_threads": torch.get_num_threads()}))
+
+
+def cpu_pinned_rows(model_name, T, budget_s=3.0):
+    """utts/s with ONE OpenMP thread pinned per physical core, for a few core counts (the unpinned "all hardware threads"
+    row loses to one thread on a busy 256-thread host: oversubscription and migration, not the reference's best)."""
+    cores = physical_cores()
+    rows = {}
+    for n in sorted({c for c in (4, 16, 64, len(cores)) if 0 < c <= len(cores)}):
+        env = dict(os.environ, OMP_NUM_THREADS=str(n), OMP_PROC_BIND="close", OMP_PLACES="cores", MKL_NUM_THREADS=str(n))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{model_name},{n},{T},{budget_s}"]
+
+        def pin(sel=cores[:n]):
+            os.sched_setaffinity(0, sel)
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, preexec_fn=pin)
+            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            rows[n] = {"threads": n, "batch": rec["batch"], "utts_per_s": round(rec["utts"] / rec["seconds"], 1),
+                       "sample_s": rec["seconds"]}
+        except Exception as e:                                # (a box that forbids affinity changes: report, do not fail)
+            rows[n] = {"threads": n, "error": str(e)[:200]}
+    return rows, len(cores)
+
+
+def cpu_baseline(cfg, sd, T, idim, model_name="ds_tcn_h256"):
     """The reference's CPU path on this box's host cores, bounded to ~25 s: oracle/torch_ref.py issues the
     ATen CPU operator sequence of the reference's PyTorch forward (the reference tree does not travel to the GPU box)."""
     import torch
@@ -246,26 +313,34 @@ def cpu_baseline(cfg, sd, T, idim):
         sweep[th] = round(n / el, 1)
     cores = max(sweep, key=sweep.get) if sweep else avail
     torch.set_num_threads(cores)
-    n, el = rate(bsz(cores), 10.0, 64 * 1024)
+    n, el = rate(bsz(cores), 8.0, 64 * 1024)
     torch.set_num_threads(avail)
-    return {"value": round(n / el, 1), "unit": "utts/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} utterances (batches of {bsz(cores)}, T={T}) through oracle/torch_ref.py -- the reference's PyTorch CPU "
-                      f"operator sequence (F.linear / conv1d / batch_norm, fp32) -- in {el:.1f} s with {cores} threads, "
-                      f"the best of a sweep {sweep}; host has {ncpu} hardware threads",
+    pinned, nphys = cpu_pinned_rows(model_name, T)
+    rows["pinned_one_thread_per_physical_core"] = pinned
+    value, vcores, how = n / el, int(cores), f"{cores} unpinned threads, the best of a sweep {sweep}"
+    for k, r in pinned.items():
+        if r.get("utts_per_s", 0) > value:
+            value, vcores, how = r["utts_per_s"], int(k), (f"{k} threads pinned one per physical core "
+                                                           "(OMP_PROC_BIND=close, OMP_PLACES=cores, affinity set)")
+    return {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port",
+            "sample": f"batches of T={T} utterances through oracle/torch_ref.py -- the reference's PyTorch CPU operator sequence "
+                      f"(F.linear / conv1d / batch_norm, fp32) -- for 3 .. 8 s per row; reported: {how}; host has {ncpu} hardware "
+                      f"threads on {nphys} physical cores (of those this process may use)",
             "rows": rows}
 
 
-def self_launch(args):
-    """--gpus N without a launcher: spawn the N ranks ourselves (what the driver's torch.distributed.run line does)."""
+def self_launch(args, script=None, need_gpus=True):
+    """--gpus N without a launcher: spawn the N ranks ourselves (what the driver's torch.distributed.run line does).
+    `script` / `need_gpus`: tests/tools/bench_stub.py drives this launcher with CPU ranks."""
     import torch
-    if not os.environ.get("WEKWS_BENCH_STUB") and torch.cuda.device_count() < args.gpus:
+    if need_gpus and torch.cuda.device_count() < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script or __file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -282,11 +357,15 @@ def main():
                     help="seconds of the same forward before the W warm-up steps: an idle MI355X runs its first ~0.25 s "
                          "of work at lower clocks (measured: 0.293 ms per step after 10 steps, 0.244 ms after 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # model,threads,T,seconds: see cpu_pinned_rows
     ap.add_argument("--no-extras", action="store_true", help="only the contract fields + roofline")
     ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3", "f16"],
                     help="matrix arithmetic of `value` (enum wekws_hip_precision); default = f16x3 with block floating "
                          "point (fp32-level accuracy at any operand scale); the f32 number is always reported beside it")
     args = ap.parse_args()
+    if args.cpu_worker:
+        name, th, tt, bud = args.cpu_worker.split(",")
+        return cpu_worker(name, int(th), int(tt), float(bud))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -296,12 +375,9 @@ def main():
     from wekws_amd import pack, parallel
     from wekws_amd.utils import synth
 
-    stub = bool(os.environ.get("WEKWS_BENCH_STUB"))   # test hook for the launcher plumbing only (tests/test_dist.py):
-    rank, world, local = parallel.init_distributed("gloo" if stub else None)   # gloo ranks on CPU, forward stubbed
+    rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
-    if stub:
-        return stub_run(args, torch, dist, parallel, rank, world)
     from wekws_amd.model.kws_model import init_model
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
@@ -316,7 +392,12 @@ def main():
         sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval().set_precision(args.precision)
-    parallel.broadcast_weights(model, src=0, device=dev)
+    torch.cuda.synchronize()
+    t_bc = time.perf_counter()
+    parallel.broadcast_weights(model, src=0, device=dev)     # the job's ONE collective (RCCL over xGMI when world > 1)
+    torch.cuda.synchronize()
+    t_bc = time.perf_counter() - t_bc
+    bc_bytes = 4 * sum(int(t.numel()) for t in model.state_dict().values() if t.is_floating_point())
     model.freeze()
     prec = {"default": "f16x3"}.get(args.precision, args.precision)
 
@@ -354,10 +435,16 @@ def main():
                                           # alternates two 110 MB cache buffers (dropping the result at once recycles ONE
                                           # buffer, whose rewrites hit the memory-side cache: 0.24 instead of 0.28 ms)
     step_ms = time_steps(torch, one_step, max(50, args.steps), 0)
+    # the same steps with the result dropped at once (one output buffer recycled by the caching allocator)
+    step_ms_single = time_steps(torch, lambda: model(x), max(50, args.steps), 0)
+    rank_rates, bc_ms_max = [B * args.steps / elapsed], t_bc * 1e3
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed, t_bc], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_rates = [B * args.steps / float(t[0].item()) for t in allr]
+        bc_ms_max = max(float(t[1].item()) for t in allr) * 1e3
+        elapsed = max(float(t[0].item()) for t in allr)       # MAX over ranks
     assert torch.isfinite(y).all()
 
     if rank == 0:
@@ -379,7 +466,20 @@ def main():
                                   "(GPU clock ramp out of idle); then exactly K timed steps",
                        "parallelism": f"utterance-parallel x{world}"},
             "step_ms": dict(pct(step_ms), samples=len(step_ms), launches_per_sample=GROUP),
+            "value_single_output_buffer": {
+                "value": round(B * world / float(np.median(step_ms_single)) * 1e3, 1), "unit": "utts/s",
+                "step_ms": pct(step_ms_single),
+                "note": "result dropped at once: ONE 110 MB cache buffer is recycled and its rewrites hit the 256 MB "
+                        "memory-side cache; `value` / `step_ms` keep the result bound across the next call (two buffers "
+                        "alternate), as score.py:125 does"},
         }
+        if world > 1:
+            out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "collectives_in_timed_region": 0, "broadcast_bytes": bc_bytes,
+                           "broadcast_ms_max_over_ranks": round(bc_ms_max, 3),
+                           "note": "one broadcast of the weights before the timed region (RCCL over xGMI for backend nccl); "
+                                   "the forward itself has no collective"}
+            out["per_rank_utts_per_s"] = {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1)}
         if args.model in FLOP_PER_UTT:
             roof = mfma_roofline(args.model, B, kern_ms, prec)
             roof["kernel_ms_note"] = "HIP events around the K timed steps / K"
@@ -433,7 +533,7 @@ def main():
                           "note": "instruction-bound radix-4 FFT + mel slots (~2.6 MFLOP per utterance), not HBM-bound"})
             out["rooflines_other"] = other
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim, args.model)
             if extras:
                 for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
                     c2 = dict(synth.MODEL_CONFIGS[name])
@@ -442,39 +542,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def stub_run(args, torch, dist, parallel, rank, world):
-    """WEKWS_BENCH_STUB=1: the multi-rank plumbing of this file on CPU ranks (gloo) with the forward replaced by a
-    sleep -- rendezvous, weight broadcast, barrier-bracketed timing, MAX over ranks, one line from rank 0.  Measures
-    nothing; exists so that the CPU suite can run `bench.py --gpus 2` end to end."""
-    from wekws_amd import pack
-    from wekws_amd.model.kws_model import init_model
-    from wekws_amd.utils import synth
-    cfg = dict(synth.MODEL_CONFIGS["mdtc_small"])
-    model = init_model(cfg)
-    if rank == 0:
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 1234).items()})
-    parallel.broadcast_weights(model, src=0, device=torch.device("cpu"))
-    wsum = float(np.abs(model.packed()[1].astype(np.float64)).sum())
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))                       # rank 1 is slower: the line must carry the MAX
-    dist.barrier()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    ws = torch.tensor([wsum], dtype=torch.float64)
-    dist.all_reduce(ws, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(args.batch * world * args.steps / float(tt.item()), 1),
-                          "unit": "utts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(tt.item()) / args.steps * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
-                          "config": {"workload": "launcher plumbing test (forward stubbed)"},
-                          "weights_identical_on_all_ranks": abs(float(ws.item()) - wsum) < 1e-9}))
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

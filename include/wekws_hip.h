@@ -193,13 +193,25 @@ enum wekws_hip_option {
 int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
 
 /*
+ * The arithmetic a model's calls REALLY run in (an enum wekws_hip_precision, never DEFAULT; negative error code for a NULL
+ * model): desc.precision is a request, and not every backbone has a kernel for every mode -- FSMN and matrix-core
+ * classifiers have the F16X3 kernel only (a precision-F32 request is served by it: same 1e-4 bar, different rounding),
+ * F16 is honoured by the 16-wave DS-TCN / MDTC kernels only, a GRU without an fp16 kernel for its shape runs F32.  A caller
+ * that needs exact-f32 reference rounding (a parity baseline) checks this instead of trusting the request.  Reflects the
+ * kernel-selection options as they are set now.
+ */
+int wekws_hip_effective_precision(const wekws_hip_model* m);
+
+/*
  * Scratch memory.  Inputs longer than one LDS tile (WEKWS_HIP_TILE_FRAMES frames; FSMN: 64) and every GRU call take
  * scratch from a grow-only buffer owned by (model, stream).  Growing it allocates, and frees the previous buffer behind
  * ONE synchronisation of that stream -- the only synchronisation the library ever performs on a caller's stream.  To keep
  * calls free of it (latency-critical loops; required before capturing a stream into a HIP graph, where a call that
  * would have to grow fails with WEKWS_HIP_EINVAL instead), size the buffer up front:
- *   wekws_hip_workspace_bytes  bytes a forward of (B, T) needs (0: none)
- *   wekws_hip_reserve          make the stream's buffer at least that large now
+ *   wekws_hip_workspace_bytes  bytes a forward of exactly (B, T) needs (0: none).  NOT monotonic: a GRU chunk of <= 16
+ *                              frames is spread over more workgroups and needs more scratch than a longer one
+ *   wekws_hip_reserve          make the stream's buffer large enough for every call of at most B streams x at most T
+ *                              frames now (the maximum of the above over the shapes where the launch geometry changes)
  *   wekws_hip_release          free the stream's buffer (e.g. before destroying the stream)
  */
 size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T);
@@ -328,6 +340,15 @@ int wekws_hip_score_maxpool(const float* scores, int B, int T, int K, const int3
  */
 int wekws_hip_det_false_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
                                const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream);
+/*
+ * The same scan on the scores AS THE REFERENCE'S TEXT FILE CARRIES THEM: score.py:134-135 writes '{:.6f}' and
+ * compute_det.py parses that back, so every score is rounded to six decimals before it meets a threshold -- 0.4999997
+ * is "0.500000" and counts as >= 0.5.  Use this one (and round the maxima of wekws_hip_score_maxpool the same way on the
+ * host: rounding is monotonic, so max and rounding commute) to reproduce a stats file bit for bit; use the plain one for
+ * the float32 posteriors themselves.
+ */
+int wekws_hip_det_false_alarms_text(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                                    const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream);
 
 #ifdef __cplusplus
 }

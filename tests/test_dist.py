@@ -93,19 +93,46 @@ def test_load_packed_is_superseded_by_later_weight_changes():
     assert not np.array_equal(m.packed()[1], blob_a)
 
 
+def test_load_packed_survives_moving_the_module():
+    """`m.load_packed(blob); m.cuda()` (or .to(dtype)) replaces every parameter / buffer object -- version
+    counters restart -- but does not change a weight: the installed blob must stay what packed() reports and what runs,
+    not be silently dropped in favour of the module's own (possibly default-initialised) tensors.  A real edit after the
+    move still supersedes it."""
+    cfg = synth.MODEL_CONFIGS["ds_tcn_h64"]
+    m = init_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(pack.model_spec(cfg), 6).items()})
+    _, blob = pack.pack(cfg, synth.synth_state_dict(pack.model_spec(cfg), 5))
+    m.load_packed(blob)
+    m.to(torch.float64)
+    m.to(torch.float32)
+    assert np.array_equal(m.packed()[1], blob)
+    m.freeze()
+    m.to(torch.float64).to(torch.float32)          # frozen models keep the blob through a move as well
+    assert np.array_equal(m.packed()[1], blob)
+    with torch.no_grad():
+        m.classifier.linear.bias.add_(1.0)
+    assert not np.array_equal(m.packed()[1], blob)
+    m.load_packed(blob)
+    with torch.no_grad():
+        m.classifier.linear.bias.add_(1.0)         # edited BEFORE the move: the move must not resurrect the blob
+    m.to(torch.float64).to(torch.float32)
+    assert not np.array_equal(m.packed()[1], blob)
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` without a launcher must spawn the two ranks itself (what the driver's own
     torch.distributed.run line does) and print ONE line with n_gpus = 2 and the MAX-over-ranks time.  CPU ranks over gloo
-    with the forward stubbed (WEKWS_BENCH_STUB: the launcher / rendezvous / broadcast / timing plumbing is what is under
-    test; the GPU path of the same file runs on the GPU box)."""
+    with the forward stubbed (tests/tools/bench_stub.py calls bench.self_launch: the launcher / rendezvous / broadcast /
+    timing plumbing is what is under test; the GPU path, bench.py itself, runs on the GPU box)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WEKWS_BENCH_STUB="1")
+    env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "bench_stub.py"), "--gpus", "2", "--steps", "5",
+                        "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -40,5 +40,11 @@ def test_contract_line_small_run():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    pinned = c["rows"]["pinned_one_thread_per_physical_core"]          # one OpenMP thread per physical core, affinity set
+    assert pinned and all(("utts_per_s" in r) or ("error" in r) for r in pinned.values())
+    assert c["value"] >= max([r.get("utts_per_s", 0) for r in pinned.values()] + [c["rows"]["one_core"]["utts_per_s"]]) - 1e-6
+    # both allocator patterns of the headline are in the record
+    v1 = d["value_single_output_buffer"]
+    assert v1["value"] > 0 and "median" in v1["step_ms"]
     # the product is (much) faster than the CPU path it replaces; not a quality claim, a sanity check of both numbers
     assert d["value"] > 10 * c["value"]

@@ -54,3 +54,42 @@ def test_det_on_model_posteriors():
     mx, am = det.max_pool_scores(y)
     rmx, ram = det_oracle.max_pool(y.cpu().numpy())
     assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(am.cpu().numpy(), ram)
+
+
+def test_det_through_the_score_text_file():
+    """the reference's chain is score.py -> '{:.6f}' text -> compute_det.py, so its comparisons see scores
+    rounded to six decimals: 0.4999997 is written "0.500000" and counts as >= 0.5.  The `_text` scan (text_format=True)
+    must reproduce that chain -- here recorded by formatting the float32 scores exactly as score.py:134-135 does, parsing
+    them back like compute_det.py:53-57 and running the pinned oracle loops on the parsed lists -- including scores
+    planted within 5e-7 of thresholds on both sides, where the plain float32 scan answers differently."""
+    rng = np.random.default_rng(7)
+    B, T, K, kw, ws, step = 24, 60, 2, 1, 5, 0.01
+    s = rng.random((B, T, K)).astype(np.float32)
+    th = det.det_thresholds(step)
+    near = np.float32(th[rng.integers(1, len(th) - 1, size=(B, 12))])
+    delta = np.float32(rng.choice([-4e-7, -2e-7, 2e-7, 4e-7], size=(B, 12)))
+    cols = rng.integers(0, T, size=(B, 12))
+    for b in range(B):
+        s[b, cols[b], kw] = near[b] + delta[b]
+    lengths = rng.integers(T // 2, T + 1, size=B).astype(np.int32)
+    is_kw = rng.random(B) < 0.4
+    dur = 3600.0
+    st, lt = torch.from_numpy(s).cuda(), torch.from_numpy(lengths).cuda()
+    parsed = [[float(tok) for tok in " ".join("{:.6f}".format(x) for x in s[b, :lengths[b], kw].tolist()).split()]
+              for b in range(B)]                                   # score.py:134-135 -> compute_det.py:53-57
+    want = np.asarray([[det_oracle.false_alarms(parsed[b], t, ws) for t in th] for b in range(B)])
+    got_text = det.false_alarm_counts(st, kw, th, ws, lt, text_format=True).cpu().numpy()
+    got_raw = det.false_alarm_counts(st, kw, th, ws, lt).cpu().numpy()
+    assert np.array_equal(got_text, want)
+    assert not np.array_equal(got_raw, want)                       # the planted scores do flip counts
+    rows = det.det_stats(st, lt, is_kw, kw, dur, step, ws, text_format=True)
+    # the stats rows from the parsed lists, with the reference's own loop structure (compute_det.py:79-104)
+    ref_rows, frr, fah = [], 0.0, 0.0
+    for t in th:
+        nfr = sum(1 for b in range(B) if is_kw[b] and float(max(parsed[b])) < t)
+        nfa = sum(det_oracle.false_alarms(parsed[b], t, ws) for b in range(B) if not is_kw[b])
+        if is_kw.any():
+            frr = nfr / int(is_kw.sum())
+        fah = max(nfa, 1e-6) / (dur / 3600.0)
+        ref_rows.append((float(t), fah, frr))
+    assert rows == ref_rows

@@ -446,8 +446,27 @@ def test_fsmn_f32_request_is_served_by_the_block_floating_kernel():
     sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
     x = synth.synth_feats(2, 20, cfg["input_dim"], seed=1)
     y0, c0 = run(build(cfg, sd), x)
-    y1, c1 = run(build(cfg, sd).set_precision("f32"), x)
+    m32 = build(cfg, sd).set_precision("f32")
+    y1, c1 = run(m32, x)
     assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
+    # ... and the library says so: the request is 'f32', what runs is 'f16x3' (wekws_hip_effective_precision)
+    assert m32.effective_precision() == "f16x3" and build(cfg, sd).effective_precision() == "f16x3"
+
+
+def test_effective_precision_reports_what_runs():
+    """desc.precision is a request; wekws_hip_effective_precision is the truth a parity baseline can rely on."""
+    from wekws_amd import pack
+    want = {("ds_tcn_h256", "default"): "f16x3", ("ds_tcn_h256", "f32"): "f32", ("ds_tcn_h256", "f16"): "f16",
+            ("ds_tcn_h64", "f16"): "f16x3", ("ds_tcn_h64", "f32"): "f32", ("mdtc_h64", "f16"): "f16",
+            ("mdtc_small", "f16"): "f16x3", ("gru_2x128", "f32"): "f32", ("gru_2x128", "default"): "f16x3",
+            ("gru_2x128", "f16"): "f16x3", ("tcn_h64", "f16x3"): "f16x3", ("fsmn_small", "f16"): "f16x3"}
+    for (name, prec), eff in want.items():
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3)).set_precision(prec)
+        assert m.effective_precision() == eff, (name, prec)
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3)).set_precision("f16").set_option("w16", 0)
+    assert m.effective_precision() == "f16x3"           # the generic kernel has no one-product mode
 
 
 def test_weight_update_repacks():
@@ -704,3 +723,33 @@ def test_reserve_makes_long_inputs_capturable():
         torch.cuda.synchronize()
         assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), name
         assert _capi.load().wekws_hip_workspace_bytes(model._get_handle(x.device).ptr, 3, T) > 0
+
+
+def test_reserve_covers_every_smaller_shape():
+    """the scratch need is not monotonic in (B, T) -- a GRU streaming chunk of <= 16 frames spreads its streams
+    over more workgroups than a longer call -- so reserve(B, T) has to hold the maximum over the shapes it claims to cover.
+    After reserve(256, 20): 10-frame chunks of 256, 128 and 3 streams capture into a HIP graph (a call that had to grow the
+    buffer would fail inside the capture) and replay bit-identically."""
+    from wekws_amd import _capi, pack
+    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"])
+    model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234)).freeze()
+    lib, dev = _capi.load(), torch.device("cuda", torch.cuda.current_device())
+    h = model._get_handle(dev)
+    assert lib.wekws_hip_workspace_bytes(h.ptr, 256, 10) > lib.wekws_hip_workspace_bytes(h.ptr, 256, 20)   # the trap itself
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model.reserve(256, 20)
+    torch.cuda.synchronize()
+    for B, T in ((256, 10), (128, 10), (3, 16), (256, 20), (200, 1)):
+        x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=B + T)).cuda()
+        h0 = torch.from_numpy(synth.synth_feats(2, B, 128, seed=3)).cuda().contiguous()
+        y_ref, c_ref = model(x, h0)
+        torch.cuda.synchronize()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y_static, c_static = model(x, h0)
+        y_static.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), (B, T)

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Turn the FETCH_SIZE / WRITE_SIZE passes and the kernel trace of tools/pmc.sh into profiles/r02_pmc_traffic.json --
+"""Turn the FETCH_SIZE / WRITE_SIZE passes and the kernel trace of tools/pmc.sh into profiles/pmc_traffic.json --
 the file bench.py reads `roofline.kernel` / `roofline.traffic` from, keyed by the sha-256 of the library file the passes
 ran with (bench.py ignores the file unless it loads that very library).
 
-    python tools/pmc_traffic.py <key>=<tag> [<key>=<tag> ...] --profile profiles/r02a_....txt
-        key  "model/B<batch>/<precision>", e.g. ds_tcn_h256/B1024/f16x3
-        tag  the <tag> given to tools/pmc.sh (reads gpurun_out/prof_<tag>_{trace,fetch,write}/)
+    python tools/pmc_traffic.py <key>=<tag>[=<profile summary>] [...]
+        key      "model/B<batch>/<precision>", e.g. ds_tcn_h256/B1024/f16x3
+        tag      the <tag> given to tools/pmc.sh (reads gpurun_out/prof_<tag>_{trace,fetch,write}/)
+        profile  the committed text summary of THOSE passes (profiles/rNN..._f16x3.txt): bench.py's traffic_source
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports
 half the bytes of wide coalesced reads; WRITE_SIZE is taken as reported (uncalibrated for partial-line writes).
 """
@@ -41,22 +42,22 @@ def counter(tag, kind, name, kernel):
 
 def main():
     args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
-    profile = sys.argv[sys.argv.index("--profile") + 1] if "--profile" in sys.argv else None
     from wekws_amd import _capi
     sha = hashlib.sha256(open(_capi.lib_path(), "rb").read()).hexdigest()[:16]
-    out = {"lib_sha16": sha, "profile": profile,
+    out = {"lib_sha16": sha,
            "formula": "(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes; gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md, HBM)",
            "command": "tools/pmc.sh <tag> python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 [--precision f32]"}
     for a in args:
-        key, tag = a.split("=")
+        key, tag, *prof = a.split("=")
         kernel, calls, avg_ns = dominant_kernel(tag)
         fetch, nf = counter(tag, "fetch", "FETCH_SIZE", kernel)
         write, nw = counter(tag, "write", "WRITE_SIZE", kernel)
         out[key] = {"kernel": kernel, "kernel_avg_ms": round(avg_ns / 1e6, 4) if avg_ns > 1e3 else round(avg_ns / 1e3, 4),
                     "calls_in_trace": calls, "FETCH_SIZE_KiB": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
-                    "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024))}
+                    "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
+                    "profile": prof[0] if prof else None}
         print(key, out[key])
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "wekws_hip_cache_elems": (C.c_size_t, [C.c_void_p, C.c_int]),
     "wekws_hip_output_elems": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "wekws_hip_effective_precision": (C.c_int, [C.c_void_p]),
     "wekws_hip_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wekws_hip_release": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "wekws_hip_softmax_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wekws_hip_score_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wekws_hip_det_false_alarms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p]),
+    "wekws_hip_det_false_alarms_text": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p]),
     "wekws_hip_splice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p]),

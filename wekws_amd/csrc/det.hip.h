@@ -11,6 +11,13 @@
 // for the max (wave arg-max, ties -> lowest frame, like list.index(max(list))); one thread per (utterance, threshold)
 // for the sequential alarm scan (T is ~100 frames for a 1-s utterance; the scan of one threshold is inherently serial,
 // the 101 thresholds and the utterances are the parallelism).
+//
+// "Bit-exact" has one more link in the reference's chain: score.py:134-135 writes every score as '{:.6f}' text and
+// compute_det.py compares the PARSED values, so a score within 5e-7 of a threshold (0.4999997 -> "0.500000") counts on the
+// other side of it than the float32 it came from.  The plain entry points compare the float32 scores (what a caller that
+// skips the text file means); the `_text` alarm scan (template R6) first rounds each score to six decimals the way the
+// text round trip does -- rint(s * 1e6) / 1e6 in double, which is float(format(s, '.6f')) except on exact decimal ties
+// of s * 1e6 that a float32 cannot produce -- and the host mirror rounds the maxima the same way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,6 +51,7 @@ __global__ __launch_bounds__(256) void det_maxpool_kernel(const float* __restric
   }
 }
 
+template <bool R6>
 __global__ __launch_bounds__(256) void det_alarm_kernel(const float* __restrict__ scores, int B, int T, int K, int keyword,
                                                         const int32_t* __restrict__ lengths,
                                                         const double* __restrict__ thresholds, int n_thr, int window_shift,
@@ -56,7 +64,9 @@ __global__ __launch_bounds__(256) void det_alarm_kernel(const float* __restrict_
   const float* p = scores + int64_t(b) * T * K + keyword;
   int n = 0, i = 0;
   while (i < len) {
-    if (double(p[int64_t(i) * K]) >= th) { ++n; i += window_shift; }
+    double v = double(p[int64_t(i) * K]);
+    if constexpr (R6) v = rint(v * 1e6) / 1e6;                // score.py:134-135 '{:.6f}' -> float(): six decimals
+    if (v >= th) { ++n; i += window_shift; }
     else ++i;
   }
   alarms[e] = n;
@@ -70,11 +80,15 @@ inline int launch_det_maxpool(const float* scores, int B, int T, int K, const in
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-inline int launch_det_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+inline int launch_det_alarms(bool text6, const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
                              const double* thresholds, int n_thr, int window_shift, int32_t* alarms, hipStream_t stream) {
   const int64_t n = int64_t(B) * n_thr;
-  hipLaunchKernelGGL(det_alarm_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scores, B, T, K, keyword,
-                     lengths, thresholds, n_thr, window_shift, alarms);
+  if (text6)
+    hipLaunchKernelGGL(det_alarm_kernel<true>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scores, B, T, K, keyword,
+                       lengths, thresholds, n_thr, window_shift, alarms);
+  else
+    hipLaunchKernelGGL(det_alarm_kernel<false>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, scores, B, T, K, keyword,
+                       lengths, thresholds, n_thr, window_shift, alarms);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

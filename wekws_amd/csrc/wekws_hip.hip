@@ -786,6 +786,23 @@ int wekws_hip_cache_dim(const wekws_hip_model* m) {
 }
 int wekws_hip_cache_len(const wekws_hip_model* m) { return m ? m->cache_len : 0; }
 
+int wekws_hip_effective_precision(const wekws_hip_model* m) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  const wekws_hip_desc& d = m->desc;
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return WEKWS_HIP_PRECISION_F16X3;        // one kernel (fsmn_f16.hip.h)
+  if (d.backbone == WEKWS_HIP_BACKBONE_GRU)
+    return (d.precision == WEKWS_HIP_PRECISION_F32 || !wekws::gru_f16_supported(m->gq)) ? WEKWS_HIP_PRECISION_F32
+                                                                                           : WEKWS_HIP_PRECISION_F16X3;
+  if (d.precision == WEKWS_HIP_PRECISION_F32) return WEKWS_HIP_PRECISION_F32;          // conv_stack.hip.h serves every shape
+  if (d.precision == WEKWS_HIP_PRECISION_F16) {
+    // one product per term only where a 16-wave kernel takes the `split` switch (wekws_hip_forward's dispatch)
+    const bool ds16 = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && d.hdim == 256 && m->w16_ok && !m->mm_ok;
+    const bool md16 = d.backbone == WEKWS_HIP_BACKBONE_MDTC && m->mdtc16_ok;
+    if (ds16 || md16) return WEKWS_HIP_PRECISION_F16;
+  }
+  return WEKWS_HIP_PRECISION_F16X3;
+}
+
 size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
   if (!m || B <= 0) return 0;
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * m->desc.hdim;
@@ -815,9 +832,31 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
 
 size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T) { return m ? workspace_need(m, B, T) : 0; }
 
+// What a reservation for "calls of up to (B, T)" has to hold: workspace_need() is not monotonic -- a GRU chunk of <= 16
+// frames spreads its streams over more, smaller workgroups (gru_f16_spw), so (256, 10) needs more scratch than (256, 20)
+// and (128, 10) as much as (256, 10) -- so the maximum over the shapes where the geometry changes is taken: the frame
+// counts {T, min(T, 16)} and the stream counts B, the packed-workgroup boundaries 2^k x (workgroups) below B, and the
+// two-tiles-per-workgroup threshold.
+static size_t reserve_need(const wekws_hip_model* m, int B, int T) {
+  size_t need = 0;
+  const int ts[2] = {T, T < 16 ? T : 16};
+  int bs[8], nb = 0;
+  bs[nb++] = B;
+  const int wgs = m->fsmn_cus < wekws::kGruMaxPackedWgs ? m->fsmn_cus : wekws::kGruMaxPackedWgs;
+  for (int k = 1; k <= 16; k *= 2)
+    if (k * wgs < B) bs[nb++] = k * wgs;
+  if (16 * 256 < B) bs[nb++] = 16 * 256;
+  for (int i = 0; i < nb; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const size_t n = workspace_need(m, bs[i], ts[j]);
+      need = n > need ? n : need;
+    }
+  return need;
+}
+
 int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream_) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
-  const size_t need = workspace_need(m, B, T);
+  const size_t need = reserve_need(m, B, T);
   if (!need) return WEKWS_HIP_OK;
   DeviceGuard guard(m->device);
   if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
@@ -1093,17 +1132,25 @@ int wekws_hip_score_maxpool(const float* scores, int B, int T, int K, const int3
   return WEKWS_HIP_OK;
 }
 
-int wekws_hip_det_false_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
-                               const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream_) {
+static int det_false_alarms(bool text6, const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                            const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream_) {
   if (!scores || !thresholds || !alarms) return fail(WEKWS_HIP_EINVAL, "NULL argument");
   if (B < 0 || T <= 0 || K <= 0 || keyword < 0 || keyword >= K || n_thr <= 0 || window_shift <= 0)
     return fail(WEKWS_HIP_EINVAL, "B=%d T=%d K=%d keyword=%d n_thr=%d window_shift=%d", B, T, K, keyword, n_thr, window_shift);
   if (B == 0) return WEKWS_HIP_OK;
   if ((int64_t(B) * n_thr + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "det_false_alarms: too many items for one launch");
-  const int rc = wekws::launch_det_alarms(scores, B, T, K, keyword, lengths, thresholds, n_thr, window_shift, alarms,
+  const int rc = wekws::launch_det_alarms(text6, scores, B, T, K, keyword, lengths, thresholds, n_thr, window_shift, alarms,
                                           static_cast<hipStream_t>(stream_));
   if (rc) return fail(rc, "det_alarm launch failed: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
+}
+int wekws_hip_det_false_alarms(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                               const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream_) {
+  return det_false_alarms(false, scores, B, T, K, keyword, lengths, thresholds, n_thr, window_shift, alarms, stream_);
+}
+int wekws_hip_det_false_alarms_text(const float* scores, int B, int T, int K, int keyword, const int32_t* lengths,
+                                    const double* thresholds, int n_thr, int window_shift, int32_t* alarms, void* stream_) {
+  return det_false_alarms(true, scores, B, T, K, keyword, lengths, thresholds, n_thr, window_shift, alarms, stream_);
 }
 
 }  // extern "C"

@@ -50,32 +50,45 @@ def max_pool_scores(scores: torch.Tensor, lengths: Optional[torch.Tensor] = None
     return mx, am.to(torch.int64)
 
 
+def round_like_score_file(values: np.ndarray) -> np.ndarray:
+    """float64 values as compute_det.py sees scores after score.py:134-135 wrote them as '{:.6f}' text."""
+    return np.asarray([float("{:.6f}".format(v)) for v in np.asarray(values, np.float64).ravel()],
+                      np.float64).reshape(np.shape(values))
+
+
 def false_alarm_counts(scores: torch.Tensor, keyword: int, thresholds: Sequence[float], window_shift: int = 50,
-                       lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(B, T, K) posteriors -> (B, n_thr) int32 alarm counts of column `keyword`: the scan of compute_det.py:88-96."""
+                       lengths: Optional[torch.Tensor] = None, text_format: bool = False) -> torch.Tensor:
+    """(B, T, K) posteriors -> (B, n_thr) int32 alarm counts of column `keyword`: the scan of compute_det.py:88-96.
+    text_format: compare the scores rounded to six decimals, i.e. as the reference's score text file carries them."""
     s, ln = _check(scores, lengths)
     B, T, K = (int(v) for v in s.shape)
     th = torch.from_numpy(np.ascontiguousarray(thresholds, np.float64)).to(s.device)
     out = torch.empty((B, th.numel()), dtype=torch.int32, device=s.device)
     if B and T and K:
         stream = torch.cuda.current_stream(s.device).cuda_stream
-        _capi.check(_capi.load().wekws_hip_det_false_alarms(s.data_ptr(), B, T, K, int(keyword),
-                                                            ln.data_ptr() if ln is not None else None, th.data_ptr(),
-                                                            int(th.numel()), int(window_shift), out.data_ptr(),
-                                                            ctypes.c_void_p(stream)), "wekws_hip_det_false_alarms")
+        lib = _capi.load()
+        fn = lib.wekws_hip_det_false_alarms_text if text_format else lib.wekws_hip_det_false_alarms
+        _capi.check(fn(s.data_ptr(), B, T, K, int(keyword), ln.data_ptr() if ln is not None else None, th.data_ptr(),
+                       int(th.numel()), int(window_shift), out.data_ptr(), ctypes.c_void_p(stream)),
+                    "wekws_hip_det_false_alarms")
     return out
 
 
 def det_stats(scores: torch.Tensor, lengths: Optional[torch.Tensor], is_keyword: Sequence[bool], keyword: int,
-              filler_duration: float, step: float = 0.01, window_shift: int = 50) -> List[Tuple[float, float, float]]:
+              filler_duration: float, step: float = 0.01, window_shift: int = 50,
+              text_format: bool = False) -> List[Tuple[float, float, float]]:
     """The rows compute_det.py:97-104 writes to its stats file -- (threshold, false alarms per hour, false reject rate)
     -- for one keyword column of a scored batch: `is_keyword[b]` says whether utterance b's transcript is the keyword
-    (compute_det.py:45-50).  Only the (B,) maxima and the (B, n_thr) counts leave the device."""
+    (compute_det.py:45-50).  Only the (B,) maxima and the (B, n_thr) counts leave the device.
+    text_format=True reproduces the stats file of the reference's score.py -> compute_det.py chain bit for bit: there the
+    scores pass through '{:.6f}' text (score.py:134-135) before they are compared."""
     th = det_thresholds(step)
     mx, _ = max_pool_scores(scores, lengths)
-    alarms = false_alarm_counts(scores, keyword, th, window_shift, lengths).cpu().numpy()
+    alarms = false_alarm_counts(scores, keyword, th, window_shift, lengths, text_format=text_format).cpu().numpy()
     kw = np.asarray(list(is_keyword), bool)
     mk = mx[:, keyword].cpu().numpy().astype(np.float64)[kw]
+    if text_format:
+        mk = round_like_score_file(mk)                       # max and a monotonic rounding commute
     rows = []
     false_reject_rate = false_alarm_per_hour = 0.0           # (the reference leaves them undefined when a table is empty)
     for j, t in enumerate(th):

@@ -115,11 +115,20 @@ class KWSModel(nn.Module):
 
     # ------------------------------------------------------------------ weights -> device library
     def _apply(self, fn, *args, **kwargs):
-        # .to() / .cuda() / .float(): buffers become new tensor objects and storages move
+        # .to() / .cuda() / .float(): buffers become new tensor objects (version counters restart at 0) and storages move.
+        # Moving or casting the module's tensors is not a modification of the weights: a blob installed by load_packed()
+        # that was still valid before the move stays what runs (and what packed() / checkpoints report) after it.
+        blob = getattr(self, "_packed_blob", None)
+        keep = blob is not None and (self._frozen or self._versions() == self._packed_versions)
         self._tlist = None
         self._handle = None
         self._frozen = False
-        return super()._apply(fn, *args, **kwargs)
+        out = super()._apply(fn, *args, **kwargs)
+        if keep:
+            self._packed_versions = self._versions()
+        elif blob is not None:
+            self._packed_blob = None
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         # assign=True swaps the Parameter objects themselves: drop the cached tensor list and re-pack on the next call
@@ -133,6 +142,9 @@ class KWSModel(nn.Module):
         """Promise that the weights will not be modified in place any more: forward stops comparing tensor versions
         (a streaming loop over MDTC's 363 tensors otherwise spends more host time there than the GPU needs for the
         chunk).  load_state_dict / .to() / set_precision / load_packed lift the promise again."""
+        if getattr(self, "_packed_blob", None) is not None and self._versions() != self._packed_versions:
+            self._packed_blob = None      # edited after load_packed(): the module's own tensors win (as in _get_handle)
+            self._handle = None
         self._frozen = True
         return self
 
@@ -193,6 +205,15 @@ class KWSModel(nn.Module):
         self._handle = None
         self._frozen = False
         return self
+
+    def effective_precision(self, device: Optional[torch.device] = None) -> str:
+        """The arithmetic the calls really run in -- 'f32' | 'f16x3' | 'f16' (wekws_hip_effective_precision).  set_precision
+        is a request: FSMN has the split-fp16 kernel only (an 'f32' request gets 'f16x3': same 1e-4 bar, not the
+        reference's rounding), 'f16' is honoured by the 16-wave DS-TCN / MDTC kernels only."""
+        dev = device or next(self.parameters()).device
+        code = _capi.load().wekws_hip_effective_precision(self._get_handle(dev).ptr)
+        _capi.check(min(code, 0), "wekws_hip_effective_precision")
+        return {v: k for k, v in pack.PRECISION.items()}[code]
 
     def set_option(self, name: str, value: int) -> "KWSModel":
         """Kernel-selection override (enum wekws_hip_option: 'w16', 'mdtc16', 'stream', 'mm', 'head_slices') -- for A/B

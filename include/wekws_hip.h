@@ -188,7 +188,8 @@ enum wekws_hip_option {
   WEKWS_HIP_OPT_STREAM = 2,     /* chunks of <= 16 frames: 1 (default) the kernels with the LDS-resident cache, 0 the batch kernels */
   WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
   WEKWS_HIP_OPT_HEAD_SLICES = 4,/* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
-  WEKWS_HIP_OPT_G16 = 5         /* DS-TCN hidden 256, calls without an incoming cache: 1 (default) the kernel that keeps the residual tile in registers (ds256_g16.hip.h), 0 the 16-wave LDS-tile kernel */
+  WEKWS_HIP_OPT_G16 = 5,        /* DS-TCN hidden 256, calls without an incoming cache: 1 (default) the kernel that keeps the residual tile in registers (ds256_g16.hip.h), 0 the 16-wave LDS-tile kernel */
+  WEKWS_HIP_OPT_ENVELOPE = 6    /* weights outside the split-fp16 envelope (wekws_hip_weight_spread_log2): 1 (default) run the exact-f32 kernels, 0 keep the split-fp16 kernels (to MEASURE where the envelope ends; accuracy is then not promised) */
 };
 int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
 
@@ -201,6 +202,17 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
  * kernel-selection options as they are set now.
  */
 int wekws_hip_effective_precision(const wekws_hip_model* m);
+/*
+ * The envelope of the split-fp16 kernels.  Block floating point gives every weight matrix ONE power-of-two scale, so an
+ * element keeps 22 significand bits only within 16 binades of the matrix maximum; a model whose matrices spread the
+ * magnitudes of their rows (or of their K columns) over more than 2^WEKWS_HIP_F16X3_ENVELOPE_LOG2 would lose fp32-level
+ * accuracy in the small rows (measured against the live reference: tests/golden/make_hetero_golden.py).  wekws_hip_create
+ * measures the spread; a DEFAULT / F16X3 model beyond the envelope runs the exact-f32 kernels instead
+ * (wekws_hip_effective_precision reports F32), an FSMN beyond it is refused with WEKWS_HIP_EUNSUPPORTED (no f32 kernel).
+ *   wekws_hip_weight_spread_log2   the largest such spread of the model, in binades (-1 for a NULL model)
+ */
+#define WEKWS_HIP_F16X3_ENVELOPE_LOG2 20
+float wekws_hip_weight_spread_log2(const wekws_hip_model* m);
 
 /*
  * Scratch memory.  Inputs longer than one LDS tile (WEKWS_HIP_TILE_FRAMES frames; FSMN: 64) and every GRU call take

@@ -242,3 +242,110 @@ def scaled_case_weights(case, sd):
     """Apply the case's sweep to the synthetic state_dict `sd` -> (sd, feature factor)."""
     kind, k = case["scale"]
     return scale_state_dict(case_config(case), sd, kind, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Heterogeneous scales (VERDICT r2 #2).  The sweeps above move WHOLE tensors by 2^k; block floating point gives every matrix
+# and every operand tile ONE scale, so what it cannot absorb is a spread INSIDE a matrix / tile.  These rewrites scale
+# individual channels with exact powers of two 2^-k, k drawn per channel from 0 .. E, again without changing the function
+# (ReLU is positively homogeneous per channel, eval BatchNorm is per-channel affine):
+#   "chan"  the residual stream: channel c of h carries 2^-k_c everywhere -- preprocessing row c and BN2's (gamma, beta)
+#           of output channel c scaled down, the depthwise taps that read channel c and the classifier column c scaled up.
+#           Matrices get ROWS spread over 2^E, the f32 activation tile gets channels spread over 2^E.
+#   "kcol"  the pointwise convolutions' K axis: the operand channel k (BN in front of the matrix: gamma, beta) scaled down,
+#           the matrix column k scaled up.  Operand tiles get channels, matrices get COLUMNS spread over 2^E.
+# Goldens come from the live reference on the rewritten model (tests/golden/make_hetero_golden.py), which also asserts that
+# the reference's own outputs do not move.  Inside 2^20 the split-fp16 kernels must hold the 1e-4 bar; beyond it
+# wekws_hip_create routes the model to the exact-f32 kernels (WEKWS_HIP_F16X3_ENVELOPE_LOG2), FSMN is refused.
+def _chan_factors(n, E, seed):
+    g = np.random.default_rng([0x4E7E, seed, E, n])
+    k = g.integers(0, E + 1, size=n)
+    k[g.integers(0, n)] = 0
+    k[(int(np.argmin(k)) + 1 + g.integers(0, n - 1)) % n] = E          # both ends of the range are present
+    return np.float64(2.0) ** (-k.astype(np.float64))
+
+
+def hetero_state_dict(cfg, sd, kind, E, seed=0):
+    sd = {n: np.array(v, copy=True) for n, v in sd.items()}
+    bb = cfg["backbone"]
+    t = bb["type"]
+
+    def rows(name, f):           # scale dim 0 (output channels / per-channel vectors)
+        w = np.asarray(sd[name], np.float64)
+        sd[name] = (w * f.reshape((-1,) + (1,) * (w.ndim - 1))).astype(np.float32)
+
+    def cols(name, f):           # scale dim 1 (input channels)
+        w = np.asarray(sd[name], np.float64)
+        sd[name] = (w * f.reshape((1, -1) + (1,) * (w.ndim - 2))).astype(np.float32)
+
+    C = bb.get("hidden_dim", cfg["hidden_dim"]) if t == "mdtc" else cfg["hidden_dim"]
+    if t == "fsmn":
+        assert kind == "kcol"
+        L = bb["num_layers"]
+        for l in range(L):
+            f = _chan_factors(bb["linear_dim"], E, seed + l)
+            rows(f"backbone.fsmn.{l}.2.linear.weight", f); rows(f"backbone.fsmn.{l}.2.linear.bias", f)
+            cols(f"backbone.fsmn.{l + 1}.0.linear.weight" if l + 1 < L else "backbone.out_linear1.linear.weight", 1.0 / f)
+        return sd
+    if t == "tcn" and bb.get("ds"):
+        blocks = [f"backbone.network.{i}.cnn." for i in range(bb["num_layers"])]
+        if kind == "chan":
+            s = _chan_factors(C, E, seed)
+            rows("preprocessing.out.0.weight", s); rows("preprocessing.out.0.bias", s)
+            for p in blocks:
+                rows(p + "0.weight", 1.0 / s)
+                rows(p + "4.weight", s); rows(p + "4.bias", s)
+            cols("classifier.linear.weight", 1.0 / s)
+        else:
+            for i, p in enumerate(blocks):
+                f = _chan_factors(C, E, seed + i)
+                rows(p + "1.weight", f); rows(p + "1.bias", f)
+                cols(p + "3.weight", 1.0 / f)
+        return sd
+    if t == "mdtc":
+        from wekws_amd import pack
+        prefixes = [p for p, _ in pack.mdtc_blocks(pack.parse_config(cfg))]
+        if kind == "chan":
+            s = _chan_factors(C, E, seed)
+            rows("preprocessing.out.0.weight", s); rows("preprocessing.out.0.bias", s)
+            for p in prefixes:
+                rows(p + "conv1.conv.weight", 1.0 / s)
+                rows(p + "bn2.weight", s); rows(p + "bn2.bias", s)
+            cols("classifier.linear.weight", 1.0 / s)
+        else:
+            for i, p in enumerate(prefixes):
+                f = _chan_factors(C, E, seed + 2 * i)
+                rows(p + "conv1.bn.weight", f); rows(p + "conv1.bn.bias", f)
+                cols(p + "conv1.pointwise.weight", 1.0 / f)
+                u = _chan_factors(C, E, seed + 2 * i + 1)
+                rows(p + "bn1.weight", u); rows(p + "bn1.bias", u)
+                cols(p + "conv2.weight", 1.0 / u)
+        return sd
+    raise ValueError(f"no heterogeneous rewrite for backbone {t}")
+
+
+def _h(model, kind, E, B=2, T=40, **kw):
+    return _c(f"{model}/{kind}_E{E}" + ("/stream" if kw.get("chunks") else ""), model, B=B, T=T, hetero=(kind, E), **kw)
+
+
+HETERO_CASES = []
+for _m, _kinds, _kw in [("ds_tcn_h256", ("chan", "kcol"), dict(T=98)),
+                        ("ds_tcn_h256", ("chan", "kcol"), dict(T=30, chunks=[10, 10, 10])),
+                        ("ds_tcn_h64", ("chan", "kcol"), dict()),
+                        ("mdtc_h64", ("chan", "kcol"), dict(T=50)),
+                        ("mdtc_h64", ("chan",), dict(T=20, chunks=[10, 10])),
+                        ("fsmn_small", ("kcol",), dict(T=20))]:
+    for _kind in _kinds:
+        for _E in (8, 16, 20, 24, 28):
+            HETERO_CASES.append(_h(_m, _kind, _E, **_kw))
+# the GRU is not homogeneous: nothing to rewrite -- instead inputs far outside the calibration range of its per-step
+# feature maximum and pre_alpha * max|x| + pre_beta bound (DESIGN.md 3.2): saturating and vanishing features
+GRU_INPUT_CASES = [_c(f"gru_2x128/x{k:+d}", "gru_2x128", B=2, T=20, cache="random", xscale=float(2.0 ** k))
+                   for k in (-24, -12, 8, 16)] + \
+                  [_c(f"gru_2x128/x{k:+d}/stream", "gru_2x128", B=2, T=30, chunks=[10, 10, 10], cache="zeros",
+                      xscale=float(2.0 ** k)) for k in (-12, 8)]
+
+
+def hetero_case_weights(case, sd):
+    kind, E = case["hetero"]
+    return hetero_state_dict(case_config(case), sd, kind, E)

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import kws_oracle
-from tests.golden.cases import SCALE_CASES, scaled_case_weights
+from tests.golden.cases import GRU_INPUT_CASES, HETERO_CASES, SCALE_CASES, hetero_case_weights, scaled_case_weights
 from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
 from wekws_amd.model.kws_model import init_model
 from wekws_amd.utils import synth
@@ -63,7 +63,7 @@ def models():
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_golden(case, precision, golden, models):
+def test_golden(case, precision, golden, models, error_report):
     """HIP vs the live-reference golden vectors (58 cases: every backbone/head, ragged T, caches, streaming), in
     both matrix precisions (wekws_hip_precision): exact-f32 MFMA and the fp16 hi/lo split."""
     cfg, sd, model = models(case, precision)
@@ -71,8 +71,11 @@ def test_golden(case, precision, golden, models):
     y, cache = run(model, x, case_in_cache(case, cfg), softmax=case.get("softmax", False), chunks=case.get("chunks"))
     gy, gc = golden[case["name"] + "/y"], golden[case["name"] + "/cache"]
     assert y.shape == gy.shape
-    assert max_abs(y, gy) <= tol_for(gy), f"y err {max_abs(y, gy):.3e}"
     c = cache if cfg["backbone"]["type"] == "gru" else cache[:1]
+    error_report[f"golden/{precision}/{case['name']}/y"] = max_abs(y, gy)
+    if c.shape == gc.shape:
+        error_report[f"golden/{precision}/{case['name']}/cache_rel"] = max_abs(c, gc) / max(1.0, float(np.abs(gc).max()))
+    assert max_abs(y, gy) <= tol_for(gy), f"y err {max_abs(y, gy):.3e}"
     assert c.shape == gc.shape
     assert max_abs(c, gc) <= tol_for(gc), f"cache err {max_abs(c, gc):.3e}"
 
@@ -95,6 +98,63 @@ def test_scale_sweep(case, precision, scale_golden, error_report):
     err = max_abs(y, gy) if np.isfinite(y).all() else float("inf")
     error_report[f"scale_sweep/{precision}/{case['name']}"] = err
     assert err <= tol_for(gy), f"y err {err:.3e}"
+
+
+@pytest.fixture(scope="module")
+def hetero_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hetero_golden.npz"))
+
+
+@pytest.mark.parametrize("case", HETERO_CASES, ids=[c["name"] for c in HETERO_CASES])
+def test_heterogeneous_scales(case, hetero_golden, error_report):
+    """per-channel power-of-two factors spread over 2^E INSIDE matrices and operand tiles
+    (tests/golden/cases.py::hetero_state_dict), goldens from the live reference (which is bit-invariant under the
+    rewrite).  Default precision must hold the 1e-4 bar at every spread: inside the envelope (2^20,
+    WEKWS_HIP_F16X3_ENVELOPE_LOG2) on the split-fp16 kernels, beyond it because wekws_hip_create routes the model to the
+    exact-f32 kernels -- and says so (effective_precision).  Spreads along a matrix's K axis ("kcol") never reach the
+    kernels: wekws_hip_create balances the columns.  The error of the split-fp16 kernels WITHOUT the routing (option
+    envelope = 0) is recorded, not asserted: it is the measurement of where the envelope really ends
+    (gpurun_out/parity_errors.json)."""
+    kind, E = case["hetero"]
+    cfg, sd = case_weights(case)
+    sd2 = hetero_case_weights(case, sd)
+    gy = hetero_golden[case["name"] + "/y"]
+    x = case_input(case)
+    model = build(cfg, sd2)
+    y, _ = run(model, x, case_in_cache(case, cfg), chunks=case.get("chunks"))
+    spread, eff = model.weight_spread_log2(), model.effective_precision()
+    if kind == "kcol":
+        # factors on the K axis of a matrix are absorbed at wekws_hip_create (balance_operand_channels: every column
+        # maximum in [1, 2), the inverse factor folded into the per-channel stage in front): no spread left, no routing
+        assert spread <= 12 and eff == "f16x3", (spread, eff)
+    else:
+        assert spread >= E - 0.5
+        assert eff == ("f16x3" if spread <= 20 else "f32"), (spread, eff)
+        if E <= 8:
+            assert eff == "f16x3"                  # (random rows add 2 .. 5 binades of their own: E = 16 / 20 may land on either side)
+    err = max_abs(y, gy) if np.isfinite(y).all() else float("inf")
+    error_report[f"hetero/default({eff})/{case['name']}"] = err
+    assert err <= tol_for(gy), f"y err {err:.3e} at spread 2^{spread:.1f} ({eff})"
+    if eff == "f32":                               # the split-fp16 kernels on their own beyond the envelope, measured
+        raw = build(cfg, sd2).set_option("envelope", 0)
+        yr, _ = run(raw, x, case_in_cache(case, cfg), chunks=case.get("chunks"))
+        assert raw.effective_precision() == "f16x3"
+        error_report[f"hetero/f16x3_forced/{case['name']}"] = max_abs(yr, gy) if np.isfinite(yr).all() else float("inf")
+
+
+@pytest.mark.parametrize("case", GRU_INPUT_CASES, ids=[c["name"] for c in GRU_INPUT_CASES])
+def test_gru_out_of_range_inputs(case, hetero_golden, error_report):
+    """Features x 2^-24 .. 2^+16 (vanishing / saturating gates): the GRU's per-step feature maximum and its
+    pre_alpha * max|x| + pre_beta bound far from the magnitudes the other goldens exercise."""
+    cfg, sd = case_weights(case)
+    x = (case_input(case) * np.float32(case["xscale"])).astype(np.float32)
+    for precision in ("f16x3", "f32"):
+        y, _ = run(build(cfg, sd).set_precision(precision), x, case_in_cache(case, cfg), chunks=case.get("chunks"))
+        gy = hetero_golden[case["name"] + "/y"]
+        err = max_abs(y, gy) if np.isfinite(y).all() else float("inf")
+        error_report[f"gru_inputs/{precision}/{case['name']}"] = err
+        assert err <= tol_for(gy), f"{precision}: y err {err:.3e}"
 
 
 @pytest.mark.parametrize("name,B,T", [("ds_tcn_h256", 5, 98), ("ds_tcn_h64", 7, 33), ("tcn_h64", 3, 98),
@@ -590,9 +650,11 @@ def test_exported_models(name):
 
 
 @pytest.mark.gpu
-def test_reference_android_asset_hip():
+def test_reference_android_asset_hip(error_report):
     """The trained DS-TCN the reference ships as an ORT file, converted by tests/tools/make_ref_asset.py in the build
-    container (the asset itself is not in this repo): packed file -> C ABI, streamed in 80-frame chunks."""
+    container (the asset itself is not in this repo): packed file -> C ABI, streamed in 80-frame chunks.  The only REAL
+    weights in the suite: the measured margin (and the spread of the trained matrices, wekws_hip_weight_spread_log2) goes
+    to gpurun_out/parity_errors.json."""
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "ref_asset")
     if not os.path.exists(os.path.join(root, "kws.wekwship")):
@@ -612,6 +674,11 @@ def test_reference_android_asset_hip():
                                           y[:, t:t + 80].data_ptr(), caches[(i & 1) ^ 1].data_ptr(), 0,
                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "forward")
     torch.cuda.synchronize()
+    error_report["trained_kws_ort/y"] = max_abs(y.cpu().numpy(), exp["y"])
+    error_report["trained_kws_ort/cache_rel"] = (max_abs(caches[(i + 1) & 1].cpu().numpy(), exp["cache"])
+                                                 / max(1.0, float(np.abs(exp["cache"]).max())))
+    error_report["trained_kws_ort/weight_spread_log2"] = float(lib.wekws_hip_weight_spread_log2(h.ptr))
+    error_report["trained_kws_ort/effective_precision"] = int(lib.wekws_hip_effective_precision(h.ptr))
     assert max_abs(y.cpu().numpy(), exp["y"]) <= POSTERIOR_TOL
     assert max_abs(caches[(i + 1) & 1].cpu().numpy(), exp["cache"]) <= 1e-4 * max(1.0, float(np.abs(exp["cache"]).max()))
 

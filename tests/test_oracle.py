@@ -74,6 +74,35 @@ def test_oracle_matches_scale_sweep_golden(case, scale_golden):
     assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
 
 
+from tests.golden.cases import GRU_INPUT_CASES, HETERO_CASES, hetero_case_weights  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hetero_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hetero_golden.npz"))
+
+
+@pytest.mark.parametrize("case", HETERO_CASES + GRU_INPUT_CASES, ids=[c["name"] for c in HETERO_CASES + GRU_INPUT_CASES])
+def test_oracle_matches_hetero_golden(case, hetero_golden):
+    """Heterogeneous per-channel scales inside matrices / operand tiles (tests/golden/cases.py::hetero_state_dict) and the
+    GRU's out-of-range inputs, goldens from the live reference: the fp32 oracle follows."""
+    cfg, sd = case_weights(case)
+    name = case["name"]
+    if case.get("hetero"):
+        sd = hetero_case_weights(case, sd)
+        assert abs(synth.checksum(sd) - float(hetero_golden[name + "/wsum"])) <= 1e-6 * float(hetero_golden[name + "/wsum"])
+    x = (case_input(case) * np.float32(case.get("xscale", 1.0))).astype(np.float32)
+    cache0 = case_in_cache(case, cfg)
+    if case.get("chunks"):
+        y, _ = kws_oracle.forward_streaming(cfg, sd, x, case["chunks"], cache0)
+    else:
+        y, _ = kws_oracle.forward(cfg, sd, x, cache0)
+    gy = hetero_golden[name + "/y"]
+    assert y.shape == gy.shape
+    assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+
+
 TORCH_REF_STREAM = [c for c in CASES if c.get("chunks") and not c.get("softmax")
                     and c["model"] in ("ds_tcn_h256", "ds_tcn_h64", "tcn_h64", "mdtc_h64", "mdtc_small", "gru_2x128")]
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "wekws_hip_output_elems": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_effective_precision": (C.c_int, [C.c_void_p]),
+    "wekws_hip_weight_spread_log2": (C.c_float, [C.c_void_p]),
     "wekws_hip_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wekws_hip_release": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -61,7 +62,7 @@ SIGNATURES = {
                                    C.c_void_p]),
 }
 
-OPTIONS = {"w16": 0, "mdtc16": 1, "stream": 2, "mm": 3, "head_slices": 4, "g16": 5}   # enum wekws_hip_option
+OPTIONS = {"w16": 0, "mdtc16": 1, "stream": 2, "mm": 3, "head_slices": 4, "g16": 5, "envelope": 6}   # enum wekws_hip_option
 
 _lib: Optional[C.CDLL] = None
 

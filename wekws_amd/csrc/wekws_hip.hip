@@ -92,6 +92,34 @@ inline float pow2_scale_host(float bound, float* inv) {
 // Host-side builder of the device weight image; every section starts 16-byte aligned.
 struct Image {
   std::vector<float> data;
+  // Largest spread (binades) between the row maxima, or between the column maxima, of any matrix packed for the fp16
+  // matrix cores.  Block floating point gives every matrix ONE power-of-two scale: an element 2^-e below the matrix
+  // maximum keeps 22 - max(0, e - 16) significand bits, so a row (or a K column) whose largest element sits more than
+  // ~20 binades below the matrix maximum contributes with visibly less than fp32 precision (measured through the live
+  // reference: tests/golden/make_hetero_golden.py).  wekws_hip_create routes such a model to the exact-f32 kernels.
+  float spread_log2 = 0.f;
+  void note_spread(const float* Wsrc, int O, int Ksrc, int ld) {
+    std::vector<float> rmax(size_t(O), 0.f), cmax(size_t(Ksrc), 0.f);
+    float wmax = 0.f;
+    for (int o = 0; o < O; ++o)
+      for (int k = 0; k < Ksrc; ++k) {
+        const float a = std::fabs(Wsrc[size_t(o) * ld + k]);
+        if (!std::isfinite(a)) continue;
+        rmax[o] = a > rmax[o] ? a : rmax[o];
+        cmax[k] = a > cmax[k] ? a : cmax[k];
+        wmax = a > wmax ? a : wmax;
+      }
+    if (!(wmax > 0.f)) return;
+    auto upd = [&](const std::vector<float>& v) {
+      for (float x : v)
+        if (x > 0.f) {                                       // (all-zero rows / columns: padding, pruned units)
+          const float sp = std::log2(wmax / x);
+          spread_log2 = sp > spread_log2 ? sp : spread_log2;
+        }
+    };
+    upd(rmax);
+    upd(cmax);
+  }
   uint32_t reserve(size_t n) {
     size_t off = (data.size() + 3) / 4 * 4;
     data.resize(off + n, 0.f);
@@ -128,6 +156,7 @@ struct Image {
     const size_t halves = size_t(Op) * Kp * 2;
     uint32_t off = reserve(halves / 2);
     _Float16* dst = reinterpret_cast<_Float16*>(data.data() + off);
+    if (inv_scale) note_spread(Wsrc, O, Ksrc, ld);
     float wmax = 0.f;
     for (int o = 0; o < O; ++o)
       for (int k = 0; k < Ksrc; ++k) {
@@ -255,6 +284,9 @@ struct wekws_hip_model {
   bool mdtc_stream_eligible = false;   // mdtc64_stream.hip.h: dilations 1 / 2 / 4 / 8, the two streams' caches fit into LDS
   bool mdtc16_ok = false; // MDTC h64: the 16-wave kernel (WEKWS_HIP_OPT_MDTC16 = 0: the generic 8-wave one)
   bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
+  float spread_log2 = 0.f;  // Image::spread_log2 of the weights this model was created from
+  bool out_of_envelope = false;  // DEFAULT / F16X3 request, but the weights are outside the split-fp16 envelope ...
+  bool auto_f32 = false;  // ... and therefore the F32 kernels run (WEKWS_HIP_OPT_ENVELOPE = 0 keeps the split-fp16 kernels)
   bool g16_ok = true;     // ... calls without an incoming cache: the register-resident kernel (ds256_g16.hip.h; WEKWS_HIP_OPT_G16 = 0: ds256_w16)
   int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, 0 / 1 off, n forces n
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
@@ -310,7 +342,121 @@ struct wekws_hip_fbank {
 
 // FSMN: validate, zero-pad every channel count to a multiple of 32, pre-split + pre-pack the six kinds of dense
 // layers as MFMA A operands (fsmn_f16.hip.h), upload.
-static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elems, int device, wekws_hip_model** out) {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Operand-channel balancing (round 3).  A matrix product W a is unchanged when column k of W is multiplied by c_k and
+// element k of a by 1 / c_k.  Where a is produced by a per-channel stage the library owns -- the depthwise conv + folded
+// BN (+ ReLU) in front of a pointwise conv, the (ReLU'd) rows of the matrix in front of another matrix -- the factor moves
+// into that stage's weights at no cost, exactly (c_k a power of two > 0; ReLU is positively homogeneous).  The library
+// uses the freedom to give every K column of such a matrix a maximum in [1, 2): the operand tile then carries every
+// channel at the magnitude of its CONTRIBUTION, one block-floating scale per matrix / tile covers the whole K axis, and the
+// chained operand bounds (dw_alpha, mid_alpha, FSMN's affine bounds: products of row 1-norms) stay tight.  Without it a
+// trained model that parks a 2^16 factor in a BatchNorm in front of a pointwise conv breaks the MDTC / FSMN kernels at
+// 1e-3 (tests/golden/cases.py "kcol" cases, measured) although fp32 arithmetic -- the reference -- does not care.
+// What must NOT be rescaled: anything the caller sees -- the residual stream (the conv caches hold it), FSMN's projections
+// (its cache), GRU states.  Matrices are walked from the output side so that a matrix's rows are rescaled (by its
+// consumer's balancing) before its own columns are balanced.  Exact in every precision mode: the F32 kernels compute the
+// same bits as without it.
+// ---------------------------------------------------------------------------------------------------------------------
+// c_k for column k of W[O][K] (leading dimension ld): the power of two that puts the column maximum into [1, 2); 1 for an
+// all-zero (or non-finite) column
+static std::vector<float> column_balance(const float* W, int O, int K, int ld) {
+  std::vector<float> c(size_t(K), 1.f);
+  for (int k = 0; k < K; ++k) {
+    float mx = 0.f;
+    for (int o = 0; o < O; ++o) {
+      const float a = std::fabs(W[size_t(o) * ld + k]);
+      if (std::isfinite(a) && a > mx) mx = a;
+    }
+    if (mx > 0.f) {
+      int e = 0;
+      (void)std::frexp(mx, &e);                              // mx = f 2^e, f in [0.5, 1)  ->  mx 2^(1 - e) in [1, 2)
+      e = 1 - e;
+      e = e > 100 ? 100 : e < -100 ? -100 : e;
+      c[k] = std::ldexp(1.f, e);
+    }
+  }
+  return c;
+}
+static void scale_columns(float* W, int O, int K, int ld, const std::vector<float>& c) {
+  for (int o = 0; o < O; ++o)
+    for (int k = 0; k < K; ++k) W[size_t(o) * ld + k] *= c[k];
+}
+// rows of the producing stage: W[K][n] (n values per channel) and optionally bias[K], multiplied by 1 / c_k
+static void scale_rows_inv(float* W, int K, int n, float* bias, const std::vector<float>& c) {
+  for (int k = 0; k < K; ++k) {
+    const float ic = 1.f / c[k];
+    for (int j = 0; j < n; ++j) W[size_t(k) * n + j] *= ic;
+    if (bias) bias[k] *= ic;
+  }
+}
+static void balance_operand_channels(const wekws_hip_desc& d, float* w) {
+  const int C = d.hdim, ks = d.kernel_size;
+  if (d.backbone == WEKWS_HIP_BACKBONE_DS_TCN) {
+    float* p = w + size_t(C) * d.idim + C;
+    for (int i = 0; i < d.num_layers; ++i) {                 // [wd C x ks][bd C][Wp C x C][bp C]
+      float* wd = p; float* bd = wd + size_t(C) * ks; float* Wp = bd + C;
+      const std::vector<float> c = column_balance(Wp, C, C, C);
+      scale_columns(Wp, C, C, C, c);
+      scale_rows_inv(wd, C, ks, bd, c);                      // a_k = ReLU(dw_k(u) + b_k): c_k > 0 commutes with the ReLU
+      p = Wp + size_t(C) * C + C;
+    }
+  } else if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
+    float* p = w + size_t(C) * d.idim + C;
+    for (int i = 0; i < n_blocks(d); ++i) {                  // [wd C x ks][bd C][W1 C x C][b1 C][W2 C x C][b2 C]
+      float* wd = p; float* bd = wd + size_t(C) * ks; float* W1 = bd + C; float* b1 = W1 + size_t(C) * C;
+      float* W2 = b1 + C;
+      const std::vector<float> c2 = column_balance(W2, C, C, C);
+      scale_columns(W2, C, C, C, c2);
+      scale_rows_inv(W1, C, C, b1, c2);                      // mid_m = ReLU(W1[m] a + b1[m])
+      const std::vector<float> c1 = column_balance(W1, C, C, C);
+      scale_columns(W1, C, C, C, c1);
+      scale_rows_inv(wd, C, ks, bd, c1);                     // a_k = BN(dw_k(u)) (linear)
+      p = W2 + size_t(C) * C + C;
+    }
+  } else if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+    const int I = d.idim, A1 = d.aux[0], A2 = d.aux[1], D = d.num_stack, K = d.odim, nt = d.kernel_size + d.stack_size;
+    float* in1 = w; float* in1b = in1 + size_t(A1) * I; float* in2 = in1b + A1; float* in2b = in2 + size_t(C) * A1;
+    float* lay = in2b + C;
+    const size_t lstride = size_t(D) * C + size_t(D) * nt + size_t(C) * D + C;   // Wproj, taps, Waff, baff
+    float* out1 = lay + lstride * d.num_layers; float* out1b = out1 + size_t(A2) * C;
+    float* out2 = out1b + A2;
+    auto waff = [&](int l) { return lay + lstride * l + size_t(D) * C + size_t(D) * nt; };
+    {
+      const std::vector<float> c = column_balance(out2, K, A2, A2);            // out_linear2 <- out_linear1 (linear)
+      scale_columns(out2, K, A2, A2, c);
+      scale_rows_inv(out1, A2, C, out1b, c);
+    }
+    {
+      const std::vector<float> c = column_balance(out1, A2, C, C);             // out_linear1 <- ReLU(affine of the last layer)
+      scale_columns(out1, A2, C, C, c);
+      float* wa = waff(d.num_layers - 1);
+      scale_rows_inv(wa, C, D, wa + size_t(C) * D, c);
+    }
+    for (int l = d.num_layers - 1; l >= 0; --l) {                               // Wproj(l) <- ReLU(affine(l-1)) | ReLU(in_linear2)
+      float* wp = lay + lstride * l;
+      const std::vector<float> c = column_balance(wp, D, C, C);
+      scale_columns(wp, D, C, C, c);
+      if (l > 0) {
+        float* wa = waff(l - 1);
+        scale_rows_inv(wa, C, D, wa + size_t(C) * D, c);
+      } else {
+        scale_rows_inv(in2, C, A1, in2b, c);
+      }
+      // (Waff(l)'s columns are fed by the memory block of Wproj(l)'s output, which is the layer's CACHE: not rescaled)
+    }
+    {
+      const std::vector<float> c = column_balance(in2, C, A1, A1);             // in_linear2 <- in_linear1 (linear)
+      scale_columns(in2, C, A1, A1, c);
+      scale_rows_inv(in1, A1, I, in1b, c);
+    }
+  }
+}
+
+static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_elems, int device, wekws_hip_model** out) {
+  std::vector<float> balanced(blob_in, blob_in + n_elems);
+  balance_operand_channels(d, balanced.data());
+  const float* blob = balanced.data();
   // every precision request is served by the block-floating split-fp16 kernel (22-bit products, fp32 accumulate: the
   // accuracy of fp32 arithmetic at any operand scale, tests/test_hip_parity.py::test_scale_sweep); an exact-f32 FSMN
   // kernel is not built
@@ -384,6 +530,10 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   dense(K, A2, q.op, true, &q.out2_a, &q.out2_b, &q.out2);
   if (size_t(p - blob) != n_elems)
     return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
+  if (img.spread_log2 > WEKWS_HIP_F16X3_ENVELOPE_LOG2)
+    return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: a weight matrix spreads its row / column magnitudes over 2^%.1f (> 2^%d): outside the "
+                "envelope in which the split-fp16 kernel keeps fp32-level accuracy, and FSMN has no exact-f32 kernel",
+                double(img.spread_log2), WEKWS_HIP_F16X3_ENVELOPE_LOG2);
 
   wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
   if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
@@ -404,6 +554,7 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob, size_t n_elem
   }
   q.w = m->d_w;
   m->fq = q;
+  m->spread_log2 = img.spread_log2;
   *out = m;
   return WEKWS_HIP_OK;
 }
@@ -419,7 +570,7 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
     return 2 * size_t(B) * d.num_stack * m->cache_len * d.num_layers * sizeof(float);
   }
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    if (d.precision == WEKWS_HIP_PRECISION_F32 || !wekws::gru_f16_supported(m->gq)) return 0;
+    if (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq)) return 0;
     size_t seq_b = 0, gi_b = 0, sc_b = 0;
     wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
     return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + sc_b;
@@ -496,6 +647,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   if (need != n_elems) return fail(WEKWS_HIP_EINVAL, "weight blob has %zu floats, descriptor needs %zu", n_elems, need);
   const int C = d.hdim, ks = d.kernel_size, K = d.odim;
   if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return create_fsmn(d, blob, n_elems, device, out);
+  std::vector<float> balanced(blob, blob + n_elems);        // (exact power-of-two rescaling: see balance_operand_channels)
+  balance_operand_channels(d, balanced.data());
+  blob = balanced.data();
   if (desc_conv(d)) {
     if (C != 32 && C != 64 && C != 128 && C != 256)
       return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for 32/64/128/256", C);
@@ -739,6 +893,12 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     delete m;
     return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
   }
+  // the promise of DEFAULT / F16X3 is fp32-level accuracy: weights outside the envelope in which the split-fp16 kernels
+  // keep it (Image::spread_log2) are served by the exact-f32 kernels instead (wekws_hip_effective_precision says so)
+  m->spread_log2 = img.spread_log2;
+  m->out_of_envelope = (d.precision == WEKWS_HIP_PRECISION_DEFAULT || d.precision == WEKWS_HIP_PRECISION_F16X3) &&
+                       img.spread_log2 > WEKWS_HIP_F16X3_ENVELOPE_LOG2;
+  m->auto_f32 = m->out_of_envelope;
 
   auto cleanup = [&]() {
     if (m->d_w) (void)hipFree(m->d_w);
@@ -791,9 +951,9 @@ int wekws_hip_effective_precision(const wekws_hip_model* m) {
   const wekws_hip_desc& d = m->desc;
   if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return WEKWS_HIP_PRECISION_F16X3;        // one kernel (fsmn_f16.hip.h)
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU)
-    return (d.precision == WEKWS_HIP_PRECISION_F32 || !wekws::gru_f16_supported(m->gq)) ? WEKWS_HIP_PRECISION_F32
-                                                                                           : WEKWS_HIP_PRECISION_F16X3;
-  if (d.precision == WEKWS_HIP_PRECISION_F32) return WEKWS_HIP_PRECISION_F32;          // conv_stack.hip.h serves every shape
+    return (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq))
+               ? WEKWS_HIP_PRECISION_F32 : WEKWS_HIP_PRECISION_F16X3;
+  if (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32) return WEKWS_HIP_PRECISION_F32;   // conv_stack.hip.h serves every shape
   if (d.precision == WEKWS_HIP_PRECISION_F16) {
     // one product per term only where a 16-wave kernel takes the `split` switch (wekws_hip_forward's dispatch)
     const bool ds16 = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && d.hdim == 256 && m->w16_ok && !m->mm_ok;
@@ -802,6 +962,8 @@ int wekws_hip_effective_precision(const wekws_hip_model* m) {
   }
   return WEKWS_HIP_PRECISION_F16X3;
 }
+
+float wekws_hip_weight_spread_log2(const wekws_hip_model* m) { return m ? m->spread_log2 : -1.f; }
 
 size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
   if (!m || B <= 0) return 0;
@@ -825,6 +987,7 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
     case WEKWS_HIP_OPT_MM: m->mm_ok = m->mm_eligible && (value < 0 ? m->desc.odim > 16 : value != 0); break;
     case WEKWS_HIP_OPT_HEAD_SLICES: m->fsmn_slices = value; break;
     case WEKWS_HIP_OPT_G16: m->g16_ok = value != 0; break;
+    case WEKWS_HIP_OPT_ENVELOPE: m->auto_f32 = m->out_of_envelope && value != 0; break;
     default: return fail(WEKWS_HIP_EINVAL, "unknown option %d", option);
   }
   return WEKWS_HIP_OK;
@@ -898,7 +1061,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     const int rc = forward_fsmn(m, x, B, T, in_cache, y, out_cache, stream);
     if (rc) return rc;
   } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && wekws::gru_f16_supported(m->gq);
+    const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32 && wekws::gru_f16_supported(m->gq);
     int rc;
     if (f16) {
       // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
@@ -955,7 +1118,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
         a.head_slices = m->fsmn_slices >= 0 ? m->fsmn_slices : (sl > 8 ? 8 : sl);
       }
       int rc;
-      const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32;  // DEFAULT -> split fp16 for the conv backbones
+      const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32;  // DEFAULT -> split fp16 for the conv backbones
       const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
       // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
       // (the streaming kernels move whole caches with 16-byte accesses: both cache pointers must be 16-byte aligned)

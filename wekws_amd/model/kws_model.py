@@ -215,6 +215,12 @@ class KWSModel(nn.Module):
         _capi.check(min(code, 0), "wekws_hip_effective_precision")
         return {v: k for k, v in pack.PRECISION.items()}[code]
 
+    def weight_spread_log2(self, device: Optional[torch.device] = None) -> float:
+        """Largest spread (binades) between the row / column magnitudes of any matrix that feeds the matrix cores
+        (wekws_hip_weight_spread_log2); above 20 a default-precision model runs the exact-f32 kernels."""
+        dev = device or next(self.parameters()).device
+        return float(_capi.load().wekws_hip_weight_spread_log2(self._get_handle(dev).ptr))
+
     def set_option(self, name: str, value: int) -> "KWSModel":
         """Kernel-selection override (enum wekws_hip_option: 'w16', 'mdtc16', 'stream', 'mm', 'head_slices') -- for A/B
         measurements and the tests that keep every kernel family parity-green; defaults are the product choice."""

@@ -25,6 +25,13 @@ __global__ void k(int iters, long long* cyc, float* sink) {
       else if (OP == 7) { asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(v[i]) : "v"(u[i])); }
       else if (OP == 8) { asm volatile("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(*(unsigned long long*)&p[i]) : "v"(*(unsigned long long*)&p[i]), "v"(*(unsigned long long*)&p[(i + 1) & 7])); }
       else if (OP == 9) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) & 7])); }
+      // round 3: DPP row shifts (independent accumulators / one dependent chain), and the split's mix instructions
+      else if (OP == 10) { asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:3 row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(p[i].x), "v"(p[i].y)); }
+      else if (OP == 11) { asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:3 row_mask:0xf bank_mask:0xf" : "+v"(v[0]) : "v"(p[i].x), "v"(p[i].y)); }
+      else if (OP == 12) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[0]) : "v"(p[i].x), "v"(p[i].y)); }
+      else if (OP == 13) { asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(u[i]) : "v"(v[i]), "v"(p[i].y)); }
+      else if (OP == 14) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:3 row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(p[i].x)); }
+      else if (OP == 15) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(p[i].x), "v"(p[i].y)); }
     }
   }
   long long t1 = __builtin_readcyclecounter();
@@ -51,5 +58,8 @@ int main() {
   run<0>("v_fma_f32", dc, ds); run<1>("v_pk_fma_f32 (2 fma)", dc, ds); run<2>("cvt16+cvt32+add (3 ops)", dc, ds);
   run<3>("v_cvt_f16_f32", dc, ds); run<4>("v_cvt_pkrtz_f16_f32", dc, ds); run<5>("v_cndmask_b32", dc, ds);
   run<6>("v_max_f32", dc, ds); run<7>("v_cvt_f32_f16", dc, ds); run<8>("v_lshl_add_u64", dc, ds); run<9>("v_add_u32", dc, ds);
+  run<15>("v_fmac_f32 (8 chains)", dc, ds); run<10>("v_fmac_f32_dpp (8 chains)", dc, ds);
+  run<12>("v_fmac_f32 (1 chain)", dc, ds); run<11>("v_fmac_f32_dpp (1 chain)", dc, ds);
+  run<13>("v_fma_mixlo_f16", dc, ds); run<14>("v_mov_b32_dpp", dc, ds);
   return 0;
 }

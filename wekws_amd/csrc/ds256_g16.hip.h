@@ -28,6 +28,8 @@
 // The streaming cache is handed over from the registers; the classifier head reads the tile from LDS as before (it is
 // written there once, after the last block).
 #pragma once
+#include <utility>
+
 #include "ds256_w16.hip.h"
 
 namespace wekws {
@@ -56,28 +58,29 @@ __device__ __forceinline__ void g16_fmac_shr(float& o, float x, float w) {
   G16_SHR(9) G16_SHR(10) G16_SHR(11) G16_SHR(12) G16_SHR(13) G16_SHR(14) G16_SHR(15)
 #undef G16_SHR
 }
-// o += w * x[lane + S] for the lanes whose source stays inside their 16-lane row
-template <int S>
-__device__ __forceinline__ void g16_fmac_shl(float& o, float x, float w) {
-  static_assert(S >= 1 && S <= 15, "row shift");
-#define G16_SHL(n) if constexpr (S == n) asm("v_fmac_f32_dpp %0, %1, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf" : "+v"(o) : "v"(x), "v"(w));
-  G16_SHL(1) G16_SHL(2) G16_SHL(3) G16_SHL(4) G16_SHL(5) G16_SHL(6) G16_SHL(7) G16_SHL(8)
-  G16_SHL(9) G16_SHL(10) G16_SHL(11) G16_SHL(12) G16_SHL(13) G16_SHL(14) G16_SHL(15)
-#undef G16_SHL
+// Frame layout of the register-resident tile (round 3, second version): MFMA column n = 16 tt + l (tile tt, lane l of the
+// 16-lane row) holds FRAME  f(n) = NT l + tt  -- every lane owns NT CONSECUTIVE frames, one per register.  The matrix
+// products never look at what a column means (columns are independent), so the permutation costs nothing there; it only
+// shows where frames are named: the feature staging, the depthwise taps, the cache slices and the classifier tile.
+//   * a tap s frames back, s = q NT + m: register tt - m of the lane q places to the left (tt >= m), else register
+//     tt - m + NT of the lane q + 1 places to the left: ONE v_fmac_f32_dpp row_shr per tap and output (the first version, frame
+//     = 16 tt + l, needed a row_shr on one tile plus a row_shl on the tile before: 13 instead of 7 DPP operations per
+//     output -- and a DPP operation costs 3.3 SIMD cycles at four waves per SIMD against 2.3 for a plain v_fmac,
+//     tools/probe/valu_rate.hip), a plain FMA when q = 0, nothing when the lane shift leaves the 16-lane row (left context
+//     = zeros, bound_ctrl off);
+//   * the slice of the streaming cache a block hands over is pad = 7 d frames = whole lanes when NT | T: 28 contiguous
+//     bytes per lane and channel (dwordx4 + dwordx3) instead of 4-byte stores.
+template <int S, int TT_, int NT, int R_>
+__device__ __forceinline__ void g16_tap(float& o, const f32x4 (&hv)[NT], float w) {
+  constexpr int Q = S / NT, M = S % NT;
+  constexpr int REG = TT_ >= M ? TT_ - M : TT_ - M + NT;
+  constexpr int SH = TT_ >= M ? Q : Q + 1;
+  if constexpr (SH == 0) o = fmaf(w, hv[REG][R_], o);
+  else if constexpr (SH <= 15) g16_fmac_shr<SH>(o, hv[REG][R_], w);
 }
-
-// One tap of the causal dilated depthwise conv on the register-resident tile: o += w * h[t - S], t = 16 TT_ + (lane & 15).
-// Tiles below 0 are the (all-zero) left context: nothing to add.
-template <int S, int TT_, int NT>
-__device__ __forceinline__ void g16_tap(float& o, const f32x4 (&hv)[NT], int r, float w) {
-  constexpr int Q = S / 16, R = S % 16;
-  constexpr int TC = TT_ - Q, TP = TC - 1;
-  if constexpr (R == 0) {
-    if constexpr (TC >= 0) o = fmaf(w, hv[TC][r], o);
-  } else {
-    if constexpr (TC >= 0) g16_fmac_shr<R>(o, hv[TC][r], w);
-    if constexpr (TP >= 0) g16_fmac_shl<16 - R>(o, hv[TP][r], w);
-  }
+template <int S, int NT, int R_, int... TTs>
+__device__ __forceinline__ void g16_tap_tiles(float (&o)[NT], const f32x4 (&hv)[NT], float w, std::integer_sequence<int, TTs...>) {
+  (g16_tap<S, TTs, NT, R_>(o[TTs], hv, w), ...);
 }
 
 // scale + split of one depthwise output into the LOW (HI_HALF = false) or HIGH half of the packed hi / lo registers:
@@ -100,33 +103,74 @@ __device__ __forceinline__ void g16_split_into(float v, float s, unsigned& ph, u
   }
 }
 
-// Depthwise conv + folded BN + ReLU + scale / split of channel row R_ (of the lane's four) for the tiles TT_ .. NT - 1.
-// Tap j multiplies the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
-template <int D, int R_, int TT_, int NT, bool SPLIT>
-__device__ __forceinline__ void g16_dw_row(const f32x4 (&hv)[NT], const float (&dww)[9], float sa, unsigned (&ph)[NT][2],
-                                           unsigned (&pl)[NT][2]) {
-  float o = dww[8];
-  g16_tap<7 * D, TT_, NT>(o, hv, R_, dww[0]);
-  g16_tap<6 * D, TT_, NT>(o, hv, R_, dww[1]);
-  g16_tap<5 * D, TT_, NT>(o, hv, R_, dww[2]);
-  g16_tap<4 * D, TT_, NT>(o, hv, R_, dww[3]);
-  g16_tap<3 * D, TT_, NT>(o, hv, R_, dww[4]);
-  g16_tap<2 * D, TT_, NT>(o, hv, R_, dww[5]);
-  g16_tap<1 * D, TT_, NT>(o, hv, R_, dww[6]);
-  g16_tap<0, TT_, NT>(o, hv, R_, dww[7]);
-  o = fmaxf(o, 0.f);
-  g16_split_into<(R_ & 1) != 0, SPLIT>(o, sa, ph[TT_][R_ >> 1], pl[TT_][R_ >> 1]);
-  if constexpr (TT_ + 1 < NT) g16_dw_row<D, R_, TT_ + 1, NT, SPLIT>(hv, dww, sa, ph, pl);
-}
+// Depthwise conv + folded BN + ReLU + scale / split of channel row R_ (of the lane's four), all NT frames of the lane at
+// once: NT independent accumulators per tap, so consecutive instructions never depend on one another.  Tap j multiplies
+// the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
 template <int D, int R_, int NT, bool SPLIT>
-__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
-                                            unsigned (&pl)[NT][2]) {
+__device__ __forceinline__ void g16_dw_row(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
+                                           unsigned (&pl)[NT][2]) {
   // taps + bias of channel o0 + R_ (padded 12-float record): three LDS broadcasts
   const float4* src = reinterpret_cast<const float4*>(taps_o0 + R_ * 12);
   const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-  const float dww[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
-  g16_dw_row<D, R_, 0, NT, SPLIT>(hv, dww, sa, ph, pl);
-  if constexpr (R_ + 1 < 4) g16_dw_rows<D, R_ + 1, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+  constexpr auto tiles = std::make_integer_sequence<int, NT>{};
+  float o[NT];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) o[tt] = q2.x;
+  g16_tap_tiles<7 * D, NT, R_>(o, hv, q0.x, tiles);
+  g16_tap_tiles<6 * D, NT, R_>(o, hv, q0.y, tiles);
+  g16_tap_tiles<5 * D, NT, R_>(o, hv, q0.z, tiles);
+  g16_tap_tiles<4 * D, NT, R_>(o, hv, q0.w, tiles);
+  g16_tap_tiles<3 * D, NT, R_>(o, hv, q1.x, tiles);
+  g16_tap_tiles<2 * D, NT, R_>(o, hv, q1.y, tiles);
+  g16_tap_tiles<1 * D, NT, R_>(o, hv, q1.z, tiles);
+  g16_tap_tiles<0, NT, R_>(o, hv, q1.w, tiles);
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+    g16_split_into<(R_ & 1) != 0, SPLIT>(fmaxf(o[tt], 0.f), sa, ph[tt][R_ >> 1], pl[tt][R_ >> 1]);
+}
+template <int D, int NT, bool SPLIT>
+__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
+                                            unsigned (&pl)[NT][2]) {
+  g16_dw_row<D, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+  g16_dw_row<D, 1, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+  g16_dw_row<D, 2, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+  g16_dw_row<D, 3, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+}
+
+// NT consecutive floats (row r of the lane's registers) to a dword-aligned address, as wide stores
+template <int NT>
+__device__ __forceinline__ void g16_store_run(float* dst, const f32x4 (&hv)[NT], int r) {
+  struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
+  struct __attribute__((packed, aligned(4))) V3 { float v[3]; };
+  struct __attribute__((packed, aligned(4))) V2 { float v[2]; };
+  if constexpr (NT == 7) {
+    *reinterpret_cast<V4*>(dst) = V4{{hv[0][r], hv[1][r], hv[2][r], hv[3][r]}};
+    *reinterpret_cast<V3*>(dst + 4) = V3{{hv[4][r], hv[5][r], hv[6][r]}};
+  } else if constexpr (NT == 4) {
+    *reinterpret_cast<V4*>(dst) = V4{{hv[0][r], hv[1][r], hv[2][r], hv[3][r]}};
+  } else if constexpr (NT == 2) {
+    *reinterpret_cast<V2*>(dst) = V2{{hv[0][r], hv[1][r]}};
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) dst[tt] = hv[tt][r];
+  }
+}
+
+// The features of one utterance, one item (K step, k-octet, column n) per thread like w16_load_x, but column n of the operand
+// planes is frame NT (n % 16) + n / 16
+template <int NT, int PB>
+__device__ __forceinline__ W16XItem g16_load_x(const float* __restrict__ xb, int T, int idim, int nk) {
+  constexpr int TT = 16 * NT;
+  W16XItem it;
+  const int e = threadIdx.x;
+  const int n = e % TT, q = e / TT;
+  const int f = NT * (n & 15) + (n >> 4);
+  const int oct = q & 3, st = q >> 2;
+  const int kf = st * 32 + oct * 8;
+  const bool has = e < nk * 4 * TT;
+  it.dst = has ? st * 2 * PB + (oct * TT + n) * 16 : -1;
+  w16_fetch_x(it, xb + int64_t(f) * idim + kf, xb, has && f < T && kf < idim);
+  return it;
 }
 
 // One 32-deep K step for one o-tile, B fragments of tile tt + 1 requested before the MFMAs of tile tt
@@ -176,7 +220,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   char* const pst = planes + (wave >> 1) * 2 * PB + ((((wave & 1) * 2 + (lq >> 1)) * TT + l15) * 16 + (lq & 1) * 8);
 
   f32x4 acc[NT];
-  f32x4 hv[NT];                                              // the residual tile: channels o0 .. o0 + 3, frames 16 tt + l15
+  f32x4 hv[NT];                                              // the residual tile: channels o0 .. o0 + 3, frames NT l15 + tt
   G16_PH_DECL;
 
   // ---- block floating point (conv_stack_f16.hip.h): maximum of the feature tile
@@ -197,7 +241,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
   W16XItem xi;
   if (one_trip) {
-    xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+    xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
     amax_publish(amax_cells, w16_x_amax(xi));
   } else {
     amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
@@ -231,8 +275,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       const int steps = min(2, nk - k0);
       __syncthreads();
       sx = pow2_scale(amax_read(amax_cells), &cpre);
-      for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, frame)
-        const int t = e % TT;
+      for (int e = tid; e < steps * 4 * TT; e += kW16Threads) {   // item = (step, k-octet, column)
+        const int n = e % TT;
+        const int t = NT * (n & 15) + (n >> 4);              // the column's frame
         const int q = e / TT;
         const int oct = q & 3, st = q >> 2;
         const int kf = (k0 + st) * 32 + oct * 8;
@@ -246,7 +291,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
           split16(v, h, l);
           vh[i] = h; vl[i] = l;
         }
-        char* dst = planes + st * 2 * PB + (oct * TT + t) * 16;
+        char* dst = planes + st * 2 * PB + (oct * TT + n) * 16;
         *reinterpret_cast<f16x8*>(dst) = vh;
         if constexpr (SPLIT) *reinterpret_cast<f16x8*>(dst + PB) = vl;
       }
@@ -274,17 +319,24 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   }
   G16_PH(0);                                                 // [0] preprocessing
   // ======================================= residual blocks =======================================
+  F16Frag a0, a1;                                            // weight fragments of the even / odd K steps, carried over
+  auto frag_base = [&](int i) __attribute__((always_inline)) {
+    return reinterpret_cast<const uint4*>(W + __builtin_amdgcn_readfirstlane(blk[i].a1_16)) + size_t(wave) * OTS;
+  };
+  {
+    const uint4* ap0 = frag_base(0);
+    F16Frag t[1];
+    load_a16<1>(t, ap0 + lane, 0); a0 = t[0];
+    load_a16<1>(t, ap0 + 128 + lane, 0); a1 = t[0];
+  }
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = blk[bi];
     const int pad = bd.pad;
-    const uint4* ap1 = reinterpret_cast<const uint4*>(W + bd.a1_16) + size_t(wave) * OTS + lane;
+    // (wave-uniform bases in scalar registers: the fragment addresses are base + lane, one shared vector offset)
+    const uint4* ap1 = frag_base(bi);
+    // the fragments of the NEXT block's first two K steps are requested by this block's last two (below)
+    const uint4* apn = frag_base(min(bi + 1, P.nblocks - 1));
     const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (requested before anything is stored)
-    F16Frag a0, a1;                                          // weight fragments of the even / odd K steps
-    {
-      F16Frag t[1];
-      load_a16<1>(t, ap1, 0); a0 = t[0];
-      load_a16<1>(t, ap1 + 128, 0); a1 = t[0];
-    }
     // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
     //      by the epilogue that produced it)
     float c1;
@@ -299,10 +351,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       unsigned ph[NT][2], pl[NT][2];                         // packed fp16: [tile][channels (0,1) | (2,3)]
       const float* taps_o0 = taps + o0 * 12;
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
-        case 1: g16_dw_rows<1, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        case 2: g16_dw_rows<2, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        case 4: g16_dw_rows<4, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        default: g16_dw_rows<8, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
+        default: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
       }
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -325,15 +377,16 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
 #pragma unroll 1
     for (int ks = 0; ks < NKS; ks += 2) {
       const char* bsrc = planes + ks * 2 * PB + frag_off;
+      const uint4* nx = ks + 2 < NKS ? ap1 + (ks + 2) * 128 : apn;   // (last pass: K steps 0 / 1 of the next block)
       g16_mfma_step<NT, SPLIT>(acc, a0, bsrc, bsrc + PB);
       {
         F16Frag t[1];
-        load_a16<1>(t, ap1 + min(ks + 2, NKS - 2) * 128, 0); a0 = t[0];
+        load_a16<1>(t, nx + lane, 0); a0 = t[0];
       }
       g16_mfma_step<NT, SPLIT>(acc, a1, bsrc + 2 * PB, bsrc + 3 * PB);
       {
         F16Frag t[1];
-        load_a16<1>(t, ap1 + min(ks + 3, NKS - 1) * 128, 0); a1 = t[0];
+        load_a16<1>(t, nx + 128 + lane, 0); a1 = t[0];
       }
     }
     G16_PH(4);                                               // [4] matrix phase
@@ -348,10 +401,14 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     //      instead of 48, was measured 2 % slower than the direct stores.)
     if (A.out_cache) {
       float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
+      const int p0 = NT * l15 - (T - pad);                   // slice column of this lane's first frame
+      if (p0 >= 0 && p0 + NT <= pad) {                       // the lane's NT frames are NT consecutive columns of the slice
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        if (tt * 16 < T && tt * 16 + 16 > T - pad) {         // (wave-uniform: the tile holds frames of the slice)
-          const int p = tt * 16 + l15 - (T - pad);
+        for (int r = 0; r < 4; ++r) g16_store_run<NT>(oc + r * Pc + p0, hv, r);
+      } else if (p0 + NT > 0 && p0 < pad) {                  // (NT does not divide T: slice boundary inside the lane)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const int p = p0 + tt;
           if (p >= 0 && p < pad) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
@@ -390,7 +447,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hbuf[(o0 + r) * SS + tt * 16 + l15] = hv[tt][r];
+    for (int r = 0; r < 4; ++r) hbuf[(o0 + r) * SS + NT * l15 + tt] = hv[tt][r];
   }
   __syncthreads();
   conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, w16_lds, b);

@@ -215,7 +215,10 @@ def test_empty_cache_equals_zero_cache():
         x = synth.synth_feats(4, 37, cfg["input_dim"], seed=9)
         y0, c0 = run(model, x)
         y1, c1 = run(model, x, np.zeros(pack.cache_shape(pack.parse_config(cfg), 4), np.float32))
-        assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
+        assert np.array_equal(c0, c1), name
+        # (DS-TCN h256 without a cache runs ds256_g16, whose keyword head sums in another order than the kernels that take a
+        # cache: same state bit for bit, posteriors to a few ulp)
+        assert np.array_equal(y0, y1) or (name == "ds_tcn_h256" and max_abs(y0, y1) <= 5e-7), name
 
 
 def test_forward_stream_is_forward_with_cache():
@@ -248,7 +251,8 @@ def test_streaming_kernel_equals_batch_kernel():
             cfg["output_dim"] = K
         sd = synth.synth_state_dict(packer.model_spec(cfg), 77)
         for prec in ("default", "f16"):
-            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0)      # the batch kernel fed the same chunks
+            # the batch kernel (ds256_w16: it shares conv_stack_head with the streaming kernel) fed the same chunks
+            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0).set_option("g16", 0)
             got = build(cfg, sd).set_precision(prec).set_option("stream", 1)
             for B, T in ((5, 10), (3, 16), (2, 1), (300, 7)):
                 x = torch.from_numpy(synth.synth_feats(B, 3 * T, 40, seed=B)).cuda()
@@ -463,10 +467,11 @@ def test_generic_kernels_behind_the_specialised_ones(golden):
 
 def test_register_resident_kernel_equals_lds_tile_kernel():
     """DS-TCN h256 calls without an incoming cache run ds256_g16 (residual tile in registers, depthwise conv through DPP row
-    shifts); option g16 = 0 sends them through ds256_w16 (tile in LDS).  Same arithmetic in the same order: outputs AND the
-    returned cache must agree bit for bit, for every tile shape (T = 1 .. 112, i.e. NT = 1 / 2 / 4 / 7), ragged T, long
-    inputs (tiles after the first carry a cache and take the w16 path either way), both precisions that have the kernel,
-    and with / without the cache being asked for."""
+    shifts); option g16 = 0 sends them through ds256_w16 (tile in LDS).  The backbone is the same arithmetic in the same
+    order: the returned cache (every block's input) must agree bit for bit, for every tile shape (T = 1 .. 112, i.e. NT =
+    1 / 2 / 4 / 7), ragged T, long inputs (tiles after the first carry a cache and take the w16 path either way), both
+    precisions that have the kernel.  The keyword head of g16 adds its 256 products per output in a different order (64
+    register partial sums instead of conv_stack_head's four LDS walks): posteriors agree to a few ulp, not bit for bit."""
     from wekws_amd import pack
     for name in ("ds_tcn_h256",):
         cfg = dict(synth.MODEL_CONFIGS[name])
@@ -478,9 +483,12 @@ def test_register_resident_kernel_equals_lds_tile_kernel():
                 x = synth.synth_feats(B, T, cfg["input_dim"], seed=T)
                 ya, ca = run(a, x)
                 yb, cb = run(b, x)
-                assert np.array_equal(ya, yb) and np.array_equal(ca, cb), (prec, B, T)
+                assert np.array_equal(ca, cb), (prec, B, T)
+                assert max_abs(ya, yb) <= 5e-7, (prec, B, T, max_abs(ya, yb))
                 xt = torch.from_numpy(x).cuda()
-                assert torch.equal(a.posteriors(xt), b.posteriors(xt)), (prec, B, T)
+                # (a first chunk of <= 16 frames that asks for the cache runs ds256_stream, posteriors() runs g16)
+                assert max_abs(a.posteriors(xt).cpu().numpy(), ya) <= (5e-7 if T <= 16 else 0.0), (prec, B, T)
+                assert max_abs(a.posteriors(xt).cpu().numpy(), b.posteriors(xt).cpu().numpy()) <= 5e-7, (prec, B, T)
 
 
 def test_ds256_matrix_core_depthwise_variant(golden):

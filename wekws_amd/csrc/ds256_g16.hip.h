@@ -198,7 +198,7 @@ __device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a
 template <int NT, bool SPLIT>
 __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParams P, const CallArgs A) {
   using G = W16Geom<NT>;
-  constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB, KS = 8;
+  constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB;
   constexpr int NKS = C / 32;                                // K steps per layer
   constexpr int OTS = NKS * 128;                             // uint4 per o-tile
   static_assert(size_t(2 * NKS) * PB <= G::LDS_BYTES, "the operand planes of a whole layer live where the f32 tile was");
@@ -233,15 +233,22 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     if (tid < C * 3) reinterpret_cast<float4*>(taps)[tid] = reinterpret_cast<const float4*>(W + nb.dw_pk)[tid];
   };
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
-  stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
-  __syncthreads();
-  stage_taps(blk[0]);
   const int nk = P.kpre16 / 32;
   // 40-d fbank: the features pass through registers once
   const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
+  // The block table is requested first and the features right behind it: the table's trip to L2, the barrier and the request
+  // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM
+  // (stage_block_table + barrier + feature request used to put two trips to memory end to end at the head of every workgroup).
+  static_assert(kAmaxMaxBlocks * sizeof(BlockDesc) / 4 <= kW16Threads, "one table dword per thread");
+  const int ntbl = P.nblocks * int(sizeof(BlockDesc) / 4);
+  uint32_t tbl = 0;
+  if (tid < ntbl) tbl = reinterpret_cast<const uint32_t*>(P.blocks)[tid];
   W16XItem xi;
+  if (one_trip) xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
+  if (tid < ntbl) reinterpret_cast<uint32_t*>(blk)[tid] = tbl;
+  __syncthreads();
+  stage_taps(blk[0]);
   if (one_trip) {
-    xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
     amax_publish(amax_cells, w16_x_amax(xi));
   } else {
     amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
@@ -443,14 +450,55 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     G16_PH(3);
   }
 
-  // ---- the classifier reads the tile from LDS (conv_stack_head): written once, where the planes were
+  // ---- classifier
+  if (P.head == HEAD_LINEAR && P.odim <= 2) {
+    // keyword heads (one or two outputs per frame; classifier.py:63-67): from the registers.  Every lane multiplies its
+    // 4 channels x NT frames with the classifier rows (8 NT FMAs), the 64 partial sums per output -- 16 waves x 4
+    // channel groups -- meet in LDS where the planes were, four lanes add 16 of them each, a quad reduction and the
+    // sigmoid finish the frame: one barrier, ~60 vector and ~25 LDS instructions per wave instead of writing the tile to
+    // LDS for conv_stack_head (two more barriers, 80 LDS reads per output part; 8 k of the kernel's 110 k cycles).
+    const int K = P.odim;
+    constexpr int PS = 32 * NT + 16;                          // floats per partial row: 16 lanes x (NT frames x 2 outputs), padded
+    float* const part = w16_lds;
+    {
+      const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0);
+      const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0);
+      float* dst = part + (wave * 4 + lq) * PS + 2 * NT * l15;
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
+        float p0 = w0.x * hv[tt][0], p1 = w1.x * hv[tt][0];
+        p0 = fmaf(w0.y, hv[tt][1], p0); p1 = fmaf(w1.y, hv[tt][1], p1);
+        p0 = fmaf(w0.z, hv[tt][2], p0); p1 = fmaf(w1.z, hv[tt][2], p1);
+        p0 = fmaf(w0.w, hv[tt][3], p0); p1 = fmaf(w1.w, hv[tt][3], p1);
+        *reinterpret_cast<float2*>(dst + 2 * tt) = float2{p0, p1};   // frame NT l15 + tt: outputs (0, 1)
+      }
+    }
+    __syncthreads();
+    {
+      const int e = tid >> 2, qd = tid & 3;                  // e = 2 frame + output; four lanes per e
+      const int t = e >> 1, k = e & 1;
+      const float* src = part + qd * 16 * PS + e;
+      float v = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hbuf[(o0 + r) * SS + NT * l15 + tt] = hv[tt][r];
+      for (int i = 0; i < 16; ++i) v += src[i * PS];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+      if (qd == 0 && t < T && k < K) {
+        v += W[P.head_b + k];
+        if (P.sigmoid) v = sigmoidf_(v);
+        A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+      }
+    }
+  } else {
+    // every other head reads the tile from LDS (conv_stack_head): written once, where the planes were
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hbuf[(o0 + r) * SS + NT * l15 + tt] = hv[tt][r];
+    }
+    __syncthreads();
+    conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, w16_lds, b);
   }
-  __syncthreads();
-  conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, w16_lds, b);
   G16_PH(7);                                                 // [7] classifier
   G16_PH_DUMP;
 }

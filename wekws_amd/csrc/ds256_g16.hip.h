@@ -83,58 +83,61 @@ __device__ __forceinline__ void g16_tap_tiles(float (&o)[NT], const f32x4 (&hv)[
   (g16_tap<S, TTs, NT, R_>(o[TTs], hv, w), ...);
 }
 
-// scale + split of one depthwise output into the LOW (HI_HALF = false) or HIGH half of the packed hi / lo registers:
-// hi = fp16(v s) (one rounding of the exact product), d = v s - hi (exact), lo = fp16(d)  -- split16s(), but writing halves
-template <bool HI_HALF, bool SPLIT>
-__device__ __forceinline__ void g16_split_into(float v, float s, unsigned& ph, unsigned& pl) {
-  float d;
-  if constexpr (!HI_HALF) {
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(ph) : "v"(v), "v"(s));                     // (upper half: written next)
-    if constexpr (SPLIT) {
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(s), "v"(ph));
-      asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(pl) : "v"(d));
-    }
-  } else {
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(ph) : "v"(v), "v"(s));
-    if constexpr (SPLIT) {
-      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(v), "v"(s), "v"(ph));
-      asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(pl) : "v"(d));
-    }
+typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 g16_f16x2 __attribute__((ext_vector_type(2)));
+
+// scale + split of TWO depthwise outputs (channel rows 2 p and 2 p + 1 of one frame) into one packed hi and one packed lo
+// register: t = v s (exact, s is a power of two), hi = fp16(t), lo = fp16(t - hi) -- split16s(), two at a time with
+// v_cvt_pk_f16_f32: 8 vector operations per output pair, none of them slow.  (The first version used the
+// mixed-precision FMAs, v_fma_mixlo / mixhi_f16 and v_fma_mix_f32, three per output: tools/probe/valu_rate.hip measures
+// 6.0 SIMD cycles for one of those at four waves per SIMD against 1.9 for a v_fma_f32 and 3.3 for a packed operation --
+// the split was 36 % of the depthwise phase.)  Same roundings, same bits.
+template <bool SPLIT>
+__device__ __forceinline__ void g16_split_pair(float v0, float v1, float s, unsigned& ph, unsigned& pl) {
+  const float t0 = fmaxf(v0, 0.f) * s, t1 = fmaxf(v1, 0.f) * s;
+  const g16_f16x2 h = __builtin_convertvector(g16_f32x2{t0, t1}, g16_f16x2);
+  ph = __builtin_bit_cast(unsigned, h);
+  if constexpr (SPLIT) {
+    const float d0 = t0 - static_cast<float>(h[0]), d1 = t1 - static_cast<float>(h[1]);
+    pl = __builtin_bit_cast(unsigned, __builtin_convertvector(g16_f32x2{d0, d1}, g16_f16x2));
   }
 }
 
-// Depthwise conv + folded BN + ReLU + scale / split of channel row R_ (of the lane's four), all NT frames of the lane at
-// once: NT independent accumulators per tap, so consecutive instructions never depend on one another.  Tap j multiplies
-// the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
-template <int D, int R_, int NT, bool SPLIT>
-__device__ __forceinline__ void g16_dw_row(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
-                                           unsigned (&pl)[NT][2]) {
-  // taps + bias of channel o0 + R_ (padded 12-float record): three LDS broadcasts
-  const float4* src = reinterpret_cast<const float4*>(taps_o0 + R_ * 12);
-  const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+// Depthwise conv + folded BN + ReLU + scale / split of the channel-row pair (2 P_, 2 P_ + 1) of the lane's four, all NT
+// frames of the lane at once: 2 NT independent accumulators per tap, so consecutive instructions never depend on one
+// another.  Tap j multiplies the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
+template <int D, int P_, int NT, bool SPLIT>
+__device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+  // taps + bias of channels o0 + 2 P_, + 1 (padded 12-float records): six LDS broadcasts
+  const float4* src = reinterpret_cast<const float4*>(taps_o0 + 2 * P_ * 12);
+  const float4 a0 = src[0], a1 = src[1], a2 = src[2], b0 = src[3], b1 = src[4], b2 = src[5];
   constexpr auto tiles = std::make_integer_sequence<int, NT>{};
-  float o[NT];
+  constexpr int RA = 2 * P_, RB = 2 * P_ + 1;
+  float oa[NT], ob[NT];
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt) o[tt] = q2.x;
-  g16_tap_tiles<7 * D, NT, R_>(o, hv, q0.x, tiles);
-  g16_tap_tiles<6 * D, NT, R_>(o, hv, q0.y, tiles);
-  g16_tap_tiles<5 * D, NT, R_>(o, hv, q0.z, tiles);
-  g16_tap_tiles<4 * D, NT, R_>(o, hv, q0.w, tiles);
-  g16_tap_tiles<3 * D, NT, R_>(o, hv, q1.x, tiles);
-  g16_tap_tiles<2 * D, NT, R_>(o, hv, q1.y, tiles);
-  g16_tap_tiles<1 * D, NT, R_>(o, hv, q1.z, tiles);
-  g16_tap_tiles<0, NT, R_>(o, hv, q1.w, tiles);
+  for (int tt = 0; tt < NT; ++tt) { oa[tt] = a2.x; ob[tt] = b2.x; }
+  g16_tap_tiles<7 * D, NT, RA>(oa, hv, a0.x, tiles); g16_tap_tiles<7 * D, NT, RB>(ob, hv, b0.x, tiles);
+  g16_tap_tiles<6 * D, NT, RA>(oa, hv, a0.y, tiles); g16_tap_tiles<6 * D, NT, RB>(ob, hv, b0.y, tiles);
+  g16_tap_tiles<5 * D, NT, RA>(oa, hv, a0.z, tiles); g16_tap_tiles<5 * D, NT, RB>(ob, hv, b0.z, tiles);
+  g16_tap_tiles<4 * D, NT, RA>(oa, hv, a0.w, tiles); g16_tap_tiles<4 * D, NT, RB>(ob, hv, b0.w, tiles);
+  g16_tap_tiles<3 * D, NT, RA>(oa, hv, a1.x, tiles); g16_tap_tiles<3 * D, NT, RB>(ob, hv, b1.x, tiles);
+  g16_tap_tiles<2 * D, NT, RA>(oa, hv, a1.y, tiles); g16_tap_tiles<2 * D, NT, RB>(ob, hv, b1.y, tiles);
+  g16_tap_tiles<1 * D, NT, RA>(oa, hv, a1.z, tiles); g16_tap_tiles<1 * D, NT, RB>(ob, hv, b1.z, tiles);
+  g16_tap_tiles<0, NT, RA>(oa, hv, a1.w, tiles);     g16_tap_tiles<0, NT, RB>(ob, hv, b1.w, tiles);
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt)
-    g16_split_into<(R_ & 1) != 0, SPLIT>(fmaxf(o[tt], 0.f), sa, ph[tt][R_ >> 1], pl[tt][R_ >> 1]);
+  for (int tt = 0; tt < NT; ++tt) {
+    // the pair's two halves of column 16 tt + l15: one 4-byte store per plane (waiting for the other pair to make it an
+    // 8-byte store holds 2 NT registers through the second pair's taps: scratch)
+    unsigned ph, pl;
+    g16_split_pair<SPLIT>(oa[tt], ob[tt], sa, ph, pl);
+    *reinterpret_cast<unsigned*>(pst + tt * 256 + P_ * 4) = ph;
+    if constexpr (SPLIT) *reinterpret_cast<unsigned*>(pst + lo_off + tt * 256 + P_ * 4) = pl;
+  }
 }
 template <int D, int NT, bool SPLIT>
-__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, unsigned (&ph)[NT][2],
-                                            unsigned (&pl)[NT][2]) {
-  g16_dw_row<D, 0, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
-  g16_dw_row<D, 1, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
-  g16_dw_row<D, 2, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
-  g16_dw_row<D, 3, NT, SPLIT>(hv, taps_o0, sa, ph, pl);
+__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+  g16_dw_pair<D, 0, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
+  g16_dw_pair<D, 1, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
 }
 
 // NT consecutive floats (row r of the lane's registers) to a dword-aligned address, as wide stores
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   }
   G16_PH(0);                                                 // [0] preprocessing
   // ======================================= residual blocks =======================================
-  F16Frag a0, a1;                                            // weight fragments of the even / odd K steps, carried over
+  F16Frag a0;                                                // weight fragment of the even K steps; K step 0: carried over
   auto frag_base = [&](int i) __attribute__((always_inline)) {
     return reinterpret_cast<const uint4*>(W + __builtin_amdgcn_readfirstlane(blk[i].a1_16)) + size_t(wave) * OTS;
   };
@@ -334,45 +337,82 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     const uint4* ap0 = frag_base(0);
     F16Frag t[1];
     load_a16<1>(t, ap0 + lane, 0); a0 = t[0];
-    load_a16<1>(t, ap0 + 128 + lane, 0); a1 = t[0];
   }
   for (int bi = 0; bi < P.nblocks; ++bi) {
     const BlockDesc bd = blk[bi];
     const int pad = bd.pad;
     // (wave-uniform bases in scalar registers: the fragment addresses are base + lane, one shared vector offset)
     const uint4* ap1 = frag_base(bi);
-    // the fragments of the NEXT block's first two K steps are requested by this block's last two (below)
+    // the fragment of the NEXT block's first K step is requested by this block's last pass (below)
     const uint4* apn = frag_base(min(bi + 1, P.nblocks - 1));
-    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);   // (requested before anything is stored)
     // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
     //      by the epilogue that produced it)
     float c1;
     const float sa = pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
 
+    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
+    //      the registers (still the block's INPUT: the epilogue below is what changes them): frame t = 16 tt + l15 of
+    //      channel o0 + r is column t - (T - pad).  WHERE the stores are issued matters more than how many there are: loads
+    //      and stores share one in-order counter, so any load waited for behind them waits for their trip to HBM.  At the
+    //      head of the block (or of the matrix phase) that load is the next weight fragment and the matrix phase stalls;
+    //      here nothing is requested behind them until the next block's fragments, which are not needed before ITS matrix
+    //      phase -- a whole depthwise phase later.  (A detour through LDS for 16-byte row segments, 22 store instructions
+    //      instead of 48, was measured 2 % slower than the direct stores.)
+    auto hand_over = [&]() __attribute__((always_inline)) {
+      if (A.out_cache) {
+        float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
+        const int p0 = NT * l15 - (T - pad);                   // slice column of this lane's first frame
+        if (p0 >= 0 && p0 + NT <= pad) {                       // the lane's NT frames are NT consecutive columns of the slice
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g16_store_run<NT>(oc + r * Pc + p0, hv, r);
+        } else if (p0 + NT > 0 && p0 < pad) {                  // (NT does not divide T: slice boundary inside the lane)
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            const int p = p0 + tt;
+            if (p >= 0 && p < pad) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
+            }
+          }
+        }
+        if (T < pad) {                                         // shorter than the slice: zero context in front
+          const int nz = pad - T;
+          for (int e = lane; e < 16 * nz; e += 64) {
+            const int cc = e / nz, p = e - cc * nz;
+            A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+          }
+        }
+      }
+    };
     G16_PH(1);                                               // [1] block top
+#ifdef WEKWS_G16_CACHE_AT_TOP
+    hand_over();
+#endif
 
     // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-109) of this lane's 4 channels x NT frames, from the
     //      registers; scale, split, store as operand planes of K step wave >> 1
     {
-      unsigned ph[NT][2], pl[NT][2];                         // packed fp16: [tile][channels (0,1) | (2,3)]
       const float* taps_o0 = taps + o0 * 12;
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
-        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-        default: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, ph, pl); break;
-      }
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        *reinterpret_cast<uint2*>(pst + tt * 256) = uint2{ph[tt][0], ph[tt][1]};
-        if constexpr (SPLIT) *reinterpret_cast<uint2*>(pst + PB + tt * 256) = uint2{pl[tt][0], pl[tt][1]};
+        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        default: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
       }
     }
     G16_PH(2);                                               // [2] depthwise conv -> operand planes
     __syncthreads();                                         // (B) the planes of all 256 channels are written
     G16_PH(3);                                               // [3] barrier waits
 
+    // the fragments of the odd K steps are requested here (K step 1 arrives behind K step 0's MFMAs: the depthwise phase
+    // above needs the registers), the even ones a pass ahead -- K step 0 by the block before; the epilogue's bias too
+    F16Frag a1;
+    {
+      F16Frag t[1];
+      load_a16<1>(t, ap1 + 128 + lane, 0); a1 = t[0];
+    }
+    const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
     // next block's taps: requested now, stored to LDS behind the matrix phase
     float4 tap_nx = float4{0.f, 0.f, 0.f, 0.f};
     const bool tap_ld = bi + 1 < P.nblocks && tid < C * 3;
@@ -384,52 +424,23 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
 #pragma unroll 1
     for (int ks = 0; ks < NKS; ks += 2) {
       const char* bsrc = planes + ks * 2 * PB + frag_off;
-      const uint4* nx = ks + 2 < NKS ? ap1 + (ks + 2) * 128 : apn;   // (last pass: K steps 0 / 1 of the next block)
+      const uint4* nx = ks + 2 < NKS ? ap1 + (ks + 2) * 128 : apn;   // (last pass: K step 0 of the next block)
       g16_mfma_step<NT, SPLIT>(acc, a0, bsrc, bsrc + PB);
       {
         F16Frag t[1];
         load_a16<1>(t, nx + lane, 0); a0 = t[0];
       }
       g16_mfma_step<NT, SPLIT>(acc, a1, bsrc + 2 * PB, bsrc + 3 * PB);
-      {
+      if (ks + 2 < NKS) {
         F16Frag t[1];
         load_a16<1>(t, nx + 128 + lane, 0); a1 = t[0];
       }
     }
     G16_PH(4);                                               // [4] matrix phase
 
-    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
-    //      the registers (still the block's INPUT: the epilogue below is what changes them): frame t = 16 tt + l15 of
-    //      channel o0 + r is column t - (T - pad).  WHERE the stores are issued matters more than how many there are: loads
-    //      and stores share one in-order counter, so any load waited for behind them waits for their trip to HBM.  At the
-    //      head of the block (or of the matrix phase) that load is the next weight fragment and the matrix phase stalls;
-    //      here nothing is requested behind them until the next block's fragments, which are not needed before ITS matrix
-    //      phase -- a whole depthwise phase later.  (A detour through LDS for 16-byte row segments, 22 store instructions
-    //      instead of 48, was measured 2 % slower than the direct stores.)
-    if (A.out_cache) {
-      float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
-      const int p0 = NT * l15 - (T - pad);                   // slice column of this lane's first frame
-      if (p0 >= 0 && p0 + NT <= pad) {                       // the lane's NT frames are NT consecutive columns of the slice
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g16_store_run<NT>(oc + r * Pc + p0, hv, r);
-      } else if (p0 + NT > 0 && p0 < pad) {                  // (NT does not divide T: slice boundary inside the lane)
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-          const int p = p0 + tt;
-          if (p >= 0 && p < pad) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) oc[r * Pc + p] = hv[tt][r];
-          }
-        }
-      }
-      if (T < pad) {                                         // shorter than the slice: zero context in front
-        const int nz = pad - T;
-        for (int e = lane; e < 16 * nz; e += 64) {
-          const int cc = e / nz, p = e - cc * nz;
-          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
-        }
-      }
-    }
+#ifndef WEKWS_G16_CACHE_AT_TOP
+    hand_over();
+#endif
     G16_PH(6);                                               // [6] cache hand-over
 
     // ---- epilogue: folded bias + ReLU + residual (tcn.py:60: add after the ReLU), registers only

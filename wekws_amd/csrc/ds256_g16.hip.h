@@ -162,10 +162,9 @@ __device__ __forceinline__ void g16_store_run(float* dst, const f32x4 (&hv)[NT],
 // The features of one utterance, one item (K step, k-octet, column n) per thread like w16_load_x, but column n of the operand
 // planes is frame NT (n % 16) + n / 16
 template <int NT, int PB>
-__device__ __forceinline__ W16XItem g16_load_x(const float* __restrict__ xb, int T, int idim, int nk) {
+__device__ __forceinline__ W16XItem g16_load_x(const float* __restrict__ xb, int T, int idim, int nk, int e) {
   constexpr int TT = 16 * NT;
   W16XItem it;
-  const int e = threadIdx.x;
   const int n = e % TT, q = e / TT;
   const int f = NT * (n & 15) + (n >> 4);
   const int oct = q & 3, st = q >> 2;
@@ -198,7 +197,12 @@ __device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a
   }
 }
 
-template <int NT, bool SPLIT>
+// FAST: the configuration of the keyword recipes -- features of <= 64 dims in whole aligned 8-float items (one trip through
+// registers) and a per-frame linear head with one or two outputs (from the registers) -- with PERSISTENT workgroups; the
+// general paths (any feature layout, every head through conv_stack_head) stay in the one-utterance-per-workgroup
+// instantiation: inside the utterance loop their index arithmetic is loop-invariant, gets hoisted in front of the loop and
+// the kernel spills (168 bytes of scratch per lane with both in one kernel).
+template <int NT, bool SPLIT, bool FAST>
 __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParams P, const CallArgs A) {
   using G = W16Geom<NT>;
   constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB;
@@ -208,19 +212,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   extern __shared__ __attribute__((aligned(16))) float w16_lds[];
   char* const planes = reinterpret_cast<char*>(w16_lds);     // [K step][hi | lo][k-octet][frame][8 halves]
   float* const hbuf = w16_lds + G::SLAB / 4;                 // [256][SS] f32 tile -- only for the classifier, at the end
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int T = A.T;
-  const int b = blockIdx.x;                                  // one utterance per workgroup
-  const float* __restrict__ W = P.w;
-  const int Pc = P.cache_len;
-  const int o0 = wave * 16 + lq * 4;                         // this lane's 4 channels: rows of the o-tile AND of the tile h
-  const int frag_off = (lq * TT + l15) * 16;
-  // where this lane's 4 channels of frame 16 tt + l15 sit in a hi plane: K step wave >> 1, k-octet (wave & 1) * 2 + lq / 2,
-  // halves (lq & 1) * 4 .. + 3 of the 16-byte item
-  char* const pst = planes + (wave >> 1) * 2 * PB + ((((wave & 1) * 2 + (lq >> 1)) * TT + l15) * 16 + (lq & 1) * 8);
 
   f32x4 acc[NT];
   f32x4 hv[NT];                                              // the residual tile: channels o0 .. o0 + 3, frames NT l15 + tt
@@ -232,24 +223,50 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   // depthwise taps + bias of the CURRENT block, [256][12] floats (the 12-float records of BlockDesc::dw_pk): staged for
   // block bi + 1 behind block bi's matrix phase (block 0: during the preprocessing), read back as 16-byte broadcasts
   __shared__ __attribute__((aligned(16))) float taps[C * 12];
+  const int nk = P.kpre16 / 32;
+  // 40-d fbank: the features pass through registers once
+  const bool one_trip = FAST || (nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim));
+  static_assert(kAmaxMaxBlocks * sizeof(BlockDesc) / 4 <= kW16Threads, "one table dword per thread");
+  {
+    const int ntbl = P.nblocks * int(sizeof(BlockDesc) / 4);
+    const int t0 = threadIdx.x;
+    if (t0 < ntbl) reinterpret_cast<uint32_t*>(blk)[t0] = reinterpret_cast<const uint32_t*>(P.blocks)[t0];
+  }
+  // PERSISTENT workgroups: the grid is one workgroup per compute unit (the 160 KB tile admits no second one) and every
+  // workgroup walks over utterances b, b + grid, ...  Per-phase stamps of the one-utterance-per-workgroup version add up to
+  // 104 k cycles where the kernel takes 114 k per utterance and CU: a tenth of the time went into workgroup turnover
+  // (16 waves and 160 KB of LDS to release, allocate and start four times per CU).
+  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {          // (not FAST: the grid is B, one pass)
+  // (the weight pointer is re-made opaque for every utterance: with a loop-invariant __restrict__ pointer the compiler
+  // hoists the preprocessing fragments, biases and classifier rows out of the loop and keeps them in registers for the
+  // whole kernel -- 288 bytes of scratch per lane)
+  const float* Wp = P.w;
+  if constexpr (FAST) asm volatile("" : "+s"(Wp));
+  const float* __restrict__ W = Wp;
+  // (likewise the lane coordinates and T: everything derived from them -- plane addresses, the division constants of the
+  // rarely taken paths -- would be computed once in front of the loop and held in registers)
+  int tid = threadIdx.x;
+  if constexpr (FAST) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
+  const int l15 = lane & 15, lq = lane >> 4;
+  int T = A.T;
+  if constexpr (FAST) asm volatile("" : "+s"(T));
+  const int Pc = P.cache_len;
+  const int o0 = wave * 16 + lq * 4;                         // this lane's 4 channels: rows of the o-tile AND of the tile h
+  const int frag_off = (lq * TT + l15) * 16;
+  // where this lane's 4 channels of frame 16 tt + l15 sit in a hi plane: K step wave >> 1, k-octet (wave & 1) * 2 + lq / 2,
+  // halves (lq & 1) * 4 .. + 3 of the 16-byte item
+  char* const pst = planes + (wave >> 1) * 2 * PB + ((((wave & 1) * 2 + (lq >> 1)) * TT + l15) * 16 + (lq & 1) * 8);
+
   auto stage_taps = [&](const BlockDesc& nb) __attribute__((always_inline)) {
     if (tid < C * 3) reinterpret_cast<float4*>(taps)[tid] = reinterpret_cast<const float4*>(W + nb.dw_pk)[tid];
   };
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
-  const int nk = P.kpre16 / 32;
-  // 40-d fbank: the features pass through registers once
-  const bool one_trip = nk <= 2 && 8 * TT <= kW16Threads && w16_x_vec_ok(A.x, A.xs_b, P.idim);
-  // The block table is requested first and the features right behind it: the table's trip to L2, the barrier and the request
-  // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM
-  // (stage_block_table + barrier + feature request used to put two trips to memory end to end at the head of every workgroup).
-  static_assert(kAmaxMaxBlocks * sizeof(BlockDesc) / 4 <= kW16Threads, "one table dword per thread");
-  const int ntbl = P.nblocks * int(sizeof(BlockDesc) / 4);
-  uint32_t tbl = 0;
-  if (tid < ntbl) tbl = reinterpret_cast<const uint32_t*>(P.blocks)[tid];
+  // The features are requested before the barrier: the table's trip to L2 (first utterance), the barrier and the request
+  // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM.
   W16XItem xi;
-  if (one_trip) xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
-  if (tid < ntbl) reinterpret_cast<uint32_t*>(blk)[tid] = tbl;
-  __syncthreads();
+  if (one_trip) xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk, tid);
+  __syncthreads();                                           // table staged, cells zeroed; the utterance before is done with LDS
   stage_taps(blk[0]);
   if (one_trip) {
     amax_publish(amax_cells, w16_x_amax(xi));
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   }
 
   // ---- classifier
-  if (P.head == HEAD_LINEAR && P.odim <= 2) {
+  if (FAST || (P.head == HEAD_LINEAR && P.odim <= 2)) {
     // keyword heads (one or two outputs per frame; classifier.py:63-67): from the registers.  Every lane multiplies its
     // 4 channels x NT frames with the classifier rows (8 NT FMAs), the 64 partial sums per output -- 16 waves x 4
     // channel groups -- meet in LDS where the planes were, four lanes add 16 of them each, a quad reduction and the
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
       }
     }
-  } else {
+  } else if constexpr (!FAST) {
     // every other head reads the tile from LDS (conv_stack_head): written once, where the planes were
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
@@ -512,20 +529,30 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   }
   G16_PH(7);                                                 // [7] classifier
   G16_PH_DUMP;
+  if constexpr (!FAST) break;                                // (one utterance per workgroup: no loop for the compiler to hoist out of)
+  }                                                          // next utterance of this workgroup
 }
 
-template <int NT, bool SPLIT>
-inline int launch_ds256_g16_nts(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+template <int NT, bool SPLIT, bool FAST>
+inline int launch_ds256_g16_ntsf(const StackParams& P, const CallArgs& A, hipStream_t stream, int grid) {
   using G = W16Geom<NT>;
   static DynLdsGrant grant;
-  auto kern = ds256_g16_kernel<NT, SPLIT>;
+  auto kern = ds256_g16_kernel<NT, SPLIT, FAST>;
   if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
-  hipLaunchKernelGGL(kern, dim3(A.B), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+template <int NT, bool SPLIT>
+inline int launch_ds256_g16_nts(const StackParams& P, const CallArgs& A, hipStream_t stream, int cus) {
+  const bool fast = P.head == HEAD_LINEAR && P.odim <= 2 && P.kpre16 <= 64 && 8 * 16 * NT <= kW16Threads &&
+                    P.idim % 8 == 0 && (reinterpret_cast<uintptr_t>(A.x) & 15) == 0 && A.xs_b % 4 == 0;   // = w16_x_vec_ok
+  return fast ? launch_ds256_g16_ntsf<NT, SPLIT, true>(P, A, stream, A.B < cus ? A.B : cus)
+              : launch_ds256_g16_ntsf<NT, SPLIT, false>(P, A, stream, A.B);
 }
 
 // Calls WITHOUT an incoming cache whose blocks all have dilation 1, 2, 4 or 8 (the host checks; everything else:
 // launch_ds256_w16).  split: three fp16 products per MAC on hi/lo operands (F16X3) or one on the hi halves (F16).
-int launch_ds256_g16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
+// cus: compute units of the device = the largest grid (persistent workgroups).
+int launch_ds256_g16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream, int cus);
 
 }  // namespace wekws

@@ -1132,7 +1132,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                : !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
                : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache)
-                     ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream)                      // 16 waves, tile in registers
+                     ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream, m->fsmn_cus)                      // 16 waves, tile in registers
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;

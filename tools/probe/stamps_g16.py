@@ -19,4 +19,4 @@ for _ in range(50):
 torch.cuda.synchronize()
 d = c[0].flatten()[:16].cpu().numpy()
 for role, off in (("wave 0", 0), ("wave 9", 8)):
-    print(role, " ".join(f"[{n}]={int(v)}" for n, v in zip(names, d[off:off + 8])), "total", int(d[off:off + 8].sum()))
+    print(role, "(sum over the utterances of workgroup 0; / 4 at B = 1024)", " ".join(f"[{n}]={int(v)}" for n, v in zip(names, d[off:off + 8])), "total", int(d[off:off + 8].sum()))

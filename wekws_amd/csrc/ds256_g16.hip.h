@@ -40,8 +40,8 @@ namespace wekws {
 #define G16_PH_DUMP                                                                                    \
   do {                                                                                                 \
     __syncthreads();                                                                                   \
-    if (b == 0 && A.out_cache && lane == 0 && (wave == 0 || wave == 9))                                \
-      for (int i = 0; i < 8; ++i) A.out_cache[(wave ? 8 : 0) + i] = float(tph[i]);                     \
+    if (blockIdx.x == 0 && A.out_cache && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 9)) \
+      for (int i = 0; i < 8; ++i) A.out_cache[((threadIdx.x >> 6) ? 8 : 0) + i] = float(tph[i]);          \
   } while (0)
 #else
 #define G16_PH_DECL
@@ -140,6 +140,24 @@ __device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* 
   g16_dw_pair<D, 1, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
 }
 
+// The same item from the utterance's features in LDS (FAST: copied there ahead of time, frame-major like in memory)
+template <int NT, int PB>
+__device__ __forceinline__ W16XItem g16_take_x(const float* xbuf, int T, int idim, int nk, int e) {
+  constexpr int TT = 16 * NT;
+  W16XItem it;
+  const int n = e % TT, q = e / TT;
+  const int f = NT * (n & 15) + (n >> 4);
+  const int oct = q & 3, st = q >> 2;
+  const int kf = st * 32 + oct * 8;
+  const bool has = e < nk * 4 * TT;
+  it.dst = has ? st * 2 * PB + (oct * TT + n) * 16 : -1;
+  it.ok = has && f < T && kf < idim;
+  const float* p = xbuf + (it.ok ? f * idim + kf : 0);
+  const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+  it.v = w16_f32x8{a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  return it;
+}
+
 // NT consecutive floats (row r of the lane's registers) to a dword-aligned address, as wide stores
 template <int NT>
 __device__ __forceinline__ void g16_store_run(float* dst, const f32x4 (&hv)[NT], int r) {
@@ -236,6 +254,25 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   // workgroup walks over utterances b, b + grid, ...  Per-phase stamps of the one-utterance-per-workgroup version add up to
   // 104 k cycles where the kernel takes 114 k per utterance and CU: a tenth of the time went into workgroup turnover
   // (16 waves and 160 KB of LDS to release, allocate and start four times per CU).
+  // FAST: the NEXT utterance's features are copied from HBM straight into LDS (global_load_lds: no registers) behind the
+  // classifier of the current one, into the 32 KB of the dynamic allocation above the planes (where the general
+  // instantiation keeps the classifier's f32 tile) -- a linear copy of T * idim floats in 16-byte pieces, 1 KiB per wave
+  // and instruction.  The trip to HBM that used to open every utterance (features -> registers -> maximum) now ends
+  // before the utterance starts.
+  float* const xbuf = w16_lds + (2 * NKS * PB) / 4;
+  static_assert(!FAST || size_t(2 * NKS) * PB + size_t(TT) * 64 * 4 <= G::LDS_BYTES, "feature buffer above the planes");
+  auto prefetch_x = [&](int bn) __attribute__((always_inline)) {
+    const int nitems = (A.T * P.idim) >> 2;                  // 16-byte pieces (idim % 8 == 0)
+    const float* src = A.x + int64_t(bn) * A.xs_b;
+    const int t0 = threadIdx.x;
+    for (int e0 = 0; e0 < nitems; e0 += kW16Threads) {       // (wave-uniform trip count; a wave's pieces are consecutive)
+      const int wbase = __builtin_amdgcn_readfirstlane(e0 + (t0 & ~63));
+      if (e0 + t0 < nitems)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (e0 + t0) * 4),
+                                         (__attribute__((address_space(3))) void*)(xbuf + wbase * 4), 16, 0, 0);
+    }
+  };
+  if constexpr (FAST) prefetch_x(blockIdx.x);
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {          // (not FAST: the grid is B, one pass)
   // (the weight pointer is re-made opaque for every utterance: with a loop-invariant __restrict__ pointer the compiler
   // hoists the preprocessing fragments, biases and classifier rows out of the loop and keeps them in registers for the
@@ -258,16 +295,26 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   // halves (lq & 1) * 4 .. + 3 of the 16-byte item
   char* const pst = planes + (wave >> 1) * 2 * PB + ((((wave & 1) * 2 + (lq >> 1)) * TT + l15) * 16 + (lq & 1) * 8);
 
+  // taps + biases of a block: copied from the weight image straight into LDS (global_load_lds, 12 waves x 1 KiB), no
+  // registers in between.  Nobody waits for the copy explicitly: every wave consumes weight fragments it requested
+  // AFTER it (loads return in order) before it reaches the barrier in front of the depthwise phase that reads the taps.
   auto stage_taps = [&](const BlockDesc& nb) __attribute__((always_inline)) {
-    if (tid < C * 3) reinterpret_cast<float4*>(taps)[tid] = reinterpret_cast<const float4*>(W + nb.dw_pk)[tid];
+    if (wave < C * 3 / 64)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + nb.dw_pk + tid * 4),
+                                       (__attribute__((address_space(3))) void*)(taps + wave * 256), 16, 0, 0);
   };
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   // The features are requested before the barrier: the table's trip to L2 (first utterance), the barrier and the request
   // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM.
   W16XItem xi;
-  if (one_trip) xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk, tid);
+  if constexpr (!FAST) {
+    if (one_trip) xi = g16_load_x<NT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk, tid);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's pieces of the feature copy have landed
+  }
   __syncthreads();                                           // table staged, cells zeroed; the utterance before is done with LDS
   stage_taps(blk[0]);
+  if constexpr (FAST) xi = g16_take_x<NT, PB>(xbuf, T, P.idim, nk, tid);
   if (one_trip) {
     amax_publish(amax_cells, w16_x_amax(xi));
   } else {
@@ -430,10 +477,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       load_a16<1>(t, ap1 + 128 + lane, 0); a1 = t[0];
     }
     const float4 ebias = *reinterpret_cast<const float4*>(W + bd.b1 + o0);
-    // next block's taps: requested now, stored to LDS behind the matrix phase
-    float4 tap_nx = float4{0.f, 0.f, 0.f, 0.f};
-    const bool tap_ld = bi + 1 < P.nblocks && tid < C * 3;
-    if (tap_ld) tap_nx = reinterpret_cast<const float4*>(W + blk[bi + 1].dw_pk)[tid];
+    // next block's taps: on their way into LDS during the matrix phase
+    if (bi + 1 < P.nblocks) stage_taps(blk[bi + 1]);         // (this block's taps were last read before barrier (B))
 
     // ---- pointwise conv: all eight K steps back to back
 #pragma unroll
@@ -472,7 +517,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
     amax_publish(amax_cells + 3 + bi, hmax);             // = the input tile of block bi + 1
-    if (tap_ld) reinterpret_cast<float4*>(taps)[tid] = tap_nx;   // (this block's taps were last read before barrier (B))
     G16_PH(5);                                               // [5] epilogue
     __syncthreads();                                         // (A) maximum published, planes free, taps staged
     G16_PH(3);
@@ -491,6 +535,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     {
       const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0);
       const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0);
+      if constexpr (FAST) {                                  // (behind the classifier rows: loads return in order)
+        if (b + int(gridDim.x) < A.B) prefetch_x(b + gridDim.x);
+      }
       float* dst = part + (wave * 4 + lq) * PS + 2 * NT * l15;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -528,9 +575,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     conv_stack_head<KIND_DS, 256, NT, kW16Threads, SS>(P, A, hbuf, w16_lds, b);
   }
   G16_PH(7);                                                 // [7] classifier
-  G16_PH_DUMP;
   if constexpr (!FAST) break;                                // (one utterance per workgroup: no loop for the compiler to hoist out of)
   }                                                          // next utterance of this workgroup
+  G16_PH_DUMP;                                               // (stamp builds: sums over this workgroup's utterances)
 }
 
 template <int NT, bool SPLIT, bool FAST>

@@ -491,6 +491,26 @@ def test_register_resident_kernel_equals_lds_tile_kernel():
                 assert max_abs(a.posteriors(xt).cpu().numpy(), b.posteriors(xt).cpu().numpy()) <= 5e-7, (prec, B, T)
 
 
+def test_register_resident_f32_kernel_equals_generic_f32_kernel():
+    """Precision F32, DS-TCN h256 keyword configuration without an incoming cache: ds256_g32 (tile in registers, exact-f32
+    MFMA) against the generic conv_stack_kernel (option g16 = 0) -- the same products, each rounded once; the sums are
+    taken in the same order inside a K group but the generic kernel's epilogue / head differ in association, so the
+    comparison is to fp32 rounding noise, for every tile shape, ragged T and long inputs."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 77)
+    a = build(cfg, sd).set_precision("f32").set_option("g16", 1)
+    b = build(cfg, sd).set_precision("f32").set_option("g16", 0)
+    for B, T in ((3, 1), (2, 7), (1, 16), (5, 17), (2, 33), (3, 64), (2, 65), (4, 98), (300, 98), (1, 112), (2, 150)):
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=T)
+        ya, ca = run(a, x)
+        yb, cb = run(b, x)
+        assert max_abs(ya, yb) <= 1e-6, (B, T, max_abs(ya, yb))
+        assert max_abs(ca, cb) <= 2e-6 * max(1.0, float(np.abs(cb).max())), (B, T, max_abs(ca, cb))
+        xt = torch.from_numpy(x).cuda()
+        assert max_abs(a.posteriors(xt).cpu().numpy(), ya) <= 1e-6, (B, T)
+
+
 def test_ds256_matrix_core_depthwise_variant(golden):
     """Option mm = 1 selects the DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores (ds256_mm.hip.h)
     for keyword heads too: same goldens, same tolerance, including streaming and carried caches."""

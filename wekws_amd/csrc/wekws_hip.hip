@@ -20,6 +20,7 @@
 #include "dense_stack_f16.hip.h"
 #include "ds256_w16.hip.h"
 #include "ds256_g16.hip.h"
+#include "ds256_g32.hip.h"
 #include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
 #include "mdtc64_w16.hip.h"
@@ -1130,7 +1131,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       switch (d.backbone) {
         case WEKWS_HIP_BACKBONE_DS_TCN:
           rc = strm ? wekws::launch_ds256_stream(split, m->sp, a, stream)
-               : !f16 ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+               : !f16 ? ((C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache &&
+                          (rc = wekws::launch_ds256_g32(nt, m->sp, a, stream, m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
+                             ? rc                                                            // exact f32, tile in registers
+                             : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream))
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
                : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache)
                      ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream, m->g16_one_pass ? (1 << 30) : m->fsmn_cus)                      // 16 waves, tile in registers

@@ -215,10 +215,16 @@ def test_empty_cache_equals_zero_cache():
         x = synth.synth_feats(4, 37, cfg["input_dim"], seed=9)
         y0, c0 = run(model, x)
         y1, c1 = run(model, x, np.zeros(pack.cache_shape(pack.parse_config(cfg), 4), np.float32))
+        if name == "mdtc_h64":
+            # MDTC h64 without a cache runs mdtc64_g4, whose tile holds frames -off .. 16 NT - 1 - off (the utterance's end
+            # aligned with a lane boundary): at T = 37 its padding frames are not the 16-wave kernel's, a block-floating
+            # scale may come out a binade apart and the results agree to rounding noise instead of bit for bit
+            assert max_abs(c0, c1) <= 3e-6 * max(1.0, float(np.abs(c1).max())) and max_abs(y0, y1) <= 3e-6, name
+            continue
         assert np.array_equal(c0, c1), name
         # (DS-TCN h256 without a cache runs ds256_g16, whose keyword head sums in another order than the kernels that take a
         # cache: same state bit for bit, posteriors to a few ulp)
-        assert np.array_equal(y0, y1) or (name == "ds_tcn_h256" and max_abs(y0, y1) <= 5e-7), name
+        assert np.array_equal(y0, y1) or (name == "ds_tcn_h256" and max_abs(y0, y1) <= 5e-7) or name == "mdtc_h64", name
 
 
 def test_forward_stream_is_forward_with_cache():
@@ -267,7 +273,8 @@ def test_streaming_kernel_equals_batch_kernel():
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(packer.model_spec(cfg), 78)
         for prec in ("default", "f16"):
-            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0)      # the batch kernel fed the same chunks
+            # the batch kernel (mdtc64_w16: same head and tile as the streaming kernel) fed the same chunks
+            ref = build(cfg, sd).set_precision(prec).set_option("stream", 0).set_option("g16", 0)
             got = build(cfg, sd).set_precision(prec).set_option("stream", 1)
             for B, T in ((5, 10), (2, 16), (1, 1), (301, 7)):
                 x = torch.from_numpy(synth.synth_feats(B, 3 * T, cfg["input_dim"], seed=B)).cuda()
@@ -509,6 +516,33 @@ def test_register_resident_f32_kernel_equals_generic_f32_kernel():
         assert max_abs(ca, cb) <= 2e-6 * max(1.0, float(np.abs(cb).max())), (B, T, max_abs(ca, cb))
         xt = torch.from_numpy(x).cuda()
         assert max_abs(a.posteriors(xt).cpu().numpy(), ya) <= 1e-6, (B, T)
+
+
+def test_mdtc_one_utterance_per_workgroup_kernel_equals_16_wave_kernel():
+    """MDTC h64 keyword models without an incoming cache run mdtc64_g4 (one utterance per 4-wave workgroup, residual tile
+    in registers); option g16 = 0 sends them through mdtc64_w16.  Same arithmetic: where both kernels see the same set of
+    padding frames (NT divides T, e.g. the 98-frame utterance) the returned cache agrees bit for bit; elsewhere the
+    block-floating scales may be taken from different don't-care frames and the results agree to rounding noise.  40-d and
+    80-d inputs (2 / 3 K steps), every tile shape, ragged T, long inputs, both precisions."""
+    from wekws_amd import pack
+    for name in ("mdtc_h64", "mdtc_h64_80d"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 79)
+        for prec in ("default", "f16"):
+            a = build(cfg, sd).set_precision(prec).set_option("g16", 1)
+            b = build(cfg, sd).set_precision(prec).set_option("g16", 0)
+            for B, T in ((3, 1), (2, 7), (1, 16), (5, 17), (2, 33), (3, 64), (2, 65), (4, 98), (301, 98), (1, 112), (3, 111),
+                         (2, 150)):
+                x = synth.synth_feats(B, T, cfg["input_dim"], seed=T)
+                ya, ca = run(a, x)
+                yb, cb = run(b, x)
+                tol = 3e-6 if prec == "default" else 2e-3
+                assert max_abs(ya, yb) <= tol, (name, prec, B, T, max_abs(ya, yb))
+                assert max_abs(ca, cb) <= tol * max(1.0, float(np.abs(cb).max())), (name, prec, B, T, max_abs(ca, cb))
+                if T == 98:
+                    assert np.array_equal(ca, cb), (name, prec, B, T)
+                xt = torch.from_numpy(x).cuda()
+                assert max_abs(a.posteriors(xt).cpu().numpy(), ya) <= (tol if T <= 16 else 0.0), (name, prec, B, T)
 
 
 def test_ds256_matrix_core_depthwise_variant(golden):

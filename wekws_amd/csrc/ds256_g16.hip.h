@@ -193,8 +193,10 @@ __device__ __forceinline__ W16XItem g16_load_x(const float* __restrict__ xb, int
   return it;
 }
 
-// One 32-deep K step for one o-tile, B fragments of tile tt + 1 requested before the MFMAs of tile tt
-template <int NT, bool SPLIT>
+// One 32-deep K step for one o-tile, B fragments of tile tt + 1 requested before the MFMAs of tile tt.
+// FIRST: the accumulators start at zero -- the first MFMA of every tile takes the constant 0 as its C operand instead of
+// NT x 4 registers that somebody had to clear.
+template <int NT, bool SPLIT, bool FIRST = false>
 __device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a, const char* bh, const char* bl) {
   f16x8 vh[2], vl[2];
   vh[0] = *reinterpret_cast<const f16x8*>(bh);
@@ -206,7 +208,7 @@ __device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a
       if constexpr (SPLIT) vl[(tt + 1) & 1] = *reinterpret_cast<const f16x8*>(bl + (tt + 1) * 256);
     }
     __builtin_amdgcn_sched_barrier(0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh[tt & 1], acc[tt], 0, 0, 0);
+    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vh[tt & 1], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[tt], 0, 0, 0);
     if constexpr (SPLIT) {
       acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, vl[tt & 1], acc[tt], 0, 0, 0);
       acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, vh[tt & 1], acc[tt], 0, 0, 0);
@@ -462,7 +464,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
         case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
         case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
-        default: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 8: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        default: break;
       }
     }
     G16_PH(2);                                               // [2] depthwise conv -> operand planes

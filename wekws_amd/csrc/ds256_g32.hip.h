@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
         case 1: g32_dw_rows<1, NT>(hv, taps_o0, pst); break;
         case 2: g32_dw_rows<2, NT>(hv, taps_o0, pst); break;
         case 4: g32_dw_rows<4, NT>(hv, taps_o0, pst); break;
-        default: g32_dw_rows<8, NT>(hv, taps_o0, pst); break;
+        case 8: g32_dw_rows<8, NT>(hv, taps_o0, pst); break;
+        default: break;
       }
     }
     G16_PH(2);                                               // [2] depthwise conv -> operand planes

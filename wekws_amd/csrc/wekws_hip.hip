@@ -21,6 +21,7 @@
 #include "ds256_w16.hip.h"
 #include "ds256_g16.hip.h"
 #include "ds256_g32.hip.h"
+#include "mdtc64_g4.hip.h"
 #include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
 #include "mdtc64_w16.hip.h"
@@ -1153,6 +1154,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
                 cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0)
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
+               : (f16 && m->mdtc16_ok && m->g16_ok && m->mdtc_stream_eligible && !a.in_cache &&
+                  (rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream)) != -4)
+                   ? rc                                                                          // one utterance per 4-wave workgroup
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
                    : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);

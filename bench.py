@@ -62,6 +62,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832, "gru_2x128": 39_588_864}  # SURVEY.md 8d (T = 98)
 BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4          # features in + posteriors out = 16,464 B
 CACHE_BYTES_PER_UTT = 256 * 105 * 4                # the (256, 105) streaming cache forward() also returns
+CACHE_BYTES = {"ds_tcn_h256": 256 * 105 * 4, "mdtc_h64": 64 * 244 * 4, "gru_2x128": 2 * 128 * 4}   # per utterance / stream
 PEAK_F32_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_F16_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -129,7 +130,7 @@ def mfma_roofline(model_name, B, kern_ms, precision):
             "frac": round(ach / peak, 4), "peak_note": note, "kernel_ms": round(kern_ms, 4), "flop_per_launch": flop,
             "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
             "algorithmic_bytes_per_launch": BYTES_PER_UTT * B,
-            "algorithmic_bytes_per_launch_with_cache_out": (BYTES_PER_UTT + CACHE_BYTES_PER_UTT) * B,
+            "algorithmic_bytes_per_launch_with_cache_out": (BYTES_PER_UTT + CACHE_BYTES.get(model_name, 0)) * B,
             "hbm_achieved_GBs": round(hbm, 2), "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": round(hbm / PEAK_HBM_GBS, 6)}
 
 
@@ -160,8 +161,15 @@ def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_o
     ts = time_steps(torch, fn, steps, 5)
     what = "posteriors only (out_cache = NULL)" if score_only else "forward"
     med = float(np.median(ts))
-    return {"workload": f"{name} {what}, {B} x 1-s utterances, T={T}", "value": round(B / med * 1e3, 1),
-            "unit": "utts/s", "step_ms": pct(ts), "steps": steps, "precision": precision}
+    out = {"workload": f"{name} {what}, {B} x 1-s utterances, T={T}", "value": round(B / med * 1e3, 1),
+           "unit": "utts/s", "step_ms": pct(ts), "steps": steps, "precision": precision}
+    if name in FLOP_PER_UTT and not score_only:                      # its own roofline (BASELINE config 2 is this model)
+        prec = {"default": "f16x3"}.get(precision, precision)
+        roof = mfma_roofline(name, B, med, prec)
+        roof["kernel_ms_note"] = "median step of this loop (HIP events per group of launches)"
+        attach_profile(roof, name, B, prec)
+        out["roofline"] = roof
+    return out
 
 
 def stream_latency(torch, init_model, pack, synth, dev, name, B, chunk=10, n=1000):

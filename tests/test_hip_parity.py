@@ -525,7 +525,7 @@ def test_mdtc_one_utterance_per_workgroup_kernel_equals_16_wave_kernel():
     block-floating scales may be taken from different don't-care frames and the results agree to rounding noise.  40-d and
     80-d inputs (2 / 3 K steps), every tile shape, ragged T, long inputs, both precisions."""
     from wekws_amd import pack
-    for name in ("mdtc_h64", "mdtc_h64_80d"):
+    for name in ("mdtc_h64", "mdtc_h64_80d", "mdtc_h64_global12"):   # (the last: pooled head, classifier.py:26-28)
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 79)
         for prec in ("default", "f16"):

@@ -14,9 +14,11 @@ cp $out/parity_errors.json $out/${tag}_parity_errors.json 2>/dev/null
 # headline kernel, both precisions: kernel trace + PMC groups + FETCH_SIZE / WRITE_SIZE passes
 tools/pmc.sh hl python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
 tools/pmc.sh hl32 python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 --precision f32 > /dev/null
+tools/pmc.sh md python bench.py --model mdtc_h64 --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
 python tools/prof_summary.py $(find $out -path "*prof_hl_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h256_f16x3.txt
+python tools/prof_summary.py $(find $out -path "*prof_md_*" -name "*_results.db" | sort) > $out/${tag}_mdtc_h64_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_hl32_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h256_f32.txt
-python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=profiles/${tag}_ds_tcn_h256_f16x3.txt ds_tcn_h256/B1024/f32=hl32=profiles/${tag}_ds_tcn_h256_f32.txt > $out/${tag}_pmc_traffic.log 2>&1
+python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=profiles/${tag}_ds_tcn_h256_f16x3.txt ds_tcn_h256/B1024/f32=hl32=profiles/${tag}_ds_tcn_h256_f32.txt mdtc_h64/B1024/f16x3=md=profiles/${tag}_mdtc_h64_f16x3.txt > $out/${tag}_pmc_traffic.log 2>&1
 cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 # streaming kernels: kernel trace of the many-streams sweep and of the GRU rows
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/prof_strm_a -o t -- bash -c "cd $root && python tools/bench_configs.py manystreams" > $out/prof_strm_a.log 2>&1)

@@ -105,7 +105,8 @@ __device__ __forceinline__ void g4_store_tail_n(int s, float* dst, const f32x4 (
   }
 }
 
-template <int NT, bool SPLIT>
+// POOLED: the head is GlobalClassifier / LastClassifier (classifier.py:26-28, :38-40) instead of the per-frame linear one.
+template <int NT, bool SPLIT, bool POOLED>
 __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackParams P, const CallArgs A) {
   constexpr int C = 64, TT = 16 * NT;
   constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the 64-channel operand
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
   // The head is linear, so the sum of the stack outputs (mdtc.py:270-273) never has to exist: every stack end adds ITS
   // contribution to the lane's partial head sums  yp[tt][k] = sum_r Wc[k][o0 + r] * out[r][frame tt]  (2 NT registers
   // instead of 4 NT for the sum itself -- the kernel is at the 128-register limit of four workgroups per CU).
-  float yp[NT][2];
+  float yp[POOLED ? 1 : NT][2];
+  // POOLED heads need even less: the time pooling commutes with the stack sum as well, so a lane keeps one running value per
+  // channel -- the sum over its (valid) frames (Global) or its frame T - 1 (Last: register NT - 1 of one lane, the
+  // utterance's end is lane-aligned) -- of every stack output.
+  float zs[4] = {0.f, 0.f, 0.f, 0.f};
 
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     a.l = __builtin_bit_cast(f16x8, ap[ln + 64]);
   };
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt) yp[tt][0] = yp[tt][1] = 0.f;
+  for (int tt = 0; tt < (POOLED ? 1 : NT); ++tt) yp[tt][0] = yp[tt][1] = 0.f;
   F16Frag g1a;                                               // GEMM 1, first K step: requested a block ahead
   __syncthreads();                                           // (A) maximum published, planes free, table / taps visible
   load_frag(g1a, frag_ptr(blk[0].a1_16), lane);
@@ -344,7 +349,22 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
         hmax = fmaxf(hmax, v);
       }
     }
-#ifndef G4_NO_ZADD
+    if constexpr (POOLED) {
+      if (bd.zadd) {
+        const int lastl = (T + off) / NT - 1;                // the lane that holds frame T - 1 (in register NT - 1)
+        if (P.head == HEAD_GLOBAL) {
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt) {
+            const bool in = NT * l15 + tt - off < T;         // (frames below zero are zeros already)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zs[r] += in ? hv[tt][r] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zs[r] += l15 == lastl ? hv[NT - 1][r] : 0.f;
+        }
+      }
+    } else
     if (bd.zadd) {                                           // the block closes a stack: its output enters the head
       const int K = P.odim;
       const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0b);
@@ -359,11 +379,59 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
         yp[tt][0] = p0; yp[tt][1] = p1;
       }
     }
-#endif
     amax_publish(amax_cells + 3 + bi, hmax);                 // = the input tile of block bi + 1
     __syncthreads();                                         // (B4) maximum published, planes free
   }
 
+  if constexpr (POOLED) {
+    // ---- pooled heads: m = mean_t / last frame of the stack sum -> W2 ReLU(W1 m + b1) + b2.  The 16 lanes of a row add
+    //      their channel sums (xor butterfly), the 64 pooled values meet in LDS, one small MLP on the vector units.
+    float* const mvec = g4_lds;                              // [64] pooled channels, then [head_hidden]
+    float* const hid = g4_lds + C;
+    int th = threadIdx.x;
+    asm volatile("" : "+v"(th));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = zs[r];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+      zs[r] = v;
+    }
+    const int c0 = (th >> 4) * 4;                            // = o0
+    if ((th & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = zs[r];
+        if (P.head == HEAD_GLOBAL) {
+          if (A.gsum) {                                      // long inputs: running sums across the tiles of the call
+            float* gp = A.gsum + int64_t(b) * C + c0 + r;
+            if (!A.first_tile) v += *gp;
+            if (!A.last_tile) *gp = v;
+          }
+          v = v / float(A.T_total);
+        }
+        mvec[c0 + r] = v;
+      }
+    }
+    __syncthreads();
+    if (A.last_tile) {
+      const int HH = P.head_hidden, K = P.odim;
+      for (int j = th; j < HH; j += kG4Threads) {
+        const float* w1 = W + P.head_w + j * C;
+        float v = W[P.head_b + j];
+        for (int c = 0; c < C; ++c) v = fmaf(w1[c], mvec[c], v);
+        hid[j] = fmaxf(v, 0.f);
+      }
+      __syncthreads();
+      for (int k = th; k < K; k += kG4Threads) {
+        const float* w2 = W + P.head_w2 + k * HH;
+        float v = W[P.head_b2 + k];
+        for (int j = 0; j < HH; ++j) v = fmaf(w2[j], hid[j], v);
+        if (P.sigmoid) v = sigmoidf_(v);
+        A.y[int64_t(b) * A.ys_b + k] = v;
+      }
+    }
+  } else
   // ---- keyword head (per-frame linear, one or two outputs; classifier.py:63-67) on the sum of the stack outputs
   //      (mdtc.py:270-273): the 16 partial sums per output (4 waves x 4 channel groups) meet in LDS
   {
@@ -389,7 +457,8 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
 }
 
 // Usable when (the host checks the model side: hidden_dim 64, kernel size 5, dilations 1 / 2 / 4 / 8, pads 4 d): no incoming
-// cache, features of <= 96 dims in whole aligned 8-float items, a per-frame linear head with one or two outputs.
+// cache, features of <= 96 dims in whole aligned 8-float items, a per-frame linear head with one or two outputs or a pooled
+// (Global / Last) head whose hidden layer fits the LDS left over.
 // Returns -4 otherwise (the caller then runs mdtc64_w16).
 int launch_mdtc64_g4(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 

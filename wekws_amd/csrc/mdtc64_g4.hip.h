@@ -17,8 +17,8 @@
 //     lane owns NT consecutive frames; off = (-T) mod NT aligns the END of the utterance with a lane boundary (frames below
 //     zero are kept at zero = the causal left context), so the cache slices (the last 4 d frames) are whole lanes plus one
 //     lane's last (4 d) mod NT registers: wide stores;
-//   * depthwise taps (k = 5, mdtc.py:55-58): one v_fmac_f32_dpp row_shr per tap and output, none when the shift is a
-//     whole number of... when the source stays in the lane (plain FMA), nothing when it leaves the 16-lane row;
+//   * depthwise taps (k = 5, mdtc.py:55-58): one v_fmac_f32_dpp row_shr per tap and output, a plain FMA when the source
+//     stays in the lane, nothing when it leaves the 16-lane row;
 //   * block = dw -> planes | barrier | GEMM 1 | barrier | mid = ReLU(BN1) -> planes | barrier | GEMM 2, epilogue in
 //     registers (residual before the ReLU, mdtc.py:115-118; stack sum, mdtc.py:270-273) | barrier: four barriers of four
 //     waves;

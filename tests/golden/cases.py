@@ -349,3 +349,25 @@ GRU_INPUT_CASES = [_c(f"gru_2x128/x{k:+d}", "gru_2x128", B=2, T=20, cache="rando
 def hetero_case_weights(case, sd):
     kind, E = case["hetero"]
     return hetero_state_dict(case_config(case), sd, kind, E)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Widths no kernel is built for (VERDICT r2 "shapes the reference accepts and the library refuses"): hidden_dim is free in
+# kws_model.py:114; the library pads the channels with zeros to the next built width.  Goldens: make_shape_golden.py.
+# ---------------------------------------------------------------------------------------------------------------------
+SHAPE_CASES = [
+    dict(name="ds_tcn_h96", model="ds_tcn_h256", hidden=96, B=3, T=60, split=23, wseed=301, xseed=31),     # -> 128
+    dict(name="ds_tcn_h192", model="ds_tcn_h256", hidden=192, B=2, T=98, split=50, wseed=302, xseed=32),   # -> 256 (ds256_g16)
+    dict(name="ds_tcn_h20", model="ds_tcn_h64", hidden=20, B=2, T=40, split=10, wseed=303, xseed=33),      # -> 32
+    dict(name="tcn_h40", model="tcn_h64", hidden=40, B=2, T=45, split=16, wseed=304, xseed=34),            # -> 64
+    dict(name="mdtc_h48", model="mdtc_h64", hidden=48, B=3, T=98, split=40, wseed=305, xseed=35),          # -> 64 (mdtc64_g4)
+    dict(name="mdtc_h96_global12", model="mdtc_h64_global12", hidden=96, B=2, T=70, wseed=306, xseed=36),   # -> 128
+]
+
+
+def shape_case_config(case):
+    cfg = copy.deepcopy(synth.MODEL_CONFIGS[case["model"]])
+    cfg["hidden_dim"] = case["hidden"]
+    if "hidden_dim" in cfg["backbone"]:
+        cfg["backbone"]["hidden_dim"] = case["hidden"]
+    return cfg

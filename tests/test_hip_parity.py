@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from oracle import kws_oracle
-from tests.golden.cases import GRU_INPUT_CASES, HETERO_CASES, SCALE_CASES, hetero_case_weights, scaled_case_weights
+from tests.golden.cases import (GRU_INPUT_CASES, HETERO_CASES, SCALE_CASES, SHAPE_CASES, hetero_case_weights,
+                                scaled_case_weights, shape_case_config)
 from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
 from wekws_amd.model.kws_model import init_model
 from wekws_amd.utils import synth
@@ -98,6 +99,39 @@ def test_scale_sweep(case, precision, scale_golden, error_report):
     err = max_abs(y, gy) if np.isfinite(y).all() else float("inf")
     error_report[f"scale_sweep/{precision}/{case['name']}"] = err
     assert err <= tol_for(gy), f"y err {err:.3e}"
+
+
+@pytest.fixture(scope="module")
+def shape_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shape_golden.npz"))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("case", SHAPE_CASES, ids=[c["name"] for c in SHAPE_CASES])
+def test_hidden_dims_without_a_kernel(case, precision, shape_golden, error_report):
+    """hidden_dim is free in the reference (kws_model.py:114); the kernels are built for 32 / 64 / 128 / 256 channels.  Any
+    other width up to 256 runs zero-padded to the next built one (wekws_hip.hip::pad_conv_channels): exact, because a zero
+    channel stays zero through the network.  Goldens from the live reference (make_shape_golden.py): one-shot posteriors and
+    cache (with the MODEL's channel count), and the same input in two chunks with the carried cache."""
+    from wekws_amd.utils import synth as synth_
+    cfg = shape_case_config(case)
+    from wekws_amd import pack
+    sd = synth_.synth_state_dict(pack.model_spec(cfg), case["wseed"])
+    assert abs(synth_.checksum(sd) - float(shape_golden[case["name"] + "/wsum"])) <= 1e-6 * abs(float(shape_golden[case["name"] + "/wsum"]))
+    model = build(cfg, sd).set_precision(precision)
+    x = synth_.synth_feats(case["B"], case["T"], cfg["input_dim"], seed=case["xseed"])
+    y, c = run(model, x)
+    gy, gc = shape_golden[case["name"] + "/y"], shape_golden[case["name"] + "/cache"]
+    assert y.shape == gy.shape and c.shape == gc.shape, (y.shape, c.shape)
+    error_report[f"shape/{precision}/{case['name']}"] = max_abs(y, gy)
+    assert max_abs(y, gy) <= tol_for(gy), max_abs(y, gy)
+    assert max_abs(c, gc) <= tol_for(gc), max_abs(c, gc)
+    if case.get("split"):
+        t1 = case["split"]
+        ys, cs = run(model, x, chunks=[t1, case["T"] - t1])
+        assert max_abs(ys, shape_golden[case["name"] + "/y_stream"]) <= tol_for(gy)
+        assert max_abs(cs, shape_golden[case["name"] + "/cache_stream"]) <= tol_for(gc)
 
 
 @pytest.fixture(scope="module")

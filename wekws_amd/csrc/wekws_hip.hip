@@ -300,6 +300,8 @@ struct wekws_hip_model {
   wekws::FsmnParams fq{};
   int fsmn_max_nt = 0;
   int fsmn_cus = 256;     // compute units of the device (FSMN utterance packing, GRU pass splitting)
+  int user_hdim = 0;      // conv backbones created with a hidden_dim no kernel is built for: the caller's hidden_dim (desc.hdim is
+                          // then the next built width; the extra channels are zero everywhere, see pad_conv_channels)
   int cache_len = 0;
   std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
@@ -578,10 +580,57 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
     wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
     return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + sc_b;
   }
-  if (T <= WEKWS_HIP_TILE_FRAMES) return 0;
   const size_t ce = size_t(B) * d.hdim * m->cache_len;
+  const size_t padded = m->user_hdim ? 2 * ce : 0;          // the caller's caches, widened to the built channel count, in + out
+  if (T <= WEKWS_HIP_TILE_FRAMES) return padded * sizeof(float);
   const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * d.hdim : 0;
-  return (2 * ce + ge) * sizeof(float);
+  return (2 * ce + ge + padded) * sizeof(float);
+}
+
+// Conv backbones whose hidden_dim C is not one of the built widths (32 / 64 / 128 / 256) run as the next built width Cp with
+// the extra channels ZERO everywhere: zero rows and columns in every matrix, zero taps and biases.  A zero channel stays
+// zero through the whole network (ReLU(0) = 0, residual 0 + 0) and adds exact zeros to every sum it enters, so the
+// posteriors are those of the C-channel model; maxima, and with them the block-floating scales, are unchanged.  Returns the
+// widened blob in the documented order (include/wekws_hip.h); `d` must be a conv descriptor that passed blob_elems().
+static std::vector<float> pad_conv_channels(const wekws_hip_desc& d, const float* p, int Cp) {
+  const int C = d.hdim, ks = d.kernel_size, K = d.odim;
+  std::vector<float> out;
+  auto rows = [&](int R, int Rp, int cols, int colsp, int inner) {     // [R][cols][inner] -> [Rp][colsp][inner], zero padded
+    const size_t base = out.size();
+    out.resize(base + size_t(Rp) * colsp * inner, 0.f);
+    for (int r = 0; r < R; ++r)
+      for (int c = 0; c < cols; ++c)
+        std::memcpy(&out[base + (size_t(r) * colsp + c) * inner], p + (size_t(r) * cols + c) * inner, inner * sizeof(float));
+    p += size_t(R) * cols * inner;
+  };
+  rows(C, Cp, d.idim, d.idim, 1);                            // preprocessing W [C][idim], b [C]
+  rows(C, Cp, 1, 1, 1);
+  for (int i = 0; i < n_blocks(d); ++i) {
+    if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
+      rows(C, Cp, C, Cp, ks);                                // dense conv [C][C][ks], b [C]
+      rows(C, Cp, 1, 1, 1);
+    } else {
+      rows(C, Cp, 1, 1, ks);                                 // depthwise taps [C][ks], bias [C]
+      rows(C, Cp, 1, 1, 1);
+      rows(C, Cp, C, Cp, 1);                                 // pointwise [C][C], b [C]
+      rows(C, Cp, 1, 1, 1);
+      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC) {
+        rows(C, Cp, C, Cp, 1);                               // conv2 [C][C], b [C]
+        rows(C, Cp, 1, 1, 1);
+      }
+    }
+  }
+  if (d.head == WEKWS_HIP_HEAD_LINEAR) {
+    rows(K, K, C, Cp, 1);                                    // Wc [K][C], bc [K]
+    rows(K, K, 1, 1, 1);
+  } else if (d.head == WEKWS_HIP_HEAD_GLOBAL || d.head == WEKWS_HIP_HEAD_LAST) {
+    const int HH = d.head_hidden;
+    rows(HH, HH, C, Cp, 1);                                  // W1 [HH][C], b1, W2 [K][HH], b2
+    rows(HH, HH, 1, 1, 1);
+    rows(K, K, HH, HH, 1);
+    rows(K, K, 1, 1, 1);
+  }
+  return out;
 }
 
 // The frames of one FSMN call, cut into LDS tiles chained through ping-pong workspace caches
@@ -653,9 +702,21 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   std::vector<float> balanced(blob, blob + n_elems);        // (exact power-of-two rescaling: see balance_operand_channels)
   balance_operand_channels(d, balanced.data());
   blob = balanced.data();
+  if (desc_conv(d) && C != 32 && C != 64 && C != 128 && C != 256) {
+    // any other width up to 256 (kws_model.py:114 takes any hidden_dim): run as the next built width, zero-padded
+    const int Cp = C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
+    if (C > 256) return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for up to 256 channels", C);
+    if (d.head == WEKWS_HIP_HEAD_IDENTITY)
+      return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d with the identity head: kernels are built for 32/64/128/256", C);
+    wekws_hip_desc dd = d;
+    dd.hdim = Cp;
+    const std::vector<float> wide = pad_conv_channels(d, blob, Cp);
+    if (wide.size() != blob_elems(dd)) return fail(WEKWS_HIP_EINVAL, "internal: widened blob has %zu floats, expected %zu", wide.size(), blob_elems(dd));
+    const int rc = wekws_hip_create(&dd, wide.data(), wide.size(), device, out);
+    if (rc == WEKWS_HIP_OK) (*out)->user_hdim = C;
+    return rc;
+  }
   if (desc_conv(d)) {
-    if (C != 32 && C != 64 && C != 128 && C != 256)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for 32/64/128/256", C);
     if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256)
       return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim 256 does not fit the LDS tile");
     // the conv kernels are specialised for the kernel sizes of the reference recipes
@@ -945,7 +1006,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
 
 int wekws_hip_cache_dim(const wekws_hip_model* m) {
   if (!m) return 0;
-  return m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN ? m->desc.num_stack : m->desc.hdim;
+  return m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN ? m->desc.num_stack : m->user_hdim ? m->user_hdim : m->desc.hdim;
 }
 int wekws_hip_cache_len(const wekws_hip_model* m) { return m ? m->cache_len : 0; }
 
@@ -972,7 +1033,7 @@ size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
   if (!m || B <= 0) return 0;
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * m->desc.hdim;
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN) return size_t(B) * m->desc.num_stack * m->cache_len * m->desc.num_layers;
-  return size_t(B) * m->desc.hdim * m->cache_len;
+  return size_t(B) * (m->user_hdim ? m->user_hdim : m->desc.hdim) * m->cache_len;
 }
 
 size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T) {
@@ -1087,15 +1148,30 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     const int C = d.hdim;
     float* ws_cache[2] = {nullptr, nullptr};
     float* gsum = nullptr;
-    if (ntiles > 1) {
-      // long input: tiles hand the causal context over through ping-pong caches in the stream's workspace
-      const size_t ce = size_t(B) * C * m->cache_len;
-      const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * C : 0;
+    const size_t ce = size_t(B) * C * m->cache_len;
+    float* user_out_cache = nullptr;                         // (widened models: where the caller wants the cache)
+    if (ntiles > 1 || m->user_hdim) {
       char* base = stream_workspace(m, stream, workspace_need(m, B, T));
       if (!base) return WEKWS_HIP_ENOMEM;
-      ws_cache[0] = reinterpret_cast<float*>(base);
-      ws_cache[1] = ws_cache[0] + ce;
-      if (ge) gsum = ws_cache[1] + ce;
+      float* next = reinterpret_cast<float*>(base);
+      if (ntiles > 1) {
+        // long input: tiles hand the causal context over through ping-pong caches in the stream's workspace
+        const size_t ge = d.head == WEKWS_HIP_HEAD_GLOBAL ? size_t(B) * C : 0;
+        ws_cache[0] = next;
+        ws_cache[1] = ws_cache[0] + ce;
+        if (ge) gsum = ws_cache[1] + ce;
+        next = ws_cache[1] + ce + ge;
+      }
+      if (m->user_hdim) {
+        // the caller's caches have user_hdim channel rows: widened copies with zero rows behind them go to the kernels
+        const size_t row = size_t(m->cache_len) * sizeof(float);
+        if (in_cache) {
+          HIP_TRY(hipMemsetAsync(next, 0, ce * sizeof(float), stream));
+          HIP_TRY(hipMemcpy2DAsync(next, C * row, in_cache, m->user_hdim * row, m->user_hdim * row, B, hipMemcpyDeviceToDevice, stream));
+          in_cache = next;
+        }
+        if (out_cache) { user_out_cache = out_cache; out_cache = next + ce; }
+      }
     }
     for (int i = 0; i < ntiles; ++i) {
       const int t0 = i * TILE;
@@ -1163,6 +1239,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           break;
       }
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
+    }
+    if (user_out_cache) {
+      const size_t row = size_t(m->cache_len) * sizeof(float);
+      HIP_TRY(hipMemcpy2DAsync(user_out_cache, m->user_hdim * row, out_cache, C * row, m->user_hdim * row, B, hipMemcpyDeviceToDevice, stream));
     }
   }
   if (softmax || d.activation == WEKWS_HIP_ACT_SOFTMAX) {

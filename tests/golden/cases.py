@@ -362,12 +362,23 @@ SHAPE_CASES = [
     dict(name="tcn_h40", model="tcn_h64", hidden=40, B=2, T=45, split=16, wseed=304, xseed=34),            # -> 64
     dict(name="mdtc_h48", model="mdtc_h64", hidden=48, B=3, T=98, split=40, wseed=305, xseed=35),          # -> 64 (mdtc64_g4)
     dict(name="mdtc_h96_global12", model="mdtc_h64_global12", hidden=96, B=2, T=70, wseed=306, xseed=36),   # -> 128
+    # kernel sizes below the built ones (8 for tcn / ds-tcn, 5 for mdtc): zero taps in front, cache slices remapped
+    dict(name="ds_tcn_h256_k5", model="ds_tcn_h256", ksize=5, B=2, T=98, split=37, wseed=307, xseed=37),   # (ds256_g16 / w16)
+    dict(name="tcn_h64_k3", model="tcn_h64", ksize=3, B=2, T=50, split=20, wseed=308, xseed=38),
+    dict(name="mdtc_h64_k3", model="mdtc_h64", ksize=3, B=3, T=98, split=30, wseed=309, xseed=39),         # (mdtc64_g4 / w16)
+    dict(name="ds_tcn_h96_k6", model="ds_tcn_h256", hidden=96, ksize=6, B=2, T=64, split=16, wseed=310, xseed=40),
+    # GRU hidden sizes below the built 128: zero-padded units (gates stay at r = z = 1/2, n = 0, h = 0)
+    dict(name="gru_2x64", model="gru_2x128", hidden=64, B=3, T=50, split=20, wseed=311, xseed=41),
+    dict(name="gru_2x96", model="gru_2x128", hidden=96, B=2, T=30, split=10, wseed=312, xseed=42),
 ]
 
 
 def shape_case_config(case):
     cfg = copy.deepcopy(synth.MODEL_CONFIGS[case["model"]])
-    cfg["hidden_dim"] = case["hidden"]
-    if "hidden_dim" in cfg["backbone"]:
-        cfg["backbone"]["hidden_dim"] = case["hidden"]
+    if case.get("hidden"):
+        cfg["hidden_dim"] = case["hidden"]
+        if "hidden_dim" in cfg["backbone"]:
+            cfg["backbone"]["hidden_dim"] = case["hidden"]
+    if case.get("ksize"):
+        cfg["backbone"]["kernel_size"] = case["ksize"]
     return cfg

@@ -33,7 +33,9 @@ def main():
         x = synth.synth_feats(case["B"], case["T"], cfg["input_dim"], seed=case["xseed"])
         with torch.no_grad():
             xt = torch.from_numpy(x)
-            y, c = model(xt)
+            gru = cfg["backbone"]["type"] == "gru"            # (torch.nn.GRU wants its h0: the reference's streaming callers pass zeros)
+            h0 = torch.zeros(cfg["backbone"]["num_layers"], case["B"], cfg["hidden_dim"]) if gru else None
+            y, c = model(xt, h0) if gru else model(xt)
         name = case["name"]
         out[name + "/y"] = y.numpy().astype(np.float32)
         out[name + "/cache"] = c.numpy().astype(np.float32)
@@ -42,7 +44,7 @@ def main():
         if case.get("split"):                                 # (per-frame heads: the same input in two chunks)
             with torch.no_grad():
                 t1 = case["split"]
-                ya, ca = model(xt[:, :t1])
+                ya, ca = model(xt[:, :t1], h0) if gru else model(xt[:, :t1])
                 yb, cb = model(xt[:, t1:], ca)
             out[name + "/y_stream"] = torch.cat([ya, yb], 1).numpy().astype(np.float32)
             out[name + "/cache_stream"] = cb.numpy().astype(np.float32)

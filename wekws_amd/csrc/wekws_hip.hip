@@ -268,6 +268,28 @@ size_t blob_elems(const wekws_hip_desc& d) {
 
 }  // namespace
 
+// (block-wise copy between two cache layouts (B, C, P): slice i of the destination -- d_off[i], len[i] -- comes from s_off[i] of the
+// source; destination elements outside every slice, or in channels the source does not have, are zero)
+struct CacheMap {
+  int nb;
+  int s_off[wekws::kAmaxMaxBlocks], d_off[wekws::kAmaxMaxBlocks], len[wekws::kAmaxMaxBlocks];
+};
+static __global__ void cache_remap_kernel(float* __restrict__ dst, const float* __restrict__ src, int B, int Cd, int Pd, int Cs, int Ps,
+                                          const CacheMap m) {
+  const int64_t n = int64_t(B) * Cd * Pd;
+  for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += int64_t(gridDim.x) * blockDim.x) {
+    const int p = int(e % Pd);
+    const int64_t bc = e / Pd;
+    const int c = int(bc % Cd), b = int(bc / Cd);
+    float v = 0.f;
+    if (c < Cs) {
+      for (int i = 0; i < m.nb; ++i)
+        if (p >= m.d_off[i] && p < m.d_off[i] + m.len[i]) v = src[(int64_t(b) * Cs + c) * Ps + m.s_off[i] + (p - m.d_off[i])];
+    }
+    dst[e] = v;
+  }
+}
+
 struct wekws_hip_model {
   wekws_hip_desc desc;
   int device = 0;
@@ -300,8 +322,12 @@ struct wekws_hip_model {
   wekws::FsmnParams fq{};
   int fsmn_max_nt = 0;
   int fsmn_cus = 256;     // compute units of the device (FSMN utterance packing, GRU pass splitting)
-  int user_hdim = 0;      // conv backbones created with a hidden_dim no kernel is built for: the caller's hidden_dim (desc.hdim is
-                          // then the next built width; the extra channels are zero everywhere, see pad_conv_channels)
+  // Conv backbones created with a hidden_dim / kernel_size no kernel is built for run as the next built shape (extra channels
+  // and the extra OLDEST taps are zero everywhere, see pad_conv_shape); desc then describes the built shape and these keep
+  // the caller's: its channel count, its cache length, and how its cache's per-block slices map into the wider ones.
+  int user_hdim = 0;
+  int user_cache_len = 0;
+  CacheMap widen{}, narrow{};
   int cache_len = 0;
   std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
@@ -575,10 +601,12 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
     return 2 * size_t(B) * d.num_stack * m->cache_len * d.num_layers * sizeof(float);
   }
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    if (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq)) return 0;
+    // (a hidden size below the built 128 runs zero-padded: widened copies of the caller's states, in + out)
+    const size_t padded = m->user_hdim ? 2 * size_t(d.num_layers) * B * d.hdim * sizeof(float) : 0;
+    if (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq)) return padded;
     size_t seq_b = 0, gi_b = 0, sc_b = 0;
     wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
-    return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + sc_b;
+    return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + (sc_b + 255) / 256 * 256 + padded;
   }
   const size_t ce = size_t(B) * d.hdim * m->cache_len;
   const size_t padded = m->user_hdim ? 2 * ce : 0;          // the caller's caches, widened to the built channel count, in + out
@@ -592,9 +620,45 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
 // zero through the whole network (ReLU(0) = 0, residual 0 + 0) and adds exact zeros to every sum it enters, so the
 // posteriors are those of the C-channel model; maxima, and with them the block-floating scales, are unchanged.  Returns the
 // widened blob in the documented order (include/wekws_hip.h); `d` must be a conv descriptor that passed blob_elems().
-static std::vector<float> pad_conv_channels(const wekws_hip_desc& d, const float* p, int Cp) {
+// GRU (torch.nn.GRU, kws_model.py:128-133) with a hidden size H below the built 128: the extra units have zero weights and
+// biases in all three gates, so r = z = 1/2, n = tanh(0) = 0 and h' = (1 - z) n + z h stays 0 from a zero-padded h0 -- the
+// real units never see them (zero columns).  Gate blocks [r | z | n] are padded one by one.
+static std::vector<float> pad_gru_hidden(const wekws_hip_desc& d, const float* p, int Hp) {
+  const int H = d.hdim, K = d.odim;
+  std::vector<float> out;
+  auto rows = [&](int R, int Rp, int cols, int colsp) {
+    const size_t base = out.size();
+    out.resize(base + size_t(Rp) * colsp, 0.f);
+    for (int r = 0; r < R; ++r) std::memcpy(&out[base + size_t(r) * colsp], p + size_t(r) * cols, cols * sizeof(float));
+    p += size_t(R) * cols;
+  };
+  rows(H, Hp, d.idim, d.idim);
+  rows(H, Hp, 1, 1);
+  for (int l = 0; l < d.num_layers; ++l) {
+    for (int g = 0; g < 3; ++g) rows(H, Hp, H, Hp);          // W_ih
+    for (int g = 0; g < 3; ++g) rows(H, Hp, H, Hp);          // W_hh
+    for (int g = 0; g < 3; ++g) rows(H, Hp, 1, 1);           // b_ih
+    for (int g = 0; g < 3; ++g) rows(H, Hp, 1, 1);           // b_hh
+  }
+  rows(K, K, H, Hp);
+  rows(K, K, 1, 1);
+  return out;
+}
+
+// Likewise a kernel size ks below the built one ksp: a causal dilated conv with ks taps IS the ksp-tap conv whose first
+// (oldest) ksp - ks taps are zero; only the streaming cache differs (ksp - 1 instead of ks - 1 dilations per block: the
+// extra, older frames meet zero taps) -- wekws_hip_forward copies the caller's slices into / out of the tails of the wider ones.
+static std::vector<float> pad_conv_shape(const wekws_hip_desc& d, const float* p, int Cp, int ksp) {
   const int C = d.hdim, ks = d.kernel_size, K = d.odim;
   std::vector<float> out;
+  auto taps = [&](int R, int Rp, int cols, int colsp) {      // [R][cols][ks] -> [Rp][colsp][ksp], taps right-aligned
+    const size_t base = out.size();
+    out.resize(base + size_t(Rp) * colsp * ksp, 0.f);
+    for (int r = 0; r < R; ++r)
+      for (int c = 0; c < cols; ++c)
+        std::memcpy(&out[base + (size_t(r) * colsp + c) * ksp + (ksp - ks)], p + (size_t(r) * cols + c) * ks, ks * sizeof(float));
+    p += size_t(R) * cols * ks;
+  };
   auto rows = [&](int R, int Rp, int cols, int colsp, int inner) {     // [R][cols][inner] -> [Rp][colsp][inner], zero padded
     const size_t base = out.size();
     out.resize(base + size_t(Rp) * colsp * inner, 0.f);
@@ -607,10 +671,10 @@ static std::vector<float> pad_conv_channels(const wekws_hip_desc& d, const float
   rows(C, Cp, 1, 1, 1);
   for (int i = 0; i < n_blocks(d); ++i) {
     if (d.backbone == WEKWS_HIP_BACKBONE_TCN) {
-      rows(C, Cp, C, Cp, ks);                                // dense conv [C][C][ks], b [C]
+      taps(C, Cp, C, Cp);                                    // dense conv [C][C][ks], b [C]
       rows(C, Cp, 1, 1, 1);
     } else {
-      rows(C, Cp, 1, 1, ks);                                 // depthwise taps [C][ks], bias [C]
+      taps(C, Cp, 1, 1);                                     // depthwise taps [C][ks], bias [C]
       rows(C, Cp, 1, 1, 1);
       rows(C, Cp, C, Cp, 1);                                 // pointwise [C][C], b [C]
       rows(C, Cp, 1, 1, 1);
@@ -702,19 +766,40 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   std::vector<float> balanced(blob, blob + n_elems);        // (exact power-of-two rescaling: see balance_operand_channels)
   balance_operand_channels(d, balanced.data());
   blob = balanced.data();
-  if (desc_conv(d) && C != 32 && C != 64 && C != 128 && C != 256) {
-    // any other width up to 256 (kws_model.py:114 takes any hidden_dim): run as the next built width, zero-padded
-    const int Cp = C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
-    if (C > 256) return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for up to 256 channels", C);
-    if (d.head == WEKWS_HIP_HEAD_IDENTITY)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d with the identity head: kernels are built for 32/64/128/256", C);
-    wekws_hip_desc dd = d;
-    dd.hdim = Cp;
-    const std::vector<float> wide = pad_conv_channels(d, blob, Cp);
-    if (wide.size() != blob_elems(dd)) return fail(WEKWS_HIP_EINVAL, "internal: widened blob has %zu floats, expected %zu", wide.size(), blob_elems(dd));
-    const int rc = wekws_hip_create(&dd, wide.data(), wide.size(), device, out);
-    if (rc == WEKWS_HIP_OK) (*out)->user_hdim = C;
-    return rc;
+  {
+    const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
+    const bool odd_c = C != 32 && C != 64 && C != 128 && C != 256;
+    if (desc_conv(d) && (odd_c || (ks >= 1 && ks < ks_built))) {
+      // any width up to 256 and any kernel size up to the built one (kws_model.py:114,142-157 take any): run as the next
+      // built shape, zero-padded -- exact, see pad_conv_shape
+      const int Cp = !odd_c ? C : C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
+      if (C > 256) return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for up to 256 channels", C);
+      if (n_blocks(d) > wekws::kAmaxMaxBlocks)
+        return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks with a padded shape: the cache maps hold %d", n_blocks(d), wekws::kAmaxMaxBlocks);
+      if (odd_c && d.head == WEKWS_HIP_HEAD_IDENTITY)
+        return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d with the identity head: kernels are built for 32/64/128/256", C);
+      wekws_hip_desc dd = d;
+      dd.hdim = Cp;
+      dd.kernel_size = ks_built;
+      const std::vector<float> wide = pad_conv_shape(d, blob, Cp, ks_built);
+      if (wide.size() != blob_elems(dd)) return fail(WEKWS_HIP_EINVAL, "internal: widened blob has %zu floats, expected %zu", wide.size(), blob_elems(dd));
+      const int rc = wekws_hip_create(&dd, wide.data(), wide.size(), device, out);
+      if (rc != WEKWS_HIP_OK) return rc;
+      wekws_hip_model* m = *out;
+      m->user_hdim = C;
+      // the caller's cache: per block (ks - 1) dil frames, the tail of the built kernel's (ks_built - 1) dil
+      int uoff = 0, boff = 0;
+      m->widen.nb = m->narrow.nb = n_blocks(d);
+      for (int i = 0; i < n_blocks(d); ++i) {
+        const int dil = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? ((i == 0) ? 1 : (1 << ((i - 1) % d.stack_size))) : (1 << i);
+        const int ulen = (ks - 1) * dil, blen = (ks_built - 1) * dil;
+        m->widen.s_off[i] = uoff; m->widen.d_off[i] = boff + (blen - ulen); m->widen.len[i] = ulen;
+        m->narrow.s_off[i] = boff + (blen - ulen); m->narrow.d_off[i] = uoff; m->narrow.len[i] = ulen;
+        uoff += ulen; boff += blen;
+      }
+      m->user_cache_len = uoff;
+      return WEKWS_HIP_OK;
+    }
   }
   if (desc_conv(d)) {
     if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256)
@@ -728,7 +813,21 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks: the split-fp16 kernels track %d (precision F32 has no limit)",
                   n_blocks(d), wekws::kAmaxMaxBlocks);
   } else {
-    if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128", C);
+    if (C < 128 && d.head == WEKWS_HIP_HEAD_LINEAR && d.num_layers <= wekws::kGruMaxLayers) {
+      wekws_hip_desc dd = d;
+      dd.hdim = 128;
+      const std::vector<float> wide = pad_gru_hidden(d, blob, 128);
+      if (wide.size() != blob_elems(dd)) return fail(WEKWS_HIP_EINVAL, "internal: widened blob has %zu floats, expected %zu", wide.size(), blob_elems(dd));
+      const int rc = wekws_hip_create(&dd, wide.data(), wide.size(), device, out);
+      if (rc != WEKWS_HIP_OK) return rc;
+      wekws_hip_model* m = *out;
+      m->user_hdim = C;
+      m->widen.nb = m->narrow.nb = 1;                        // states (L, B, H): one "slice" per row
+      m->widen.s_off[0] = m->widen.d_off[0] = m->narrow.s_off[0] = m->narrow.d_off[0] = 0;
+      m->widen.len[0] = m->narrow.len[0] = C;
+      return WEKWS_HIP_OK;
+    }
+    if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128 (smaller sizes run zero-padded)", C);
     if (d.num_layers > wekws::kGruMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "gru num_layers %d > %d", d.num_layers, wekws::kGruMaxLayers);
     if (d.head != WEKWS_HIP_HEAD_LINEAR) return fail(WEKWS_HIP_EUNSUPPORTED, "gru: only the per-frame linear head is built");
   }
@@ -1008,7 +1107,7 @@ int wekws_hip_cache_dim(const wekws_hip_model* m) {
   if (!m) return 0;
   return m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN ? m->desc.num_stack : m->user_hdim ? m->user_hdim : m->desc.hdim;
 }
-int wekws_hip_cache_len(const wekws_hip_model* m) { return m ? m->cache_len : 0; }
+int wekws_hip_cache_len(const wekws_hip_model* m) { return !m ? 0 : m->user_hdim ? m->user_cache_len : m->cache_len; }
 
 int wekws_hip_effective_precision(const wekws_hip_model* m) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
@@ -1031,9 +1130,10 @@ float wekws_hip_weight_spread_log2(const wekws_hip_model* m) { return m ? m->spr
 
 size_t wekws_hip_cache_elems(const wekws_hip_model* m, int B) {
   if (!m || B <= 0) return 0;
-  if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * m->desc.hdim;
+  if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) return size_t(m->desc.num_layers) * B * (m->user_hdim ? m->user_hdim : m->desc.hdim);
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_FSMN) return size_t(B) * m->desc.num_stack * m->cache_len * m->desc.num_layers;
-  return size_t(B) * (m->user_hdim ? m->user_hdim : m->desc.hdim) * m->cache_len;
+  if (m->user_hdim) return size_t(B) * m->user_hdim * m->user_cache_len;
+  return size_t(B) * m->desc.hdim * m->cache_len;
 }
 
 size_t wekws_hip_output_elems(const wekws_hip_model* m, int B, int T) {
@@ -1127,6 +1227,21 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
     const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32 && wekws::gru_f16_supported(m->gq);
     int rc;
+    float* user_h_out = nullptr;
+    if (m->user_hdim) {                                      // zero-padded hidden size: widened copies of the caller's states
+      const size_t need = workspace_need(m, B, T);
+      char* base = stream_workspace(m, stream, need);
+      if (!base) return WEKWS_HIP_ENOMEM;
+      const size_t he = size_t(d.num_layers) * B * d.hdim;
+      float* wide = reinterpret_cast<float*>(base + need) - 2 * he;       // (the tail of the workspace)
+      const int rows = d.num_layers * B;
+      const int grid = int(std::min<size_t>((he + 255) / 256, 4096));
+      if (in_cache) {
+        hipLaunchKernelGGL(cache_remap_kernel, dim3(grid), dim3(256), 0, stream, wide, in_cache, rows, 1, d.hdim, 1, m->user_hdim, m->widen);
+        in_cache = wide;
+      }
+      if (out_cache) { user_h_out = out_cache; out_cache = wide + he; }
+    }
     if (f16) {
       // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
       // same stream are ordered by the stream, calls on different streams never share a buffer
@@ -1142,6 +1257,12 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     }
     if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (user_h_out) {
+      const size_t ue = size_t(d.num_layers) * B * m->user_hdim;
+      const int grid = int(std::min<size_t>((ue + 255) / 256, 4096));
+      hipLaunchKernelGGL(cache_remap_kernel, dim3(grid), dim3(256), 0, stream, user_h_out, out_cache, d.num_layers * B, 1, m->user_hdim, 1,
+                         d.hdim, m->narrow);
+    }
   } else {
     const int TILE = WEKWS_HIP_TILE_FRAMES;
     const int ntiles = (T + TILE - 1) / TILE;
@@ -1163,11 +1284,11 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
         next = ws_cache[1] + ce + ge;
       }
       if (m->user_hdim) {
-        // the caller's caches have user_hdim channel rows: widened copies with zero rows behind them go to the kernels
-        const size_t row = size_t(m->cache_len) * sizeof(float);
+        // the caller's caches have its own channel count and slice lengths: widened copies (zeros elsewhere) go to the kernels
         if (in_cache) {
-          HIP_TRY(hipMemsetAsync(next, 0, ce * sizeof(float), stream));
-          HIP_TRY(hipMemcpy2DAsync(next, C * row, in_cache, m->user_hdim * row, m->user_hdim * row, B, hipMemcpyDeviceToDevice, stream));
+          const int grid = int(std::min<size_t>((ce + 255) / 256, 4096));
+          hipLaunchKernelGGL(cache_remap_kernel, dim3(grid), dim3(256), 0, stream, next, in_cache, B, C, m->cache_len, m->user_hdim,
+                             m->user_cache_len, m->widen);
           in_cache = next;
         }
         if (out_cache) { user_out_cache = out_cache; out_cache = next + ce; }
@@ -1241,8 +1362,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
     }
     if (user_out_cache) {
-      const size_t row = size_t(m->cache_len) * sizeof(float);
-      HIP_TRY(hipMemcpy2DAsync(user_out_cache, m->user_hdim * row, out_cache, C * row, m->user_hdim * row, B, hipMemcpyDeviceToDevice, stream));
+      const size_t ue = size_t(B) * m->user_hdim * m->user_cache_len;
+      const int grid = int(std::min<size_t>((ue + 255) / 256, 4096));
+      hipLaunchKernelGGL(cache_remap_kernel, dim3(grid), dim3(256), 0, stream, user_out_cache, out_cache, B, m->user_hdim, m->user_cache_len,
+                         C, m->cache_len, m->narrow);
     }
   }
   if (softmax || d.activation == WEKWS_HIP_ACT_SOFTMAX) {

@@ -1,16 +1,21 @@
 // Instantiations of the register-resident MDTC h64 kernel (one utterance per 4-wave workgroup).  See mdtc64_g4.hip.h.
 #include "mdtc64_g4.hip.h"
 namespace wekws {
-template <int NT, bool SPLIT, bool POOLED>
+template <int NT, bool SPLIT, bool POOLED, bool ALIGNED>
 static int launch_g4(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   constexpr int LDS = 2 * Plane<64, 16 * NT>::BYTES;
-  hipLaunchKernelGGL((mdtc64_g4_kernel<NT, SPLIT, POOLED>), dim3(A.B), dim3(kG4Threads), LDS, stream, P, A);
+  hipLaunchKernelGGL((mdtc64_g4_kernel<NT, SPLIT, POOLED, ALIGNED>), dim3(A.B), dim3(kG4Threads), LDS, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+template <int NT, bool SPLIT, bool POOLED>
+static int launch_g4_a(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  if constexpr (NT == 1) return launch_g4<NT, SPLIT, POOLED, true>(P, A, stream);     // (NT = 1 divides every T)
+  else return A.T % NT == 0 ? launch_g4<NT, SPLIT, POOLED, true>(P, A, stream) : launch_g4<NT, SPLIT, POOLED, false>(P, A, stream);
 }
 template <int NT>
 static int launch_g4_nt(bool split, bool pooled, const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  if (pooled) return split ? launch_g4<NT, true, true>(P, A, stream) : launch_g4<NT, false, true>(P, A, stream);
-  return split ? launch_g4<NT, true, false>(P, A, stream) : launch_g4<NT, false, false>(P, A, stream);
+  if (pooled) return split ? launch_g4_a<NT, true, true>(P, A, stream) : launch_g4_a<NT, false, true>(P, A, stream);
+  return split ? launch_g4_a<NT, true, false>(P, A, stream) : launch_g4_a<NT, false, false>(P, A, stream);
 }
 int launch_mdtc64_g4(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
   const bool linear = P.head == HEAD_LINEAR && P.odim <= 2;

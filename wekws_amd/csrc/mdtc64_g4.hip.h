@@ -106,7 +106,9 @@ __device__ __forceinline__ void g4_store_tail_n(int s, float* dst, const f32x4 (
 }
 
 // POOLED: the head is GlobalClassifier / LastClassifier (classifier.py:26-28, :38-40) instead of the per-frame linear one.
-template <int NT, bool SPLIT, bool POOLED>
+// ALIGNED: NT divides T (the 98-frame utterance at NT = 7), i.e. off = 0 at compile time: no frames below zero, so none of
+// the masks that keep them at zero (28 compare-selects per block).
+template <int NT, bool SPLIT, bool POOLED, bool ALIGNED>
 __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackParams P, const CallArgs A) {
   constexpr int C = 64, TT = 16 * NT;
   constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the 64-channel operand
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
   const float* __restrict__ W = P.w;
   const int Pc = P.cache_len;
   const int o0 = wave * 16 + lq * 4;                         // this lane's 4 channels: rows of the o-tile AND of the tile h
-  const int off = (NT - T % NT) % NT;                        // frame of column 16 tt + l: NT l + tt - off
+  const int off = ALIGNED ? 0 : (NT - T % NT) % NT;          // frame of column 16 tt + l: NT l + tt - off
   const int frag_off = (lq * TT + l15) * 16;
   // where this lane's 4 channels of column 16 tt + l15 sit in the hi plane: + tt * 256; lo: + MPB
   char* const pst = planes + ((o0 >> 3) * TT + l15) * 16 + (o0 & 7) * 2;
@@ -301,11 +303,9 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
 
     // ---- GEMM 1 (pointwise) over the full K = 64
     const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0b);
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     F16Frag gb;                                              // second K step: arrives behind the first one's MFMAs
     load_frag(gb, frag_ptr(bd.a1_16) + 128, laneb);
-    g16_mfma_step<NT, SPLIT>(acc, g1a, planes + frag_off, planes + MPB + frag_off);
+    g16_mfma_step<NT, SPLIT, true>(acc, g1a, planes + frag_off, planes + MPB + frag_off);   // (C = 0: no cleared accumulators)
     g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
     F16Frag g2a;                                             // GEMM 2, first K step: arrives behind the mid epilogue
     load_frag(g2a, frag_ptr(bd.a2_16), laneb);
@@ -332,10 +332,8 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0b);   // (arrives behind GEMM 2)
 
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), registers only
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_frag(gb, frag_ptr(bd.a2_16) + 128, laneb);
-    g16_mfma_step<NT, SPLIT>(acc, g2a, planes + frag_off, planes + MPB + frag_off);
+    g16_mfma_step<NT, SPLIT, true>(acc, g2a, planes + frag_off, planes + MPB + frag_off);
     g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
     if (bi + 1 < P.nblocks) load_frag(g1a, frag_ptr(blk[bi + 1].a1_16), laneb);   // next block's GEMM 1: behind its depthwise phase
     float hmax = 0.f;

@@ -484,13 +484,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     if (bi + 1 < P.nblocks) stage_taps(blk[bi + 1]);         // (this block's taps were last read before barrier (B))
 
     // ---- pointwise conv: all eight K steps back to back
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ks = 0; ks < NKS; ks += 2) {
+    auto kpass = [&](int ks, auto first_c) __attribute__((always_inline)) {
       const char* bsrc = planes + ks * 2 * PB + frag_off;
       const uint4* nx = ks + 2 < NKS ? ap1 + (ks + 2) * 128 : apn;   // (last pass: K step 0 of the next block)
-      g16_mfma_step<NT, SPLIT>(acc, a0, bsrc, bsrc + PB);
+      g16_mfma_step<NT, SPLIT, decltype(first_c)::value>(acc, a0, bsrc, bsrc + PB);   // (first pass: C = 0, nothing to clear)
       {
         F16Frag t[1];
         load_a16<1>(t, nx + lane, 0); a0 = t[0];
@@ -500,7 +497,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         F16Frag t[1];
         load_a16<1>(t, nx + 128 + lane, 0); a1 = t[0];
       }
-    }
+    };
+    kpass(0, std::true_type{});
+#pragma unroll 1
+    for (int ks = 2; ks < NKS; ks += 2) kpass(ks, std::false_type{});
     G16_PH(4);                                               // [4] matrix phase
 
 #ifndef WEKWS_G16_CACHE_AT_TOP

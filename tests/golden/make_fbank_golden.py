@@ -22,7 +22,7 @@ def main():
     out = {}
     for case in FBANK_CASES:
         pcm = fbank_input(case)
-        feats = np.stack([fbank_oracle.ref_fbank(p, case["num_bins"], 16000, case["first_push"]) for p in pcm])
+        feats = np.stack([fbank_oracle.ref_fbank(p, case["num_bins"], case["sample_rate"], case["first_push"]) for p in pcm])
         out[case["name"]] = feats.astype(np.float32)
         out[case["name"] + "/xsum"] = np.float64(np.abs(pcm.astype(np.float64)).sum())
         print(f"{case['name']:28s} {feats.shape} [{feats.min():.4f}, {feats.max():.4f}]")

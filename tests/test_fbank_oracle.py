@@ -20,7 +20,8 @@ def fgolden():
 def test_oracle_matches_golden(case, fgolden):
     pcm = fbank_input(case)
     assert abs(np.abs(pcm.astype(np.float64)).sum() - float(fgolden[case["name"] + "/xsum"])) < 1e-6
-    got = np.stack([fbank_oracle.fbank(p, case["num_bins"]) for p in pcm])
+    sr = case["sample_rate"]
+    got = np.stack([fbank_oracle.fbank(p, case["num_bins"], sr, sr // 1000 * 25, sr // 1000 * 10) for p in pcm])
     ref = fgolden[case["name"]]
     assert got.shape == ref.shape
     # same algorithm, same float32 operation order: bit-exact on this toolchain; allow 1 ulp-ish slack for libm

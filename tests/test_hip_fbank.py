@@ -29,11 +29,11 @@ def fgolden():
 @pytest.mark.parametrize("case", FBANK_CASES, ids=[c["name"] for c in FBANK_CASES])
 def test_golden(case, fgolden):
     pcm = fbank_input(case)
-    fb = Fbank(num_bins=case["num_bins"])
+    fb = Fbank(num_bins=case["num_bins"], sample_rate=case["sample_rate"])   # (8 / 4 kHz: the reference's 256- / 128-point cases)
     got = fb(torch.from_numpy(pcm).cuda()).cpu().numpy()
     ref = fgolden[case["name"]]
     assert got.shape == ref.shape
-    assert float(np.abs(got - ref).max()) <= (TOL if case["num_bins"] == 40 else TOL80)
+    assert float(np.abs(got - ref).max()) <= (TOL80 if case["num_bins"] == 80 else TOL)
 
 
 def test_batch_1024_vs_oracle_sample():
@@ -68,12 +68,15 @@ def test_int16_input_equals_widened_float_input():
         assert a.shape == b.shape and np.array_equal(a, b)
 
 
-def test_short_frames_are_refused():
-    """frame_length <= 256 samples would need the reference's 256-point FFT (fbank.h:43), which is not built: the
-    library says so instead of computing other features."""
+def test_very_short_frames_are_refused():
+    """Frames of 65 .. 512 samples are served (the reference's 128- / 256- / 512-point FFT cases: the golden cases above
+    include 8 kHz and 4 kHz audio); 64 samples or fewer have no recipe and no mel-slot layout: the library says so instead
+    of computing other features."""
     from wekws_amd import _capi
-    with pytest.raises(_capi.HipLibraryError, match="512-point"):
-        Fbank(40, sample_rate=8000)          # 25 ms at 8 kHz = 200 samples
+    with pytest.raises(_capi.HipLibraryError, match="65 .. 512"):
+        Fbank(23, sample_rate=2000)          # 25 ms at 2 kHz = 50 samples
+    with pytest.raises(_capi.HipLibraryError):
+        Fbank(40, frame_length=600)
 
 
 def test_80_bin_tolerance_end_to_end(error_report):

@@ -36,7 +36,7 @@
 namespace wekws {
 
 constexpr int kFbankMaxBins = 128;
-constexpr int kFbankMaxFft = 512;   // frame_length in (256, 512] -> 512-point FFT, the only size built
+constexpr int kFbankMaxFft = 512;   // frames of up to 512 samples; the 512-point transform serves the reference's 128 / 256 / 512-point cases
 constexpr int kFbankWaves = 4;      // frames in flight per workgroup
 
 struct FbankParams {
@@ -81,8 +81,15 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
     }
     t.push_back(float(w));
   }
+  // The reference transforms UpperPowerOfTwo(frame_length) points (fbank.h:43,117-119).  The kernel always runs its 512-point
+  // transform on the zero-padded frame: bin k of an Nref-point DFT of a frame of <= Nref samples IS bin k * 512 / Nref of
+  // its 512-point DFT, so shorter frames (8 kHz audio: 200 samples, 256 points) only change WHERE the mel bank looks -- the
+  // filters are computed over the reference's Nref / 2 bins and laid out over every stride-th bin of the 512-point spectrum.
+  int Nref = 64;
+  while (Nref < frame_length) Nref *= 2;
+  const int stride = N / Nref;
   auto mel = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };
-  const float bin_width = float(sample_rate) / N;
+  const float bin_width = float(sample_rate) / Nref;
   const float mel_lo = mel(20.0f), mel_hi = mel(float(sample_rate / 2));
   const float delta = (mel_hi - mel_lo) / (num_bins + 1);
   std::vector<float> first(num_bins), size(num_bins), start(num_bins), weights;
@@ -90,7 +97,7 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
     const float left = mel_lo + b * delta, center = mel_lo + (b + 1) * delta, right = mel_lo + (b + 2) * delta;
     int fi = -1, li = -1;
     std::vector<float> w(NB, 0.f);
-    for (int i = 0; i < NB; ++i) {
+    for (int i = 0; i < Nref / 2; ++i) {
       const float m = mel(bin_width * i);
       if (m > left && m < right) {
         w[i] = (m <= center) ? (m - left) / (center - left) : (right - m) / (right - center);
@@ -99,10 +106,13 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
       }
     }
     if (fi < 0) { fi = 0; li = -1; }  // empty filter (reference CHECK-fails; here it yields the floor)
-    first[b] = float(fi);
-    size[b] = float(li + 1 - fi);
+    first[b] = float(fi * stride);
+    size[b] = float(li >= fi ? (li - fi) * stride + 1 : 0);
     start[b] = float(weights.size());
-    for (int i = fi; i <= li; ++i) weights.push_back(w[i]);
+    for (int i = fi; i <= li; ++i) {
+      weights.push_back(w[i]);
+      if (i < li) weights.insert(weights.end(), size_t(stride - 1), 0.f);   // (the bins between two of the reference's)
+    }
   }
   fp->num_bins = num_bins;
   fp->frame_length = frame_length;

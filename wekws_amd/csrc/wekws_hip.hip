@@ -1386,11 +1386,10 @@ int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip
     return fail(WEKWS_HIP_EINVAL, "fbank cfg out of range");
   if (cfg->window != WEKWS_HIP_WINDOW_HAMMING && cfg->window != WEKWS_HIP_WINDOW_POVEY)
     return fail(WEKWS_HIP_EINVAL, "fbank window %d", cfg->window);
-  if (cfg->frame_length <= wekws::kFbankMaxFft / 2)
-    // the reference pads a frame to UpperPowerOfTwo(frame_length) (fbank.h:43,117-119): 256 points or fewer here, i.e.
-    // other bin widths and mel weights than the 512-point transform this kernel implements
-    return fail(WEKWS_HIP_EUNSUPPORTED, "fbank frame_length %d: only the 512-point FFT (257..512 samples per frame) is built",
-                cfg->frame_length);
+  if (cfg->frame_length <= 64)
+    // (the reference would transform 64 points or fewer; frames that short -- 4 ms at 16 kHz -- have no recipe, and the
+    // mel slots of a 512-point spectrum sampled every 8th bin or sparser are not laid out for it)
+    return fail(WEKWS_HIP_EUNSUPPORTED, "fbank frame_length %d: frames of 65 .. 512 samples are built", cfg->frame_length);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);

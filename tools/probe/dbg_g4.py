@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Development tool: per-block difference of the returned cache between mdtc64_g4 (option g16 = 1) and mdtc64_w16 (g16 = 0):
+the cache slices are the blocks' inputs, so the first differing slice names the block that went wrong.
+    python tools/probe/dbg_g4.py [model] [T]        (PREC=f16 for the fp16 mode)"""
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from wekws_amd import pack
 from wekws_amd.model.kws_model import init_model
 from wekws_amd.utils import synth

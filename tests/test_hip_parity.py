@@ -579,6 +579,29 @@ def test_mdtc_one_utterance_per_workgroup_kernel_equals_16_wave_kernel():
                 assert max_abs(a.posteriors(xt).cpu().numpy(), ya) <= (tol if T <= 16 else 0.0), (name, prec, B, T)
 
 
+def test_register_resident_kernels_at_every_length():
+    """Every T from 1 to 112 (all lane / register boundaries of the lane-major frame layout, slices longer than the input,
+    partial lanes in the cache hand-over) through the register-resident kernels against the LDS-tile kernels (option g16 =
+    0): DS-TCN h256 caches bit for bit (both kernels see the same 16 NT frames), MDTC h64 to rounding noise (its tile is
+    end-aligned: other padding frames, see test_mdtc_one_utterance_per_workgroup_kernel_equals_16_wave_kernel)."""
+    from wekws_amd import pack
+    for name, exact in (("ds_tcn_h256", True), ("mdtc_h64", False)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 81)
+        a = build(cfg, sd).set_option("g16", 1).set_option("stream", 0)
+        b = build(cfg, sd).set_option("g16", 0).set_option("stream", 0)
+        for T in range(1, 113):
+            x = synth.synth_feats(2, T, cfg["input_dim"], seed=1000 + T)
+            ya, ca = run(a, x)
+            yb, cb = run(b, x)
+            if exact:
+                assert np.array_equal(ca, cb), (name, T, max_abs(ca, cb))
+                assert max_abs(ya, yb) <= 5e-7, (name, T, max_abs(ya, yb))
+            else:
+                assert max_abs(ca, cb) <= 3e-6 * max(1.0, float(np.abs(cb).max())), (name, T, max_abs(ca, cb))
+                assert max_abs(ya, yb) <= 3e-6, (name, T, max_abs(ya, yb))
+
+
 def test_ds256_matrix_core_depthwise_variant(golden):
     """Option mm = 1 selects the DS-TCN h256 kernel whose depthwise conv also runs on the matrix cores (ds256_mm.hip.h)
     for keyword heads too: same goldens, same tolerance, including streaming and carried caches."""

@@ -144,7 +144,8 @@ def attach_profile(roof, model_name, B, precision):
             roof["traffic"] = rec["traffic_bytes_per_launch"]
             roof["traffic_unit"] = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes: "
                                     "FETCH corrected x2 as MI355X_MICROARCH.md prescribes for gfx950, WRITE as reported "
-                                    "(uncalibrated for partial-line writes)")
+                                    "(calibrated: exact on three store patterns of known size incl. the cache's 28-byte runs, "
+                                    "profiles/r03_write_size_calibration.txt)")
             roof["traffic_source"] = rec.get("profile") or pm.get("profile")
             roof["kernel_avg_ms_rocprof"] = rec.get("kernel_avg_ms")
             return

@@ -8,7 +8,8 @@ ran with (bench.py ignores the file unless it loads that very library).
         tag      the <tag> given to tools/pmc.sh (reads gpurun_out/prof_<tag>_{trace,fetch,write}/)
         profile  the committed text summary of THOSE passes (profiles/rNN..._f16x3.txt): bench.py's traffic_source
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports
-half the bytes of wide coalesced reads; WRITE_SIZE is taken as reported (uncalibrated for partial-line writes).
+half the bytes of wide coalesced reads; WRITE_SIZE is taken as reported -- tools/probe/write_calib.hip: it is exact (KiB) on
+contiguous float4 fills, on the cache's 28-byte dwordx4 + dwordx3 runs and on 4-byte stores of the same rows.
 """
 import glob
 import hashlib

@@ -17,6 +17,9 @@ x = torch.from_numpy(synth.synth_feats(1024, 98, 40, seed=1)).cuda()
 for _ in range(50):
     y, c = m(x)
 torch.cuda.synchronize()
-d = c[0].flatten()[:16].cpu().numpy()
-for role, off in (("wave 0", 0), ("wave 9", 8)):
-    print(role, "(sum over the utterances of workgroup 0; / 4 at B = 1024)", " ".join(f"[{n}]={int(v)}" for n, v in zip(names, d[off:off + 8])), "total", int(d[off:off + 8].sum()))
+d = c[0].flatten()[:128].cpu().numpy().reshape(16, 8)
+print("sums over the utterances of workgroup 0 (/ 4 at B = 1024); columns:", ", ".join(names))
+for w in range(16):
+    print(f"wave {w:2d}", " ".join(f"{int(v):7d}" for v in d[w]), "total", int(d[w].sum()))
+print("max    ", " ".join(f"{int(v):7d}" for v in d.max(0)))
+print("min    ", " ".join(f"{int(v):7d}" for v in d.min(0)))

@@ -20,7 +20,7 @@ x = torch.from_numpy(synth.synth_feats(1024, 98, 40, seed=1)).cuda()
 for _ in range(50):
     y, c = m(x)
 torch.cuda.synchronize()
-d = c[0].flatten()[:16].cpu().numpy()
+d = c[0].flatten()[:128].cpu().numpy().reshape(16, 8)[[0, 9]].flatten()
 for role, off in (("wave 0", 0), ("wave 9", 8)):
     print(role, "(sum over the utterances of workgroup 0)", " ".join(f"[{n}]={int(v)}" for n, v in zip(names, d[off:off + 8])),
           "total", int(d[off:off + 8].sum()))

@@ -40,8 +40,8 @@ namespace wekws {
 #define G16_PH_DUMP                                                                                    \
   do {                                                                                                 \
     __syncthreads();                                                                                   \
-    if (blockIdx.x == 0 && A.out_cache && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 9)) \
-      for (int i = 0; i < 8; ++i) A.out_cache[((threadIdx.x >> 6) ? 8 : 0) + i] = float(tph[i]);          \
+    if (blockIdx.x == 0 && A.out_cache && (threadIdx.x & 63) == 0)                                    \
+      for (int i = 0; i < 8; ++i) A.out_cache[(threadIdx.x >> 6) * 8 + i] = float(tph[i]);               \
   } while (0)
 #else
 #define G16_PH_DECL

@@ -48,6 +48,7 @@ __device__ __forceinline__ void g32_dw_pair(const f32x4 (&hv)[NT], const float* 
   constexpr auto tiles = std::make_integer_sequence<int, NT>{};
   constexpr int RA = 2 * P_, RB = 2 * P_ + 1;
   float oa[NT], ob[NT];
+  __builtin_amdgcn_s_setprio(P_ == 0 ? 3 : 1);               // (a wave that is ahead steps back: ds256_g16.hip.h)
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) { oa[tt] = a2.x; ob[tt] = b2.x; }
   g16_tap_tiles<7 * D, NT, RA>(oa, hv, a0.x, tiles); g16_tap_tiles<7 * D, NT, RB>(ob, hv, b0.x, tiles);
@@ -58,6 +59,7 @@ __device__ __forceinline__ void g32_dw_pair(const f32x4 (&hv)[NT], const float* 
   g16_tap_tiles<2 * D, NT, RA>(oa, hv, a1.y, tiles); g16_tap_tiles<2 * D, NT, RB>(ob, hv, b1.y, tiles);
   g16_tap_tiles<1 * D, NT, RA>(oa, hv, a1.z, tiles); g16_tap_tiles<1 * D, NT, RB>(ob, hv, b1.z, tiles);
   g16_tap_tiles<0, NT, RA>(oa, hv, a1.w, tiles);     g16_tap_tiles<0, NT, RB>(ob, hv, b1.w, tiles);
+  __builtin_amdgcn_s_setprio(P_ == 0 ? 2 : 0);
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
     *reinterpret_cast<float*>(pst + (RA * TT + tt * 16) * 16) = fmaxf(oa[tt], 0.f);
@@ -205,6 +207,12 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
     for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
+      if ((g & 3) == 0) {                                    // (a wave that is ahead steps back: ds256_g16.hip.h)
+        if (g == 0) __builtin_amdgcn_s_setprio(3);
+        else if (g == 4) __builtin_amdgcn_s_setprio(2);
+        else if (g == 8) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       const float4 a = an;
       an = (g + 1 < NG ? ap1 + (g + 1) * 64 : apn)[lane];
       g32_mfma_group<NT>(acc, a, planes + g * PB + frag_off);

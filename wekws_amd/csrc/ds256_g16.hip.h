@@ -493,6 +493,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       // phase one after the other -- all-wave stamps: the oldest is through the matrix phase after 6.9 k cycles, the youngest,
       // alone at the end with nobody to cover its LDS latencies, after 14.1 k, for 10.75 k of matrix pipe; with it 12.7 k
       // (depthwise phase 6.3 k -> 5.8 k).  -1.8 % in time (-5 % in cycles: the clock gives some of it back).
+      // (Chaining the B-fragment requests across K steps -- the last tile of a step requesting the first tile of the next, so
+      // that no step opens with an exposed LDS round trip -- keeps the fragment buffers alive across the weight loads: 36
+      // bytes of scratch, +4 %.  Dropped.)
       if (ks == 0) __builtin_amdgcn_s_setprio(3);
       else if (ks == 2) __builtin_amdgcn_s_setprio(2);
       else if (ks == 4) __builtin_amdgcn_s_setprio(1);

@@ -455,9 +455,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     };
     G16_PH(1);                                               // [1] block top
-#ifdef WEKWS_G16_CACHE_AT_TOP
-    hand_over();
-#endif
 
     // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-109) of this lane's 4 channels x NT frames, from the
     //      registers; scale, split, store as operand planes of K step wave >> 1
@@ -518,9 +515,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     for (int ks = 2; ks < NKS; ks += 2) kpass(ks, std::false_type{});
     G16_PH(4);                                               // [4] matrix phase
 
-#ifndef WEKWS_G16_CACHE_AT_TOP
     hand_over();
-#endif
     G16_PH(6);                                               // [6] cache hand-over
 
     // ---- epilogue: folded bias + ReLU + residual (tcn.py:60: add after the ReLU), registers only

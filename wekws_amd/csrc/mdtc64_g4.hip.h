@@ -295,19 +295,12 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     // ---- depthwise dilated conv + folded BN (mdtc.py:55-58, no ReLU), scaled, split, to the operand planes
     {
       const float* taps_o0 = &taps[bi & 1][0] + o0 * 8;
-#ifdef G4_DBG_NOP
-      asm volatile("s_nop 7\n\ts_nop 7");
-#endif
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
         case 1: g4_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
         case 2: g4_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
         case 4: g4_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-#ifdef G4_DBG_ORIG
-        default: g4_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-#else
         case 8: g4_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        default: break;
-#endif
+        default: break;                                      // (d = 8 as the `default` arm came out wrong in this kernel: DESIGN.md 3.1a)
       }
     }
     __syncthreads();                                         // (B1) the depthwise planes are written

@@ -55,8 +55,9 @@ def _slice(x, starts, ends, axes=None, steps=None):
     return x[tuple(idx)]
 
 
-def run(graph, feeds):
-    """feeds: {'input': (1,T,idim) f32, 'cache': ...} -> dict of every graph output."""
+def run(graph, feeds, also=()):
+    """feeds: {'input': (1,T,idim) f32, 'cache': ...} -> dict of every graph output (+ the intermediate values named
+    in `also`, e.g. the logits one node before the final Sigmoid)."""
     v = dict(graph.init)
     v.update({k: np.asarray(a) for k, a in feeds.items()})
     v[""] = None
@@ -128,4 +129,4 @@ def run(graph, feeds):
         else:
             raise NotImplementedError("operator %s (node %s)" % (op, n.name))
         v[n.outputs[0]] = o
-    return {k: v[k] for k in graph.outputs}
+    return {k: v[k] for k in list(graph.outputs) + list(also)}

@@ -78,8 +78,16 @@ def test_invalid_descriptors_are_rejected_with_a_message():
     assert "floats" in _capi.last_error() and not h
     # unsupported shapes -> EUNSUPPORTED, loudly (hidden sizes up to 256 and kernel sizes up to the built one run zero-padded
     # since round 3: what is left to refuse is beyond them)
+    mdtc = synth.MODEL_CONFIGS["mdtc_h64"]
     for cfg2, word in ((dict(cfg, hidden_dim=320), "hidden_dim"),
-                       (dict(cfg, backbone=dict(cfg["backbone"], kernel_size=9)), "kernel_size")):
+                       (dict(cfg, backbone=dict(cfg["backbone"], kernel_size=9)), "kernel_size"),
+                       # an odd width AND a kernel size above the built one: the padding path must refuse it too (round-3
+                       # advisor finding: (96, 9) passed the gate and pad_conv_shape overwrote neighbouring taps)
+                       (dict(cfg, hidden_dim=96, backbone=dict(cfg["backbone"], kernel_size=9)), "kernel_size"),
+                       (dict(cfg, hidden_dim=96, backbone=dict(cfg["backbone"], kernel_size=12)), "kernel_size"),
+                       (dict(mdtc, hidden_dim=48, backbone=dict(mdtc["backbone"], hidden_dim=48, kernel_size=7)), "kernel_size"),
+                       # MDTC between 129 and 255 channels: refused under the caller's own hidden_dim
+                       (dict(mdtc, hidden_dim=160, backbone=dict(mdtc["backbone"], hidden_dim=160)), "hidden_dim 160")):
         desc2, blob2 = pack.pack(cfg2, synth.synth_state_dict(pack.model_spec(cfg2), 1))
         d2 = _capi.make_desc(desc2)
         assert lib.wekws_hip_create(C.byref(d2), blob2.ctypes.data, blob2.size, 0, C.byref(h)) == -4

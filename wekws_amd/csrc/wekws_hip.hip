@@ -774,6 +774,12 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       // built shape, zero-padded -- exact, see pad_conv_shape
       const int Cp = !odd_c ? C : C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
       if (C > 256) return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for up to 256 channels", C);
+      // padding only ever ADDS zero taps: a kernel size above the built one cannot be served (pad_conv_shape would write
+      // ks floats into a ks_built-wide slot)
+      if (ks > ks_built)
+        return fail(WEKWS_HIP_EUNSUPPORTED, "kernel_size %d: this backbone's kernel is built for up to %d", ks, ks_built);
+      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && Cp > 128)
+        return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim %d: the LDS tile holds up to 128 channels", C);
       if (n_blocks(d) > wekws::kAmaxMaxBlocks)
         return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks with a padded shape: the cache maps hold %d", n_blocks(d), wekws::kAmaxMaxBlocks);
       if (odd_c && d.head == WEKWS_HIP_HEAD_IDENTITY)

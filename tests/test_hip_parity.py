@@ -1015,3 +1015,71 @@ def test_reserve_covers_every_smaller_shape():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), (B, T)
+
+
+def _gru_cfg(layers):
+    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"])
+    cfg["backbone"] = dict(cfg["backbone"], num_layers=layers)
+    return cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers", [1, 2, 3, 4])
+def test_gru_wavefront_equals_layer_major(layers, error_report):
+    """gru_pipe.hip.h runs the layers of torch.nn.GRU (kws_model.py:128-133) as pipeline stages on different CUs, handing
+    sequences over through the workspace inside ONE launch.  Same instructions per column as the layer-major kernels
+    (option gru_pipe = 0): bit-identical posteriors and states -- for one stream, partial tiles, time-packed tiles (<= 8
+    streams), more tiles than resident slots (several rounds per workgroup), T = 1 .. 3 (shorter than the look-ahead), with
+    and without an incoming state, called back to back (the progress words must be zero again after every launch), and
+    streamed in chunks.  And against the oracle, so that the pair cannot be wrong together."""
+    from wekws_amd import pack
+    cfg = _gru_cfg(layers)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 4242 + layers)
+    # (option 2: the wavefront also where the default falls back to the layer-major kernels -- more tiles than slots)
+    pipe, major = build(cfg, sd).set_option("gru_pipe", 2), build(cfg, sd).set_option("gru_pipe", 0)
+    rng = np.random.default_rng(7)
+    slots = 256 // (2 * layers)
+    shapes = [(1, 10), (1, 1), (3, 2), (5, 3), (16, 7), (19, 40), (8 * slots, 12), (8 * slots + 1, 12), (16 * slots, 21),
+              (16 * slots + 17, 9), (48 * slots + 5, 6), (2, 150)]
+    for rep, (B, T) in enumerate(shapes):
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=50 + rep)
+        h0 = None if rep % 3 == 0 else (rng.standard_normal((layers, B, 128)) * (0.5 if rep % 3 == 1 else 3.0)).astype(np.float32)
+        y1, c1 = run(pipe, x, h0)
+        y0, c0 = run(major, x, h0)
+        assert np.isfinite(y1).all()
+        assert np.array_equal(y1, y0) and np.array_equal(c1, c0), (layers, B, T, max_abs(y1, y0), max_abs(c1, c0))
+        y2, c2 = run(pipe, x, h0)                              # again: no state left behind
+        assert np.array_equal(y2, y1) and np.array_equal(c2, c1), (layers, B, T)
+        if B <= 64:
+            ry, rc = kws_oracle.forward(cfg, sd, x, h0)
+            error_report[f"gru_pipe/L{layers}/B{B}_T{T}"] = max_abs(y1, ry)
+            assert max_abs(y1, ry) <= POSTERIOR_TOL and max_abs(c1, rc) <= tol_for(rc)
+    x = synth.synth_feats(33, 47, cfg["input_dim"], seed=99)
+    ys, cs = run(pipe, x, chunks=[10, 10, 10, 10, 7])
+    yo, co = run(pipe, x)
+    assert max_abs(ys, yo) <= 2e-5 and max_abs(cs, co) <= 2e-5
+    ym, cm = run(major, x, chunks=[10, 10, 10, 10, 7])
+    assert np.array_equal(ys, ym) and np.array_equal(cs, cm)
+
+
+@pytest.mark.gpu
+def test_gru_wavefront_under_uneven_load():
+    """The hand-over must not depend on timing: the same call while another stream keeps part of the GPU busy with a
+    long-running kernel of another model, many times, every word compared."""
+    from wekws_amd import pack
+    cfg = _gru_cfg(2)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 4244)
+    pipe, major = build(cfg, sd).set_option("gru_pipe", 2), build(cfg, sd).set_option("gru_pipe", 0)
+    cfg2 = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    other = build(cfg2, synth.synth_state_dict(pack.model_spec(cfg2), 1))
+    xo = torch.from_numpy(synth.synth_feats(700, 98, 40, seed=1)).cuda()
+    x = torch.from_numpy(synth.synth_feats(301, 30, 40, seed=2)).cuda()
+    y0, c0 = major(x)
+    side = torch.cuda.Stream()
+    for it in range(20):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                other(xo)
+        y1, c1 = pipe(x)
+        assert torch.equal(y1, y0) and torch.equal(c1, c0), it
+    torch.cuda.synchronize()

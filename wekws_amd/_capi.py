@@ -62,7 +62,7 @@ SIGNATURES = {
                                    C.c_void_p]),
 }
 
-OPTIONS = {"w16": 0, "mdtc16": 1, "stream": 2, "mm": 3, "head_slices": 4, "g16": 5, "envelope": 6}   # enum wekws_hip_option
+OPTIONS = {"w16": 0, "mdtc16": 1, "stream": 2, "mm": 3, "head_slices": 4, "g16": 5, "envelope": 6, "gru_pipe": 7}   # enum wekws_hip_option
 
 _lib: Optional[C.CDLL] = None
 

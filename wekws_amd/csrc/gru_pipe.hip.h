@@ -1,0 +1,821 @@
+// GRU forward as a WAVEFRONT over the layers: one launch, the passes of gru_f16.hip.h as pipeline STAGES on different CUs.
+// Reference semantics as gru.hip.h (torch.nn.GRU as built at wekws/model/kws_model.py:128-133; LinearSubsampling1
+// subsampling.py:53-57; LinearClassifier classifier.py:63-67); arithmetic, operand values and block floating point exactly
+// those of gru_f16.hip.h -- every column sees the same instructions in the same order, so the results are bit-identical.
+//
+// gru_f16.hip.h walks the network layer by layer: P, I0, R0, I1, R1, H.  Only the recurrences R are serial in time, but they
+// ran one after the other (L x T layer-steps of ~1.1 us on 16 streams per CU) while most CUs idled.  Layer l's step t only
+// needs layer l-1's step t, so here a tile of streams is worked on by 2 L workgroups AT THE SAME TIME:
+//
+//   stage 0        PI    in0[t] = [ReLU](Wpre x[t] + b);  gi0[t] = W_ih0 in0[t] + b      (no recurrence: runs ahead)
+//   stage 2 l + 1  R_l   h_l[t] = cell(gi_l[t], h_l[t-1])                                (the serial chain; last layer: + head)
+//   stage 2 l      I_l   gi_l[t] = W_ih,l h_{l-1}[t] + b     (l >= 1)                    (per step, behind R_{l-1})
+//
+// so the chain is T + (a few steps of lag) instead of L T, each stage keeps ITS matrices in registers for the whole launch, and
+// a workgroup (= one CU: 8 waves x up to 256 registers) serves several tiles one after the other ("rounds") when there are
+// more tiles than CUs / (2 L) ("slots").
+//
+// Hand-over between the workgroups of a slot (MI355X: a CU's L1 never sees other CUs' stores, per-XCD L2s are not coherent
+// with each other, and a write-through store is acknowledged only after 1.5 .. 2 us under load -- measured: a version with
+// progress flags behind `s_waitcnt vmcnt(0)` spent more time waiting for acknowledgements than computing):
+//   * everything that crosses workgroups travels as 8-byte GRANULES {32 data bits, 32-bit tag}, two per 16-byte sc1
+//     (write-through) buffer store, read with sc1 loads (L2-served, never a stale L1 line).  The data IS the flag: a consumer
+//     requests a step's granules ahead of time, checks the tags when it needs the values (one v_min3_u32 per two tags: tags
+//     only grow, so min == tag means all equal) and re-requests until they are there.  Nobody waits for a store to complete,
+//     there is no fence, no flag and no poll on the fast path, and a producer never waits for its consumer inside a round.
+//   * where the stores go: a workgroup announces the XCD it runs on (HW_REG_XCC_ID) in a control word; a producer that finds its
+//     consumer on ITS OWN XCD within a few microseconds stores with the default policy -- the two share one L2, which then
+//     has the data when the store is acknowledged (~0.4 us), and the consumer's L2-served loads see it --; otherwise (other
+//     XCD, or the consumer not resident yet) it stores write-through.  vmcnt is ONE in-order counter for loads and stores,
+//     so whatever a wave requests behind its own stores waits for their acknowledgement: with write-through stores the
+//     recurrence's step became the acknowledgement latency.  (Observed placement: block b runs on XCD b % 8, so with the
+//     slots padded to a multiple of 8 a slot's stages share an XCD; nothing relies on it.)
+//   * tag = (launch epoch + 1) + round.  The epoch is a word in the workspace that the LAST workgroup to finish advances by
+//     the launch's rounds (one relaxed agent-scope counter) -- nothing depends on a per-launch kernel argument, so a captured
+//     graph replays correctly.  Granule buffers hold nothing but granules (every odd dword is a tag written by some launch, or
+//     the zero the allocation was cleared to; tags start at 1), so a stale or foreign word cannot pass for the current tag.
+//   * granule buffers are per slot and round parity; before round r >= 2 a producer checks ONE acknowledgement word (the tag of
+//     the last round its consumer has finished reading) -- once per ~100 us.
+// No deadlock: producers have lower workgroup indices than their consumers and the grid is at most one workgroup per CU, so
+// whenever a consumer is resident its producers are resident or done (in-order dispatch); every spin is bounded anyway
+// (error word; the kernel then terminates with garbage instead of hanging the GPU).
+#pragma once
+#include "gru_f16.hip.h"
+
+namespace wekws {
+
+constexpr int kGruPipeStages = 2 * kGruMaxLayers;
+constexpr int kGruPipeMaxSlots = 128;
+// control words (their own allocation per stream, zero when made, never re-allocated): [0] epoch, [1] workgroups done, [2] error,
+// [16 + slot * stages + stage] acknowledgements,
+// [16 + (slots + slot) * stages + stage] where the workgroup runs: tag0 << 4 | XCD
+constexpr int kGruPipeCtlWords = 16 + 2 * kGruPipeMaxSlots * kGruPipeStages;
+constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
+constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
+constexpr int kGruPipeGiStep = 8 * 3 * 2 * 1024;              // bytes of one step of gate granules: [wave][gate][half][lane][16]
+constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
+
+struct GruPipeWorkspace {
+  unsigned* ctl;                // control words
+  char* seq_in;                 // [slot][T] time-packed tiles only: preprocessing output planes (stage 0 internal)
+  char* seq_top;                // [slot][T] last layer's output planes (read back by its own workgroup's head pass)
+  float* sc;                    // [slot][T][16] time-packed tiles only: 1 / scale of the preprocessing output
+  char* gi[kGruMaxLayers];      // granules [region][T][kGruPipeGiStep]: gate pre-activations of layer l
+  char* hs[kGruMaxLayers];      // granules [region][T][kGruPipeHStep]: output sequence of layer l (l < L - 1)
+};
+
+// measurement build (tools/probe/gru_stamps.py): 100 MHz wall-clock stamps of slot 0's stages, row k, step t
+#ifdef WEKWS_GRU_PIPE_STAMPS
+__device__ unsigned long long gp_stamps[16 * 1024];
+#define GP_STAMP(k, t) do { if (slot == 0 && tid == 0 && (t) < 1024) gp_stamps[(k) * 1024 + (t)] = wall_clock64(); } while (0)
+#else
+#define GP_STAMP(k, t) do {} while (0)
+#endif
+
+typedef unsigned gp_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGpSc1 = 16;                                    // buffer aux bit: sc1 (write-through store / L2-served load)
+
+__device__ __forceinline__ unsigned gp_min3(unsigned a, unsigned b, unsigned c) { return min(a, min(b, c)); }
+__device__ __forceinline__ unsigned gp_ld_ctl(const unsigned* p) {
+  return unsigned(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+}
+// Barrier of the per-step loops: orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0)` + s_barrier on
+// this target (the workgroup-scope fence covers global memory): every step then waited for the gate values requested two
+// steps ahead AND for the acknowledgement of the step's own stores.  Nothing in these loops hands global data to another
+// wave of the workgroup.
+__device__ __forceinline__ void gp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Granule loads the compiler does not count: hipcc merges its vmcnt bookkeeping at loop headers and ends up with
+// `s_waitcnt vmcnt(0)` in front of every tag check -- the step then waits for the OTHER buffer's requests and for its own
+// stores.  These loads are inline assembly (invisible to that bookkeeping; its own waits only get more conservative), and
+// the wait in front of their first use is spelled out: vmcnt is one in-order counter, so "at most the N newest requests
+// outstanding" is exact.  The wait statement names every destination as read-write, so nothing touches them before it.
+typedef unsigned gp_desc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gp_desc gp_make_desc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  return gp_desc{unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(a)))),
+                 unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(a >> 32) & 0xffffu))),
+                 unsigned(__builtin_amdgcn_readfirstlane(int(bytes))), 0x00020000u};
+}
+// six 16-byte items at voff + {0, 1, 2, 3, 4, 5} KiB
+__device__ __forceinline__ void gp_ld6(gp_u32x4 (&g)[6], int voff, gp_desc rs) {
+  const int voff2 = voff + 4096;
+  asm volatile(
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %6, %8, 0 offen sc1\n\t"
+      "buffer_load_dwordx4 %1, %6, %8, 0 offen offset:1024 sc1\n\t"
+      "buffer_load_dwordx4 %2, %6, %8, 0 offen offset:2048 sc1\n\t"
+      "buffer_load_dwordx4 %3, %6, %8, 0 offen offset:3072 sc1\n\t"
+      "buffer_load_dwordx4 %4, %7, %8, 0 offen sc1\n\t"
+      "buffer_load_dwordx4 %5, %7, %8, 0 offen offset:1024 sc1"
+      : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5])
+      : "v"(voff), "v"(voff2), "s"(rs)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gp_wait6(gp_u32x4 (&g)[6]) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]) : "i"(N) : "memory");
+}
+// two 16-byte items at voff, voff + 16
+__device__ __forceinline__ void gp_ld2(gp_u32x4 (&g)[2], int voff, gp_desc rs) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\t"
+      "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1"
+      : "=&v"(g[0]), "=&v"(g[1])
+      : "v"(voff), "s"(rs)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gp_wait2(gp_u32x4 (&g)[2]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g[0]), "+v"(g[1]) : "i"(N) : "memory");
+}
+// 16-byte store: default policy (the consumer shares this XCD's L2) or write-through
+__device__ __forceinline__ void gp_st16(gp_u32x4 v, __amdgpu_buffer_rsrc_t rs, int off, bool same_xcd) {
+  if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, kGpSc1);
+}
+// two granules {a, tag}, {b, tag}
+__device__ __forceinline__ gp_u32x4 gp_pair(unsigned a, unsigned b, unsigned tag) { return gp_u32x4{a, tag, b, tag}; }
+
+template <int NKP>                                            // K steps of the preprocessing product (idim <= 32 NKP)
+__global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q, const GruPipeWorkspace WS,
+                                                            const float* __restrict__ x, int B, int T,
+                                                            const float* __restrict__ h0, float* __restrict__ y,
+                                                            float* __restrict__ hn, int tiles, int slots, int slots_p,
+                                                            int spw) {
+  constexpr int NN = 1;
+  using G = GruF16Geom<NN>;
+  constexpr int MB = G::MB, H = kGruH, PH = G::PLANE_H;
+  constexpr int KSB = 4 * MB * 16;                            // bytes per K step inside a plane
+  constexpr int OTS = (H / 32) * 128;                         // uint4 per o-tile of an H-deep matrix (4 K steps)
+  constexpr int SEQ = G::SEQ_STEP, GIS = kGruPipeGiStep, HSS = kGruPipeHStep;
+  const GruParams& P = Q.base;
+  extern __shared__ __attribute__((aligned(16))) char gp_lds[];
+
+  const int stage = blockIdx.x / slots_p, slot = blockIdx.x - stage * slots_p;
+  if (slot >= slots) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const float* __restrict__ W = P.w;
+  const int L = P.nlayers, K = P.odim, idim = P.idim;
+  const int u0 = wave * 16 + lq * 4;                        // first of this lane's 4 hidden units
+  const int frag = (lq * MB + l15) * 16;                    // this lane's B-fragment item of stream tile 0, K step 0
+  const int wr_off = (((u0 >> 3) * MB + l15) * 8 + (u0 & 7)) * 2;   // this lane's 4 units inside an H-wide plane
+  const int gvo = wave * 6144 + lane * 16;                  // this lane's first gate granule pair inside a step (+ (2 g + half) * 1024)
+  const int rounds = (tiles + slots - 1) / slots;
+  unsigned* const ctl = WS.ctl;
+  unsigned* const ack_out = ctl + 16 + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
+  const unsigned* const ack_in = ctl + 16 + slot * kGruPipeStages + stage;                    // what its consumer has finished reading
+  const unsigned tag0 = gp_ld_ctl(ctl) + 1u;                // tag of round 0
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  unsigned* const where = ctl + 16 + (kGruPipeMaxSlots + slot) * kGruPipeStages;   // [stage] of this slot
+  if (tid == 0) __hip_atomic_store(where + stage, (tag0 << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // does this stage's consumer run on this XCD?  asked after the weights have been requested; gives up after ~20 us (the
+  // consumer may not be resident yet: write-through stores are right wherever it turns up)
+  auto consumer_here = [&]() __attribute__((always_inline)) -> bool {
+    for (int i = 0; i < 48; ++i) {
+      const unsigned w = gp_ld_ctl(where + stage + 1);
+      if ((w >> 4) == (tag0 & 0x0fffffffu)) return (w & 15u) == xcc;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+  };
+
+  __shared__ AmaxCell gp_cell;
+  // bound of layer l's hidden state over a stream tile: max(1, max|h0[l]|) (gru_f16.hip.h); all threads, three barriers
+  auto h_bound = [&](int l, int b0, int bend) __attribute__((always_inline)) -> float {
+    __syncthreads();
+    if (tid == 0) gp_cell.v = 0u;
+    __syncthreads();
+    float m = 0.f;
+    if (h0)
+      for (int e = tid; e < MB * H; e += kThreads) {
+        const int sidx = b0 + e / H;
+        if (sidx < bend) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
+      }
+    amax_publish(&gp_cell, m);
+    __syncthreads();
+    return fmaxf(1.f, amax_read(&gp_cell));
+  };
+  // before writing round r >= 2 into the region of round r - 2: the consumer must have finished that round
+  auto wait_ack = [&](int r) __attribute__((always_inline)) {
+    if (r < 2) return;
+    const unsigned need = tag0 + unsigned(r) - 2u;
+    unsigned spins = 0;
+    while (int(gp_ld_ctl(ack_in) - need) < 0) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x200u + unsigned(stage); break; }
+    }
+  };
+  auto finish = [&]() __attribute__((always_inline)) {
+    // the last workgroup to finish advances the epoch by the tags this launch used
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned nwg = unsigned(2 * L * slots);
+      if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1u) {
+        __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl, tag0 - 1u + unsigned(rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+
+  if (stage == 0) {
+    // ============ stage PI: in0[t] = [ReLU](Wpre x[t] + b) (subsampling.py:53-57), gi0[t] = W_ih0 in0[t] + b ============
+    F16Frag a[NKP];
+    {
+      const int nkp = Q.kpre16 / 32;                          // K steps the packed matrix really has (<= NKP: the launcher)
+      const uint4* ap = reinterpret_cast<const uint4*>(W + Q.pre_a16) + size_t(wave) * nkp * 128 + lane;
+#pragma unroll
+      for (int ks = 0; ks < NKP; ++ks) {
+        a[ks].h = a[ks].l = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ks < nkp) a[ks] = load_frag(ap + ks * 128);
+      }
+    }
+    const f32x4 bpre = *reinterpret_cast<const f32x4*>(W + P.pre_b + u0);
+    const GruLayer gl = P.layer[0];
+    F16Frag wi[3][4];
+    {
+      const uint4* aih = reinterpret_cast<const uint4*>(W + Q.a_ih16[0]) + lane;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wi[g][ks] = load_frag(aih + (g * 8 + wave) * OTS + ks * 128);
+    }
+    f32x4 bias[3];
+    bias[0] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + u0);
+    bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
+    bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
+    const bool xvec = (idim % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    const float ih_inv = Q.ih_inv_s[0];
+    const bool near = consumer_here();
+    GP_STAMP(15, stage);
+    GP_STAMP(14, near ? 100 + stage : 200 + stage);
+
+    int round = 0;
+#pragma unroll 1
+    for (int tile = slot; tile < tiles; tile += slots, ++round) {
+      const int b0 = tile * spw, bend = min(B, b0 + spw), nb = bend - b0;
+      const unsigned tag = tag0 + unsigned(round);
+      const int reg = (round & 1) * slots + slot;
+      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[0] + size_t(reg) * T * GIS, 0, T * GIS, 0x00020000);
+      wait_ack(round);
+      // this lane's 8 features of K step ks of (stream s, step t); zeros outside
+      auto load_x8 = [&](int s, int t, int ks, bool ok) __attribute__((always_inline)) -> gru_f32x8 {
+        gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int k0 = ks * 32 + lq * 8;
+        if (ok && k0 < idim) {
+          const float* src = x + (int64_t(s) * T + t) * idim + k0;
+          if (xvec && k0 + 8 <= idim) {
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+            v = gru_f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (k0 + j < idim) v[j] = src[j];
+          }
+        }
+        return v;
+      };
+      const bool packed = nb <= 8;
+      if (packed) {
+        // TIME-PACKED tile (gru_f16.hip.h): the 16 MFMA columns are (step, stream) pairs; P for all steps into the workspace
+        // (this workgroup's own stores and loads), then I0
+        const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;
+        const int TP = 16 >> psh;
+        const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
+        char* const seq0 = WS.seq_in + size_t(slot) * T * SEQ;
+        float* const sc = WS.sc + size_t(slot) * T * 16;
+        for (int t0 = 0; t0 < T; t0 += TP) {
+          const int t = t0 + pdt;
+          const bool cv = t < T && pcs < nb;                    // this column exists
+          gru_f32x8 xr[NKP];
+          float ax = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks) {
+            xr[ks] = load_x8(b0 + pcs, t, ks, cv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xr[ks][j]));
+          }
+          ax = fmaxf(ax, __shfl_xor(ax, 16));
+          ax = fmaxf(ax, __shfl_xor(ax, 32));
+          float cx, inv_s0;
+          const float sx = pow2_scale(ax, &cx);
+          const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+          cx *= Q.pre_inv_s;
+          if (wave == 0 && lq == 0 && cv) sc[t * 16 + pcs] = inv_s0;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NKP; ++ks) {
+            const gru_f32x8 xs = xr[ks] * sx;
+            const f16x8 bh = __builtin_convertvector(xs, f16x8);
+            const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
+            gru_mfma1(acc, a[ks], bh, bl);
+          }
+          f32x4 v = acc * cx + bpre;
+          if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+          f16x4 vh, vl;
+          gru_split4(v * s0, vh, vl);
+          if (cv) {
+            char* dst = seq0 + size_t(t) * SEQ + (((u0 >> 3) * MB + pcs) * 8 + (u0 & 7)) * 2;
+            *reinterpret_cast<f16x4*>(dst) = vh;
+            *reinterpret_cast<f16x4*>(dst + PH) = vl;
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int t0 = 0; t0 < T; t0 += TP) {
+          const int t = t0 + pdt, tc = min(t, T - 1);
+          const bool cv = t < T && pcs < nb;
+          const char* p = seq0 + size_t(tc) * SEQ + (lq * MB + pcs) * 16;   // this column's fragment, K step 0
+          f32x4 acc[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
+          }
+          const float cin = sc[tc * 16 + pcs] * ih_inv;
+          if (cv) {                                             // into the slot the recurrence's lane (stream pcs, same lq) reads
+            const int vo = t * GIS + wave * 6144 + (lq * 16 + pcs) * 16;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+              const f32x4 v = acc[g] * cin + bias[g];
+              gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
+              gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
+            }
+          }
+        }
+      } else {
+        // CS steps at a time through LDS staging buffers (operand planes): while I0 multiplies chunk c, P makes chunk c + 1 in
+        // the other buffer -- one barrier per chunk
+        constexpr int CS = G::CS, CHUNK = CS * SEQ;
+        // the features of chunk c + 1 are requested in front of I0(c): the requests are then OLDER than I0's stores in the
+        // wave's in-order memory queue, and P(c + 1) does not wait for those stores' acknowledgements
+        gru_f32x8 xr[CS][NKP];
+        const int sx_ = b0 + l15;
+        auto x_chunk = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < NKP; ++ks) xr[dt][ks] = load_x8(sx_, t0 + dt, ks, sx_ < bend && t0 + dt < T);
+        };
+        x_chunk(0);
+        float inv_c[CS], inv_n[CS];
+#pragma unroll
+        for (int dt = 0; dt < CS; ++dt) inv_n[dt] = 1.f;
+        auto p_chunk = [&](int t0, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt) {
+            const int t = t0 + dt;
+            inv[dt] = 1.f;
+            if (t < T) {
+              float ax = 0.f;                                   // max|x[t]| over the tile: every wave holds the whole step
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xr[dt][ks][j]));
+              ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
+              float cx, inv_s0;
+              const float sx = pow2_scale(ax, &cx);
+              const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+              cx *= Q.pre_inv_s;
+              inv[dt] = inv_s0;
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks) {
+                const gru_f32x8 xs = xr[dt][ks] * sx;
+                const f16x8 bh = __builtin_convertvector(xs, f16x8);
+                const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
+                gru_mfma1(acc, a[ks], bh, bl);
+              }
+              f32x4 v = acc * cx + bpre;
+              if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+              f16x4 vh, vl;
+              gru_split4(v * s0, vh, vl);
+              char* dst = buf + dt * SEQ + wr_off;
+              *reinterpret_cast<f16x4*>(dst) = vh;
+              *reinterpret_cast<f16x4*>(dst + PH) = vl;
+            }
+          }
+        };
+        GP_STAMP(0, 0);
+        p_chunk(0, gp_lds, inv_c);
+        gp_barrier();
+        for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
+          const char* const buf = gp_lds + (c & 1) * CHUNK;
+          GP_STAMP(1, t0);
+          if (t0 + CS < T) x_chunk(t0 + CS);
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt) {
+            const int t = t0 + dt;
+            if (t < T) {
+              f32x4 acc[3];
+#pragma unroll
+              for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+              const char* p = buf + dt * SEQ + frag;
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
+              }
+              const float cin = inv_c[dt] * ih_inv;
+              const int vo = t * GIS + gvo;
+#pragma unroll
+              for (int g = 0; g < 3; ++g) {
+                const f32x4 v = acc[g] * cin + bias[g];
+                gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
+                gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
+              }
+            }
+          }
+          GP_STAMP(2, t0);
+          if (t0 + CS < T) p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
+          gp_barrier();
+        }
+      }
+      __syncthreads();                                        // (staging buffers free for the next tile)
+    }
+    finish();
+    return;
+  }
+
+  const int l = stage >> 1;
+  if (stage & 1) {
+    // ============================ stage R_l: the recurrence of layer l (last layer: + head) ============================
+    const GruLayer gl = P.layer[l];
+    const bool last = l == L - 1;
+    F16Frag wh[3][4];
+    {
+      const uint4* ahh = reinterpret_cast<const uint4*>(W + Q.a_hh16[l]) + lane;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wh[g][ks] = load_frag(ahh + (g * 8 + wave) * OTS + ks * 128);
+    }
+    const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
+    const bool near = !last && consumer_here();
+    GP_STAMP(15, stage);
+    GP_STAMP(14, near ? 100 + stage : 200 + stage);
+
+    int round = 0;
+#pragma unroll 1
+    for (int tile = slot; tile < tiles; tile += slots, ++round) {
+      const int b0 = tile * spw, bend = min(B, b0 + spw), nb = bend - b0;
+      const unsigned tag = tag0 + unsigned(round);
+      const int reg = (round & 1) * slots + slot;
+      const float hb = h_bound(l, b0, bend);
+      float chh;
+      const float shl = pow2_scale(hb, &chh);
+      chh *= Q.hh_inv_s[l];
+      char* const sout = WS.seq_top + size_t(slot) * T * SEQ;
+      const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(WS.hs[last ? 0 : l] + size_t(last ? 0 : reg) * T * HSS, 0, last ? 0 : T * HSS, 0x00020000);
+      if (!last) wait_ack(round);
+      f32x4 hreg;
+      {
+        const int s = b0 + l15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h0 && s < bend) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
+        hreg = v;
+        f16x4 vh, vl;
+        gru_split4(v * shl, vh, vl);
+        char* dst = gp_lds + wr_off;
+        *reinterpret_cast<f16x4*>(dst) = vh;
+        *reinterpret_cast<f16x4*>(dst + PH) = vl;
+      }
+      // gate pre-activations of this lane as granule pairs [gate][half], requested two steps ahead into two buffers that
+      // take turns (no copies: whatever is requested behind this wave's stores returns behind their acknowledgement)
+      gp_u32x4 ga[6], gb[6];
+      const gp_desc ds_g = gp_make_desc(WS.gi[l] + size_t(reg) * T * GIS, unsigned(T) * GIS);
+      auto load_g = [&](gp_u32x4 (&gg)[6], int t) __attribute__((always_inline)) { gp_ld6(gg, min(t, T - 1) * GIS + gvo, ds_g); };
+      // a time-packed first stage writes the columns of real streams only: the other lanes' granules never arrive
+      const bool live = l > 0 || nb > 8 || l15 < nb;
+      auto tags_ok = [&](const gp_u32x4 (&gg)[6]) __attribute__((always_inline)) -> bool {
+        unsigned m = gp_min3(gg[0][1], gg[0][3], gg[1][1]);
+        m = gp_min3(m, gg[1][3], gg[2][1]);
+        m = gp_min3(m, gg[2][3], gg[3][1]);
+        m = gp_min3(m, gg[3][3], gg[4][1]);
+        m = gp_min3(m, gg[4][3], gg[5][1]);
+        m = min(m, gg[5][3]);
+        return !__builtin_amdgcn_ballot_w64(live && m != tag);   // tags only grow: min == tag <=> all == tag
+      };
+      load_g(ga, 0);
+      load_g(gb, 1);
+      __syncthreads();
+      unsigned spins = 0;
+      auto step = [&](int t, gp_u32x4 (&g0)[6]) __attribute__((always_inline)) {
+        GP_STAMP(4 * l + 3, t);
+        const char* hbp = gp_lds + (t & 1) * 2 * PH + frag;           // image of h(t-1)
+        char* const hw = gp_lds + ((t + 1) & 1) * 2 * PH;             // image of h(t)
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f16x8 hh = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
+          const f16x8 hl = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wh[g][ks], hh, hl);
+        }
+        GP_STAMP(4 * l + 4, t);
+        // This step's gate values were requested at the end of step t - 2; behind them this wave has issued the stores of
+        // step t - 1 and six more requests (step t + 1; past the end, the last step again) -- which alone may still be out.
+        // ONE wait statement for every step: two (vmcnt(6) / vmcnt(0) in the arms of a branch) made the compiler COPY the
+        // registers -- before the wait, i.e. before the data had landed -- on the last step (wrong h_n in one tile in ~20).
+        gp_wait6<6>(g0);
+        // are they there?  (upstream runs ahead: normally yes)
+        if (!tags_ok(g0)) {
+          do {
+            __builtin_amdgcn_s_sleep(2);
+            load_g(g0, t);
+            gp_wait6<0>(g0);
+            if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
+          } while (!tags_ok(g0));
+        }
+        GP_STAMP(4 * l + 5, t);
+        // cell math, register-local (PyTorch formulation, gate order r, z, n)
+        f32x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gr = __uint_as_float(g0[0 + (r >> 1)][(r & 1) * 2]);
+          const float gz = __uint_as_float(g0[2 + (r >> 1)][(r & 1) * 2]);
+          const float gn = __uint_as_float(g0[4 + (r >> 1)][(r & 1) * 2]);
+          const float rg = gru_sigmoid(fmaf(acc[0][r], chh, gr));
+          const float zg = gru_sigmoid(fmaf(acc[1][r], chh, gz));
+          const float ng = gru_tanh(gn + rg * fmaf(acc[2][r], chh, b_hn[r]));
+          hv[r] = ng + zg * (hreg[r] - ng);                     // (1 - z) n + z h
+        }
+        hreg = hv;
+        f16x4 vh, vl;
+        gru_split4(hv * shl, vh, vl);
+        {
+          char* dst = hw + wr_off;
+          *reinterpret_cast<f16x4*>(dst) = vh;
+          *reinterpret_cast<f16x4*>(dst + PH) = vl;
+        }
+        if (last) {                                             // read back by this workgroup's own head pass
+          char* gd = sout + size_t(t) * SEQ + wr_off;
+          *reinterpret_cast<f16x4*>(gd) = vh;
+          *reinterpret_cast<f16x4*>(gd + PH) = vl;
+        } else {                                                // four state granules {hi | lo << 16, tag}
+          const gp_u32x4 hl4 = __builtin_bit_cast(gp_u32x4, __builtin_shufflevector(vh, vl, 0, 1, 2, 3, 4, 5, 6, 7));
+          const unsigned p0 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x05040100u), p1 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x07060302u);
+          const unsigned p2 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x05040100u), p3 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x07060302u);
+          const int vo = t * HSS + (((u0 >> 3) * 16 + l15) * 8 + (u0 & 7)) * 8;
+          gp_st16(gp_pair(p0, p1, tag), rs_o, vo, near);
+          gp_st16(gp_pair(p2, p3, tag), rs_o, vo + 16, near);
+        }
+        load_g(g0, t + 2);   // (clamped to the last step: every step has six requests behind its own)
+        gp_barrier();      // h(t) is complete and every wave is done with h(t-1)
+      };
+      for (int t = 0; t < T; t += 2) {
+        step(t, ga);
+        if (t + 1 < T) step(t + 1, gb);
+      }
+      gp_wait6<0>(ga);     // nothing of this tile may still be on its way into registers
+      gp_wait6<0>(gb);
+      if (hn) {
+        const int s = b0 + l15;
+        if (s < bend) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg;
+      }
+      // every gate value of this round has been read
+      if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last) {
+        // ================= head: y[t] = [sigmoid](Wc h_top[t] + bc), waves take steps round-robin =================
+        __threadfence_block();
+        __syncthreads();
+        const bool packed = nb <= 8;
+        const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;
+        const int TP = 16 >> psh;
+        const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
+        const int head_tiles = (K + 15) / 16;
+        float chd;
+        (void)pow2_scale(hb, &chd);
+        chd *= Q.head_inv_s;
+        for (int ot = 0; ot < head_tiles; ++ot) {
+          const uint4* ahd = reinterpret_cast<const uint4*>(W + Q.head_a16) + size_t(ot) * OTS + lane;
+          F16Frag a[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) a[ks] = load_frag(ahd + ks * 128);
+          const int k0 = ot * 16 + lq * 4;
+          f32x4 bc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + r < K) bc[r] = W[P.head_b + k0 + r];
+          if (packed) {
+            for (int t0 = wave * TP; t0 < T; t0 += (kThreads / 64) * TP) {
+              const int t = t0 + pdt, tc = min(t, T - 1);
+              const bool cv = t < T && pcs < nb;
+              const char* p = sout + size_t(tc) * SEQ + (lq * MB + pcs) * 16;
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+                gru_mfma1(acc, a[ks], bh, bl);
+              }
+              if (cv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (k0 + r < K) {
+                    float v = fmaf(acc[r], chd, bc[r]);
+                    if (P.sigmoid) v = sigmoidf_(v);
+                    y[(int64_t(b0 + pcs) * T + t) * K + k0 + r] = v;
+                  }
+              }
+            }
+            continue;
+          }
+          for (int t = wave; t < T; t += kThreads / 64) {
+            const char* p = sout + size_t(t) * SEQ + frag;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+              const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+              gru_mfma1(acc, a[ks], bh, bl);
+            }
+            const int s = b0 + l15;
+            if (s < bend) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (k0 + r < K) {
+                  float v = fmaf(acc[r], chd, bc[r]);
+                  if (P.sigmoid) v = sigmoidf_(v);
+                  y[(int64_t(s) * T + t) * K + k0 + r] = v;
+                }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // ===================== stage I_l (l >= 1): gi_l[t] = W_ih,l h_{l-1}[t] + b, every wave on its own =====================
+    const GruLayer gl = P.layer[l];
+    F16Frag wi[3][4];
+    {
+      const uint4* aih = reinterpret_cast<const uint4*>(W + Q.a_ih16[l]) + lane;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wi[g][ks] = load_frag(aih + (g * 8 + wave) * OTS + ks * 128);
+    }
+    f32x4 bias[3];
+    bias[0] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + u0);
+    bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
+    bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
+    const bool near = consumer_here();
+    GP_STAMP(15, stage);
+    GP_STAMP(14, near ? 100 + stage : 200 + stage);
+
+    int round = 0;
+#pragma unroll 1
+    for (int tile = slot; tile < tiles; tile += slots, ++round) {
+      const int b0 = tile * spw, bend = min(B, b0 + spw);
+      const unsigned tag = tag0 + unsigned(round);
+      const int reg = (round & 1) * slots + slot;
+      float inv_in;
+      (void)pow2_scale(h_bound(l - 1, b0, bend), &inv_in);    // scale of the previous layer's planes
+      const float cin = inv_in * Q.ih_inv_s[l];
+      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[l] + size_t(reg) * T * GIS, 0, T * GIS, 0x00020000);
+      wait_ack(round);
+      // One step of the previous layer's state is 16 KB of granules; EVERY wave needs all of it as its B operand.  Eight waves
+      // pulling it through the CU's 64 B/clk vector-memory path was 128 KB per step (measured: ~0.9 us of the stage's step), so
+      // each wave fetches ONE EIGHTH -- k-octets 2 w and 2 w + 1: lane = (octet, stream, half), four granules = 32 bytes --,
+      // checks its tags, and writes the values as fp16 hi / lo operand planes into LDS (two buffers taking turns, the layout
+      // of the recurrence's own state image); one barrier per step, then every wave reads its fragments from LDS.
+      const int po = 2 * wave + (lane >> 5), ps = (lane >> 1) & 15, phf = lane & 1;
+      const int pvo = (po * 16 + ps) * 64 + phf * 32;         // this lane's 32 bytes inside a step of granules
+      const int pwr = ((po * MB + ps) * 8 + phf * 4) * 2;     // ... and its 4 halves inside a plane
+      gp_u32x4 raw[2];
+      const gp_desc ds_i = gp_make_desc(WS.hs[l - 1] + size_t(reg) * T * HSS, unsigned(T) * HSS);
+      auto load_h = [&](int t) __attribute__((always_inline)) { gp_ld2(raw, t * HSS + pvo, ds_i); };
+      unsigned spins = 0;
+      // waits until this wave's share of step t is there, then writes it into plane buffer `buf`; `behind` = this wave has
+      // issued the step's six gate stores behind the request (they may stay out)
+      auto take = [&](int t, char* buf, bool behind) __attribute__((always_inline)) {
+        if (behind) gp_wait2<6>(raw);
+        else gp_wait2<0>(raw);
+        if (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag)) {
+          do {
+            __builtin_amdgcn_s_sleep(2);
+            load_h(t);
+            gp_wait2<0>(raw);
+            if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
+          } while (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag));
+        }
+        gp_u32x4 hl;                                            // granule data: hi | lo << 16 of one unit
+        hl[0] = __builtin_amdgcn_perm(raw[0][2], raw[0][0], 0x05040100u);
+        hl[1] = __builtin_amdgcn_perm(raw[1][2], raw[1][0], 0x05040100u);
+        hl[2] = __builtin_amdgcn_perm(raw[0][2], raw[0][0], 0x07060302u);
+        hl[3] = __builtin_amdgcn_perm(raw[1][2], raw[1][0], 0x07060302u);
+        *reinterpret_cast<unsigned long long*>(buf + pwr) = (unsigned long long)hl[0] | ((unsigned long long)hl[1] << 32);
+        *reinterpret_cast<unsigned long long*>(buf + PH + pwr) = (unsigned long long)hl[2] | ((unsigned long long)hl[3] << 32);
+      };
+      load_h(0);
+      take(0, gp_lds, false);
+      if (T > 1) load_h(1);
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        GP_STAMP(11, t);
+        const char* p = gp_lds + (t & 1) * 2 * PH + frag;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+          const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
+        }
+        GP_STAMP(12, t);
+        const int vo = t * GIS + gvo;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const f32x4 v = acc[g] * cin + bias[g];
+          gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
+          gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
+        }
+        if (t + 1 < T) {
+          take(t + 1, gp_lds + ((t + 1) & 1) * 2 * PH, true);
+          if (t + 2 < T) load_h(t + 2);                       // in flight behind the next step's products
+        }
+        GP_STAMP(13, t);
+        gp_barrier();                                         // the planes of step t + 1 are complete; those of step t are free
+      }
+      __syncthreads();                                        // every wave has read the whole round
+      if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  finish();
+}
+
+// ---- geometry of one call: stream slots per workgroup, tiles, resident slots ----
+struct GruPipeGeom {
+  int stages, spw, tiles, slots, slots_p, regions;
+};
+inline bool gru_pipe_geom(int nlayers, int B, int T, int cus, GruPipeGeom* g) {
+  g->stages = 2 * nlayers;
+  int smax = cus / g->stages;
+  smax = smax > kGruPipeMaxSlots ? kGruPipeMaxSlots : smax;
+  if (smax < 1 || nlayers > kGruMaxLayers) return false;
+  // streaming chunks (T <= 16): fewer streams per tile while every tile still gets its own slot -- a workgroup's time does
+  // not depend on how many of its 16 MFMA columns are real, and tiles of <= 8 streams run the first stage time-packed (all
+  // steps in one or two MFMA tiles).  Longer inputs: full tiles -- a time-packed first stage makes ALL steps before the
+  // recurrence sees the first one (measured at B = 256 x 98 frames: 0.67x of the layer-major kernels)
+  int spw = T <= 16 ? 1 : 16;
+  while (spw < 16 && (B + spw - 1) / spw > smax) spw *= 2;
+  g->spw = spw;
+  g->tiles = (B + spw - 1) / spw;
+  g->slots = g->tiles < smax ? g->tiles : smax;
+  g->slots_p = (g->slots + 7) / 8 * 8;                       // block b runs on XCD b % 8: a slot's stages share an XCD
+  g->regions = g->tiles > g->slots ? 2 * g->slots : g->slots;
+  return true;
+}
+// bytes of one call: the plain workspace behind the control words (seq_in, seq_top, sc: each per slot) and the granule
+// workspace (gi per layer, state granules per layer below the top: each per region)
+struct GruPipeBytes {
+  size_t seq, sc, gi, hs;
+  size_t plain() const { return 2 * seq + sc; }
+  size_t granules(int nlayers) const { return size_t(nlayers) * gi + size_t(nlayers - 1) * hs; }
+};
+inline bool gru_pipe_bytes(int nlayers, int B, int T, int cus, GruPipeBytes* b) {
+  GruPipeGeom g;
+  if (!gru_pipe_geom(nlayers, B, T, cus, &g)) return false;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  b->seq = al(size_t(g.slots) * T * GruF16Geom<1>::SEQ_STEP);
+  b->sc = al(size_t(g.slots) * T * 16 * sizeof(float));
+  b->gi = al(size_t(g.regions) * T * kGruPipeGiStep);
+  b->hs = al(size_t(g.regions) * T * kGruPipeHStep);
+  return true;
+}
+// one region of one buffer must stay below 2 GiB (32-bit buffer offsets)
+inline bool gru_pipe_supported(const GruF16Params& Q, int T) {
+  return gru_f16_supported(Q) && size_t(T) * kGruPipeGiStep < (size_t(1) << 31);
+}
+
+inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, const float* x, int B, int T, const float* h0,
+                           float* y, float* hn, int cus, hipStream_t stream) {
+  if (!gru_pipe_supported(Q, T)) return -4;
+  GruPipeGeom g;
+  if (!gru_pipe_geom(Q.base.nlayers, B, T, cus, &g)) return -4;
+  using G = GruF16Geom<1>;
+  static DynLdsGrant grant2, grant4;
+  const bool k2 = Q.kpre16 <= 64;
+  auto kern = k2 ? gru_pipe_kernel<2> : gru_pipe_kernel<4>;
+  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), k2 ? grant2 : grant4)) return -3;
+  hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn,
+                     g.tiles, g.slots, g.slots_p, g.spw);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace wekws

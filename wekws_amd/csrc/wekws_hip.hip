@@ -30,6 +30,7 @@
 #include "fsmn_f16.hip.h"
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
+#include "gru_pipe.hip.h"
 #include "mfcc.hip.h"
 #include "splice.hip.h"
 #include "topk.hip.h"
@@ -190,6 +191,10 @@ struct StreamBuf {
   hipStream_t stream;
   char* ptr;
   size_t bytes;
+  char* gran = nullptr;         // GRU wavefront: the granule buffer (gru_pipe.hip.h) -- holds nothing but {data, tag} granules
+  size_t gran_bytes = 0;
+  unsigned* ctl = nullptr;      // ... and its control words (launch epoch, acknowledgements): allocated ONCE per stream and never
+                                // re-allocated -- tags must keep growing for as long as any granule buffer of the stream lives
 };
 
 bool desc_conv(const wekws_hip_desc& d) {
@@ -310,6 +315,7 @@ struct wekws_hip_model {
   bool w16_ok = true;     // DS-TCN h256: the 16-wave kernel (WEKWS_HIP_OPT_W16 = 0: the generic 8-wave one)
   float spread_log2 = 0.f;  // Image::spread_log2 of the weights this model was created from
   bool out_of_envelope = false;  // DEFAULT / F16X3 request, but the weights are outside the split-fp16 envelope ...
+  int gru_pipe = 1;       // GRU: 1 the layer wavefront (gru_pipe.hip.h) when every tile of streams gets its own slot, 2 always, 0 never
   bool auto_f32 = false;  // ... and therefore the F32 kernels run (WEKWS_HIP_OPT_ENVELOPE = 0 keeps the split-fp16 kernels)
   bool g16_ok = true;     // ... calls without an incoming cache: the register-resident kernel (ds256_g16.hip.h; WEKWS_HIP_OPT_G16 = 0: ds256_w16)
   bool g16_one_pass = false;   // ... with a grid of B workgroups instead of persistent ones (option value 2: A/B measurements)
@@ -334,12 +340,14 @@ struct wekws_hip_model {
 };
 
 // -> device pointer to at least `need` bytes owned by (model, stream); nullptr + error text on failure
-static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need) {
+static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need, bool granules = false) {
   std::lock_guard<std::mutex> lk(m->ws_mu);
   StreamBuf* sb = nullptr;
   for (auto& e : m->ws) if (e.stream == stream) sb = &e;
-  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->ws.back(); }
-  if (sb->bytes < need) {
+  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0, nullptr, 0, nullptr}); sb = &m->ws.back(); }
+  char*& ptr = granules ? sb->gran : sb->ptr;
+  size_t& bytes = granules ? sb->gran_bytes : sb->bytes;
+  if (bytes < need) {
     // Growing frees the old buffer behind a stream synchronisation -- which a stream that is being captured into a HIP
     // graph cannot do: such a call fails and names wekws_hip_reserve (no hidden synchronisation inside a capture).
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -348,20 +356,50 @@ static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t nee
                              "wekws_hip_reserve(model, B, T, stream) before the capture begins", need);
       return nullptr;
     }
-    if (sb->ptr) {
+    if (ptr) {
       (void)hipStreamSynchronize(stream);                     // earlier calls on this stream may still use the old buffer
-      (void)hipFree(sb->ptr);
-      sb->ptr = nullptr; sb->bytes = 0;
+      (void)hipFree(ptr);
+      ptr = nullptr; bytes = 0;
     }
-    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&sb->ptr), need);
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), need);
     if (e != hipSuccess) {
-      sb->ptr = nullptr;
+      ptr = nullptr;
       fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "workspace of %zu bytes: %s", need, hipGetErrorString(e));
       return nullptr;
     }
-    sb->bytes = need;
+    bytes = need;
+    // GRU wavefront (gru_pipe.hip.h): a granule buffer must never show a word that was not written as a tag -- it is
+    // cleared once, here (tags start at 1 and only grow: the epoch lives in StreamBuf::ctl, which is never re-allocated)
+    if (granules && hipMemsetAsync(ptr, 0, need, stream) != hipSuccess) {
+      fail(WEKWS_HIP_EDEVICE, "workspace: hipMemsetAsync");
+      return nullptr;
+    }
   }
-  return sb->ptr;
+  return ptr;
+}
+
+// The control words of a stream's GRU wavefront launches (gru_pipe.hip.h): one small allocation per (model, stream), made
+// on the first call (or by wekws_hip_reserve) and kept until the stream's workspace is released.
+static unsigned* stream_ctl(wekws_hip_model* m, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(m->ws_mu);
+  StreamBuf* sb = nullptr;
+  for (auto& e : m->ws) if (e.stream == stream) sb = &e;
+  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0, nullptr, 0, nullptr}); sb = &m->ws.back(); }
+  if (!sb->ctl) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      fail(WEKWS_HIP_EINVAL, "first GRU call on a stream that is being captured: call wekws_hip_reserve(model, B, T, stream) before the capture begins");
+      return nullptr;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&sb->ctl), wekws::kGruPipeCtlBytes) != hipSuccess ||
+        hipMemsetAsync(sb->ctl, 0, wekws::kGruPipeCtlBytes, stream) != hipSuccess) {
+      if (sb->ctl) (void)hipFree(sb->ctl);
+      sb->ctl = nullptr;
+      fail(WEKWS_HIP_ENOMEM, "GRU control words");
+      return nullptr;
+    }
+  }
+  return sb->ctl;
 }
 
 struct wekws_hip_fbank {
@@ -592,6 +630,25 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_e
 
 // Scratch bytes one wekws_hip_forward(m, B, T) takes from its stream's workspace (0: none) -- the single source for the
 // forward paths below and for wekws_hip_reserve.
+// GRU: does a call of T frames run the layer wavefront (gru_pipe.hip.h)?
+static bool gru_pipe_call(const wekws_hip_model* m, int B, int T) {
+  const wekws_hip_desc& d = m->desc;
+  if (!(d.backbone == WEKWS_HIP_BACKBONE_GRU && m->gru_pipe && d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32 &&
+        wekws::gru_pipe_supported(m->gq, T)))
+    return false;
+  wekws::GruPipeGeom g;
+  if (!wekws::gru_pipe_geom(d.num_layers, B, T, m->fsmn_cus, &g)) return false;
+  // more tiles than resident slots: every workgroup serves several tiles one after the other, and the layer-major kernels
+  // (all CUs on every pass) are faster -- measured 0.6 .. 0.75x at B = 4096 .. 16384; option value 2 runs the wavefront anyway
+  return g.tiles <= g.slots || m->gru_pipe == 2;
+}
+// ... and the bytes of its granule buffer (a second per-stream buffer that holds nothing else)
+static size_t granule_need(const wekws_hip_model* m, int B, int T) {
+  if (B <= 0 || T <= 0 || !gru_pipe_call(m, B, T)) return 0;
+  wekws::GruPipeBytes pb{};
+  if (!wekws::gru_pipe_bytes(m->desc.num_layers, B, T, m->fsmn_cus, &pb)) return 0;
+  return pb.granules(m->desc.num_layers);
+}
 static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
   const wekws_hip_desc& d = m->desc;
   if (B <= 0 || T <= 0) return 0;
@@ -605,6 +662,11 @@ static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
     const size_t padded = m->user_hdim ? 2 * size_t(d.num_layers) * B * d.hdim * sizeof(float) : 0;
     if (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq)) return padded;
     size_t seq_b = 0, gi_b = 0, sc_b = 0;
+    if (gru_pipe_call(m, B, T)) {                            // seq_in, seq_top | sc
+      wekws::GruPipeBytes pb{};
+      wekws::gru_pipe_bytes(d.num_layers, B, T, m->fsmn_cus, &pb);
+      return pb.plain() + padded;
+    }
     wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
     return 2 * ((seq_b + 255) / 256 * 256) + (gi_b + 255) / 256 * 256 + (sc_b + 255) / 256 * 256 + padded;
   }
@@ -745,6 +807,12 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
 
 extern "C" {
 
+#ifdef WEKWS_GRU_PIPE_STAMPS
+// measurement build only (tools/probe/gru_stamps.py): the wall-clock stamps gru_pipe_kernel left behind
+int wekws_hip_debug_gru_stamps(unsigned long long* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wekws::gp_stamps), size_t(n) * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 const char* wekws_hip_last_error(void) { return g_err.c_str(); }
 int wekws_hip_abi_version(void) { return WEKWS_HIP_ABI_VERSION; }
 
@@ -1105,7 +1173,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
-  for (auto& e : m->ws) if (e.ptr) (void)hipFree(e.ptr);
+  for (auto& e : m->ws) { if (e.ptr) (void)hipFree(e.ptr); if (e.gran) (void)hipFree(e.gran); if (e.ctl) (void)hipFree(e.ctl); }
   delete m;
 }
 
@@ -1158,42 +1226,55 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
     case WEKWS_HIP_OPT_HEAD_SLICES: m->fsmn_slices = value; break;
     case WEKWS_HIP_OPT_G16: m->g16_ok = value != 0; m->g16_one_pass = value == 2; break;   // (2: one workgroup per utterance, a measurement aid)
     case WEKWS_HIP_OPT_ENVELOPE: m->auto_f32 = m->out_of_envelope && value != 0; break;
+    case WEKWS_HIP_OPT_GRU_PIPE: m->gru_pipe = value < 0 ? 1 : value > 2 ? 2 : value; break;
     default: return fail(WEKWS_HIP_EINVAL, "unknown option %d", option);
   }
   return WEKWS_HIP_OK;
 }
 
-size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T) { return m ? workspace_need(m, B, T) : 0; }
+size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T) { return m ? workspace_need(m, B, T) + granule_need(m, B, T) : 0; }
 
 // What a reservation for "calls of up to (B, T)" has to hold: workspace_need() is not monotonic -- a GRU chunk of <= 16
 // frames spreads its streams over more, smaller workgroups (gru_f16_spw), so (256, 10) needs more scratch than (256, 20)
 // and (128, 10) as much as (256, 10) -- so the maximum over the shapes where the geometry changes is taken: the frame
 // counts {T, min(T, 16)} and the stream counts B, the packed-workgroup boundaries 2^k x (workgroups) below B, and the
 // two-tiles-per-workgroup threshold.
-static size_t reserve_need(const wekws_hip_model* m, int B, int T) {
-  size_t need = 0;
+static void reserve_need(const wekws_hip_model* m, int B, int T, size_t* plain, size_t* gran) {
+  *plain = *gran = 0;
   const int ts[2] = {T, T < 16 ? T : 16};
-  int bs[8], nb = 0;
+  int bs[12], nb = 0;
   bs[nb++] = B;
   const int wgs = m->fsmn_cus < wekws::kGruMaxPackedWgs ? m->fsmn_cus : wekws::kGruMaxPackedWgs;
   for (int k = 1; k <= 16; k *= 2)
     if (k * wgs < B) bs[nb++] = k * wgs;
   if (16 * 256 < B) bs[nb++] = 16 * 256;
+  if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) {
+    // the wavefront's geometry (gru_pipe_geom): most slots with one stream per tile, most regions beyond 16 streams x slots
+    wekws::GruPipeGeom g;
+    if (wekws::gru_pipe_geom(m->desc.num_layers, 1 << 30, 1, m->fsmn_cus, &g)) {
+      if (g.slots < B) bs[nb++] = g.slots;
+      if (16 * g.slots + 1 <= B) bs[nb++] = 16 * g.slots + 1;
+    }
+  }
   for (int i = 0; i < nb; ++i)
     for (int j = 0; j < 2; ++j) {
-      const size_t n = workspace_need(m, bs[i], ts[j]);
-      need = n > need ? n : need;
+      const size_t n = workspace_need(m, bs[i], ts[j]), g = granule_need(m, bs[i], ts[j]);
+      *plain = n > *plain ? n : *plain;
+      *gran = g > *gran ? g : *gran;
     }
-  return need;
 }
 
 int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream_) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
-  const size_t need = reserve_need(m, B, T);
-  if (!need) return WEKWS_HIP_OK;
+  size_t need = 0, gran = 0;
+  reserve_need(m, B, T, &need, &gran);
+  if (!need && !gran) return WEKWS_HIP_OK;
   DeviceGuard guard(m->device);
   if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
-  return stream_workspace(m, static_cast<hipStream_t>(stream_), need) ? WEKWS_HIP_OK : WEKWS_HIP_ENOMEM;
+  if (need && !stream_workspace(m, static_cast<hipStream_t>(stream_), need)) return WEKWS_HIP_ENOMEM;
+  if (gran && !stream_workspace(m, static_cast<hipStream_t>(stream_), gran, true)) return WEKWS_HIP_ENOMEM;
+  if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU && m->gru_pipe && !stream_ctl(m, static_cast<hipStream_t>(stream_))) return WEKWS_HIP_ENOMEM;
+  return WEKWS_HIP_OK;
 }
 
 int wekws_hip_release(wekws_hip_model* m, void* stream_) {
@@ -1203,9 +1284,11 @@ int wekws_hip_release(wekws_hip_model* m, void* stream_) {
   std::lock_guard<std::mutex> lk(m->ws_mu);
   for (size_t i = 0; i < m->ws.size(); ++i)
     if (m->ws[i].stream == stream) {
-      if (m->ws[i].ptr) {
+      if (m->ws[i].ptr || m->ws[i].gran || m->ws[i].ctl) {
         (void)hipStreamSynchronize(stream);
-        (void)hipFree(m->ws[i].ptr);
+        if (m->ws[i].ptr) (void)hipFree(m->ws[i].ptr);
+        if (m->ws[i].gran) (void)hipFree(m->ws[i].gran);
+        if (m->ws[i].ctl) (void)hipFree(m->ws[i].ctl);
       }
       m->ws.erase(m->ws.begin() + i);
       break;
@@ -1252,13 +1335,29 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       // workspace (layer sequences + gate pre-activations): one grow-only buffer per (model, stream) -- calls on the
       // same stream are ordered by the stream, calls on different streams never share a buffer
       size_t seq_b = 0, gi_b = 0, sc_b = 0;
-      wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
-      const size_t seq_al = (seq_b + 255) / 256 * 256, gi_al = (gi_b + 255) / 256 * 256;
       char* base = stream_workspace(m, stream, workspace_need(m, B, T));
       if (!base) return WEKWS_HIP_ENOMEM;
-      wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al),
-                                reinterpret_cast<float*>(base + 2 * seq_al + gi_al)};
-      rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
+      if (gru_pipe_call(m, B, T)) {
+        wekws::GruPipeBytes pb{};
+        wekws::gru_pipe_bytes(d.num_layers, B, T, m->fsmn_cus, &pb);
+        char* gran = stream_workspace(m, stream, pb.granules(d.num_layers), true);
+        if (!gran) return WEKWS_HIP_ENOMEM;
+        wekws::GruPipeWorkspace ws{};
+        ws.ctl = stream_ctl(m, stream);
+        if (!ws.ctl) return WEKWS_HIP_ENOMEM;
+        ws.seq_in = base;
+        ws.seq_top = ws.seq_in + pb.seq;
+        ws.sc = reinterpret_cast<float*>(ws.seq_top + pb.seq);
+        for (int l = 0; l < d.num_layers; ++l) { ws.gi[l] = gran; gran += pb.gi; }
+        for (int l = 0; l + 1 < d.num_layers; ++l) { ws.hs[l] = gran; gran += pb.hs; }
+        rc = wekws::launch_gru_pipe(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
+      } else {
+        wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
+        const size_t seq_al = (seq_b + 255) / 256 * 256, gi_al = (gi_b + 255) / 256 * 256;
+        wekws::GruF16Workspace ws{{base, base + seq_al}, reinterpret_cast<float*>(base + 2 * seq_al),
+                                  reinterpret_cast<float*>(base + 2 * seq_al + gi_al)};
+        rc = wekws::launch_gru_f16(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
+      }
     } else {
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     }

@@ -462,6 +462,22 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     }
     const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
     const bool near = !last && consumer_here();
+    // Last layer with a keyword-sized head (K <= 16: one o-tile): y(t - 1) = [sigmoid](Wc h(t - 1) + bc) needs exactly the B
+    // fragments of h(t - 1) every wave reads for its recurrent product anyway -- wave t mod 8 adds the head's 12 MFMAs to
+    // step t.  No separate head pass, no copy of the sequence in global memory, no trip to L2 behind the last step.
+    const bool head_in = last && K <= 16;
+    F16Frag ahd[4];
+    f32x4 bc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ahd[ks].h = ahd[ks].l = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (head_in) {
+      const uint4* ap = reinterpret_cast<const uint4*>(W + Q.head_a16) + lane;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ahd[ks] = load_frag(ap + ks * 128);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lq * 4 + r < K) bc[r] = W[P.head_b + lq * 4 + r];
+    }
     GP_STAMP(15, stage);
     GP_STAMP(14, near ? 100 + stage : 200 + stage);
 
@@ -478,6 +494,22 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       char* const sout = WS.seq_top + size_t(slot) * T * SEQ;
       const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(WS.hs[last ? 0 : l] + size_t(last ? 0 : reg) * T * HSS, 0, last ? 0 : T * HSS, 0x00020000);
       if (!last) wait_ack(round);
+      float chd;
+      (void)pow2_scale(hb, &chd);
+      chd *= Q.head_inv_s;
+      // y of one step from its accumulator (this lane: outputs 4 lq .. 4 lq + 3 of stream l15)
+      auto put_y = [&](const f32x4& acc, int t) __attribute__((always_inline)) {
+        const int s = b0 + l15;
+        if (s < bend) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (lq * 4 + r < K) {
+              float v = fmaf(acc[r], chd, bc[r]);
+              if (P.sigmoid) v = sigmoidf_(v);
+              y[(int64_t(s) * T + t) * K + lq * 4 + r] = v;
+            }
+        }
+      };
       f32x4 hreg;
       {
         const int s = b0 + l15;
@@ -517,13 +549,17 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool my_head = head_in && t > 0 && (t & 7) == wave;     // (wave-uniform)
+        f32x4 acch = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const f16x8 hh = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
           const f16x8 hl = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
 #pragma unroll
           for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wh[g][ks], hh, hl);
+          if (my_head) gru_mfma1(acch, ahd[ks], hh, hl);
         }
+        if (my_head) put_y(acch, t - 1);
         GP_STAMP(4 * l + 4, t);
         // This step's gate values were requested at the end of step t - 2; behind them this wave has issued the stores of
         // step t - 1 and six more requests (step t + 1; past the end, the last step again) -- which alone may still be out.
@@ -560,11 +596,11 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           *reinterpret_cast<f16x4*>(dst) = vh;
           *reinterpret_cast<f16x4*>(dst + PH) = vl;
         }
-        if (last) {                                             // read back by this workgroup's own head pass
+        if (last && !head_in) {                                 // read back by this workgroup's own head pass
           char* gd = sout + size_t(t) * SEQ + wr_off;
           *reinterpret_cast<f16x4*>(gd) = vh;
           *reinterpret_cast<f16x4*>(gd + PH) = vl;
-        } else {                                                // four state granules {hi | lo << 16, tag}
+        } else if (!last) {                                     // four state granules {hi | lo << 16, tag}
           const gp_u32x4 hl4 = __builtin_bit_cast(gp_u32x4, __builtin_shufflevector(vh, vl, 0, 1, 2, 3, 4, 5, 6, 7));
           const unsigned p0 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x05040100u), p1 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x07060302u);
           const unsigned p2 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x05040100u), p3 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x07060302u);
@@ -581,13 +617,24 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       }
       gp_wait6<0>(ga);     // nothing of this tile may still be on its way into registers
       gp_wait6<0>(gb);
+      if (head_in && wave == (T & 7)) {                        // y(T - 1) from the image the last step left behind its barrier
+        const char* hbp = gp_lds + (T & 1) * 2 * PH + frag;
+        f32x4 acch = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f16x8 hh = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
+          const f16x8 hl = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
+          gru_mfma1(acch, ahd[ks], hh, hl);
+        }
+        put_y(acch, T - 1);
+      }
       if (hn) {
         const int s = b0 + l15;
         if (s < bend) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg;
       }
       // every gate value of this round has been read
       if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (last) {
+      if (last && !head_in) {
         // ================= head: y[t] = [sigmoid](Wc h_top[t] + bc), waves take steps round-robin =================
         __threadfence_block();
         __syncthreads();
@@ -596,9 +643,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const int TP = 16 >> psh;
         const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
         const int head_tiles = (K + 15) / 16;
-        float chd;
-        (void)pow2_scale(hb, &chd);
-        chd *= Q.head_inv_s;
         for (int ot = 0; ot < head_tiles; ++ot) {
           const uint4* ahd = reinterpret_cast<const uint4*>(W + Q.head_a16) + size_t(ot) * OTS + lane;
           F16Frag a[4];

@@ -18,8 +18,12 @@
 // Hand-over between the workgroups of a slot (MI355X: a CU's L1 never sees other CUs' stores, per-XCD L2s are not coherent
 // with each other, and a write-through store is acknowledged only after 1.5 .. 2 us under load -- measured: a version with
 // progress flags behind `s_waitcnt vmcnt(0)` spent more time waiting for acknowledgements than computing):
-//   * everything that crosses workgroups travels as 8-byte GRANULES {32 data bits, 32-bit tag}, two per 16-byte sc1
-//     (write-through) buffer store, read with sc1 loads (L2-served, never a stale L1 line).  The data IS the flag: a consumer
+//   * everything that crosses workgroups travels as GRANULES that carry a 32-bit tag next to the data, written by 16-byte
+//     buffer stores and read with sc1 loads (L2-served, never a stale L1 line): hidden states as two 8-byte {hi | lo fp16
+//     pair, tag} granules per store, gate pre-activations as one 16-byte {v0, v1, v2, tag} granule per store.  The second form
+//     leans on naturally aligned 16-byte stores and loads being single transactions (tools/probe/tear16.hip: no torn item in
+//     3.9e10 concurrent reads, both store policies); vector stores are ISSUE-bound on this part (~60 cycles per
+//     wave-instruction on a CU), and with 8-byte gate granules the six stores per wave and step were the first stage's time.  The data IS the flag: a consumer
 //     requests a step's granules ahead of time, checks the tags when it needs the values (one v_min3_u32 per two tags: tags
 //     only grow, so min == tag means all equal) and re-requests until they are there.  Nobody waits for a store to complete,
 //     there is no fence, no flag and no poll on the fast path, and a producer never waits for its consumer inside a round.
@@ -52,7 +56,7 @@ constexpr int kGruPipeMaxSlots = 128;
 constexpr int kGruPipeCtlWords = 16 + 2 * kGruPipeMaxSlots * kGruPipeStages;
 constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
 constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
-constexpr int kGruPipeGiStep = 8 * 3 * 2 * 1024;              // bytes of one step of gate granules: [wave][gate][half][lane][16]
+constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
 constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
 
 struct GruPipeWorkspace {
@@ -96,24 +100,21 @@ __device__ __forceinline__ gp_desc gp_make_desc(const void* base, unsigned bytes
                  unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(a >> 32) & 0xffffu))),
                  unsigned(__builtin_amdgcn_readfirstlane(int(bytes))), 0x00020000u};
 }
-// six 16-byte items at voff + {0, 1, 2, 3, 4, 5} KiB
-__device__ __forceinline__ void gp_ld6(gp_u32x4 (&g)[6], int voff, gp_desc rs) {
-  const int voff2 = voff + 4096;
+// four 16-byte items at voff + {0, 1, 2, 3} KiB
+__device__ __forceinline__ void gp_ld4(gp_u32x4 (&g)[4], int voff, gp_desc rs) {
   asm volatile(
       "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %6, %8, 0 offen sc1\n\t"
-      "buffer_load_dwordx4 %1, %6, %8, 0 offen offset:1024 sc1\n\t"
-      "buffer_load_dwordx4 %2, %6, %8, 0 offen offset:2048 sc1\n\t"
-      "buffer_load_dwordx4 %3, %6, %8, 0 offen offset:3072 sc1\n\t"
-      "buffer_load_dwordx4 %4, %7, %8, 0 offen sc1\n\t"
-      "buffer_load_dwordx4 %5, %7, %8, 0 offen offset:1024 sc1"
-      : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5])
-      : "v"(voff), "v"(voff2), "s"(rs)
+      "buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\t"
+      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
+      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\t"
+      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1"
+      : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
+      : "v"(voff), "s"(rs)
       : "memory");
 }
 template <int N>
-__device__ __forceinline__ void gp_wait6(gp_u32x4 (&g)[6]) {
-  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]) : "i"(N) : "memory");
+__device__ __forceinline__ void gp_wait4(gp_u32x4 (&g)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "i"(N) : "memory");
 }
 // two 16-byte items at voff, voff + 16
 __device__ __forceinline__ void gp_ld2(gp_u32x4 (&g)[2], int voff, gp_desc rs) {
@@ -129,10 +130,36 @@ template <int N>
 __device__ __forceinline__ void gp_wait2(gp_u32x4 (&g)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g[0]), "+v"(g[1]) : "i"(N) : "memory");
 }
+// One step of features for this lane (K steps 0 and 1, 2 x 16 bytes each), not counted by the compiler either
+__device__ __forceinline__ void gp_ldx4(f32x4 (&v)[4], const float* p0, const float* p1) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16\n\t"
+      "global_load_dwordx4 %2, %5, off\n\t"
+      "global_load_dwordx4 %3, %5, off offset:16"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+      : "v"(p0), "v"(p1)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gp_waitx16(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], f32x4 (&d)[4]) {
+  asm volatile("s_waitcnt vmcnt(%16)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+               : "i"(N)
+               : "memory");
+}
 // 16-byte store: default policy (the consumer shares this XCD's L2) or write-through
 __device__ __forceinline__ void gp_st16(gp_u32x4 v, __amdgpu_buffer_rsrc_t rs, int off, bool same_xcd) {
   if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
   else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, kGpSc1);
+}
+// the twelve gate values of a lane and step (r0..3, z0..3, n0..3) as four granules {v, v, v, tag} at off + {0, 1, 2, 3} KiB
+__device__ __forceinline__ void gp_st_gates(const f32x4 (&v)[3], unsigned tag, __amdgpu_buffer_rsrc_t rs, int off, bool same_xcd) {
+  gp_st16(gp_u32x4{__float_as_uint(v[0][0]), __float_as_uint(v[0][1]), __float_as_uint(v[0][2]), tag}, rs, off, same_xcd);
+  gp_st16(gp_u32x4{__float_as_uint(v[0][3]), __float_as_uint(v[1][0]), __float_as_uint(v[1][1]), tag}, rs, off + 1024, same_xcd);
+  gp_st16(gp_u32x4{__float_as_uint(v[1][2]), __float_as_uint(v[1][3]), __float_as_uint(v[2][0]), tag}, rs, off + 2048, same_xcd);
+  gp_st16(gp_u32x4{__float_as_uint(v[2][1]), __float_as_uint(v[2][2]), __float_as_uint(v[2][3]), tag}, rs, off + 3072, same_xcd);
 }
 // two granules {a, tag}, {b, tag}
 __device__ __forceinline__ gp_u32x4 gp_pair(unsigned a, unsigned b, unsigned tag) { return gp_u32x4{a, tag, b, tag}; }
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   const int u0 = wave * 16 + lq * 4;                        // first of this lane's 4 hidden units
   const int frag = (lq * MB + l15) * 16;                    // this lane's B-fragment item of stream tile 0, K step 0
   const int wr_off = (((u0 >> 3) * MB + l15) * 8 + (u0 & 7)) * 2;   // this lane's 4 units inside an H-wide plane
-  const int gvo = wave * 6144 + lane * 16;                  // this lane's first gate granule pair inside a step (+ (2 g + half) * 1024)
+  const int gvo = wave * 4096 + lane * 16;                  // this lane's first gate granule inside a step (+ item * 1024)
   const int rounds = (tiles + slots - 1) / slots;
   unsigned* const ctl = WS.ctl;
   unsigned* const ack_out = ctl + 16 + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
@@ -340,13 +367,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           }
           const float cin = sc[tc * 16 + pcs] * ih_inv;
           if (cv) {                                             // into the slot the recurrence's lane (stream pcs, same lq) reads
-            const int vo = t * GIS + wave * 6144 + (lq * 16 + pcs) * 16;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-              const f32x4 v = acc[g] * cin + bias[g];
-              gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
-              gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
-            }
+            const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
+            gp_st_gates(v, tag, rs_g, t * GIS + wave * 4096 + (lq * 16 + pcs) * 16, near);
           }
         }
       } else {
@@ -355,15 +377,43 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         constexpr int CS = G::CS, CHUNK = CS * SEQ;
         // the features of chunk c + 1 are requested in front of I0(c): the requests are then OLDER than I0's stores in the
         // wave's in-order memory queue, and P(c + 1) does not wait for those stores' acknowledgements
-        gru_f32x8 xr[CS][NKP];
         const int sx_ = b0 + l15;
+        // NKP == 2 (the launcher: idim <= 64 in whole octets, 16-byte aligned rows): the requests are inline assembly with a
+        // counted wait -- behind them the wave issues I0's 16 stores, and hipcc's own bookkeeping would wait for those too
+        // (vmcnt(0) at the head of P).  Otherwise: plain loads.
+        static_assert(CS == 4, "gp_waitx16 names four steps");
+        constexpr bool XF = NKP == 2;
+        f32x4 xq[XF ? CS : 1][4];
+        gru_f32x8 xr[XF ? 1 : CS][NKP];
+        const float* xp0 = x + (int64_t(min(sx_, B - 1)) * T) * idim + lq * 8;               // K step 0: features 8 lq ..
+        const float* xp1 = xp0 + ((32 + lq * 8 < idim) ? 32 : 0);                          // K step 1 (clamped when outside)
+        const bool xv0 = sx_ < bend && lq * 8 < idim, xv1 = sx_ < bend && 32 + lq * 8 < idim;
         auto x_chunk = [&](int t0) __attribute__((always_inline)) {
+          if constexpr (XF) {
 #pragma unroll
-          for (int dt = 0; dt < CS; ++dt)
+            for (int dt = 0; dt < CS; ++dt) {
+              const int64_t to = int64_t(min(t0 + dt, T - 1)) * idim;
+              gp_ldx4(xq[dt], xp0 + to, xp1 + to);
+            }
+          } else {
 #pragma unroll
-            for (int ks = 0; ks < NKP; ++ks) xr[dt][ks] = load_x8(sx_, t0 + dt, ks, sx_ < bend && t0 + dt < T);
+            for (int dt = 0; dt < CS; ++dt)
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks) xr[dt][ks] = load_x8(sx_, t0 + dt, ks, sx_ < bend && t0 + dt < T);
+          }
+        };
+        // the features of step t0 + dt, K step ks (zeros where the tile / the utterance / the feature vector ends)
+        auto x_get = [&](int t0, int dt, int ks) __attribute__((always_inline)) -> gru_f32x8 {
+          if constexpr (XF) {
+            const bool ok = t0 + dt < T && (ks ? xv1 : xv0);
+            const f32x4 a = xq[dt][2 * ks], b = xq[dt][2 * ks + 1];
+            return ok ? gru_f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} : gru_f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          } else {
+            return xr[dt][ks];
+          }
         };
         x_chunk(0);
+        if constexpr (XF) gp_waitx16<0>(xq[0], xq[1], xq[2], xq[3]);
         float inv_c[CS], inv_n[CS];
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) inv_n[dt] = 1.f;
@@ -377,7 +427,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
 #pragma unroll
               for (int ks = 0; ks < NKP; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xr[dt][ks][j]));
+                for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(x_get(t0, dt, ks)[j]));
               ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
               float cx, inv_s0;
               const float sx = pow2_scale(ax, &cx);
@@ -387,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
               f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int ks = 0; ks < NKP; ++ks) {
-                const gru_f32x8 xs = xr[dt][ks] * sx;
+                const gru_f32x8 xs = x_get(t0, dt, ks) * sx;
                 const f16x8 bh = __builtin_convertvector(xs, f16x8);
                 const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
                 gru_mfma1(acc, a[ks], bh, bl);
@@ -425,17 +475,16 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
                 for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
               }
               const float cin = inv_c[dt] * ih_inv;
-              const int vo = t * GIS + gvo;
-#pragma unroll
-              for (int g = 0; g < 3; ++g) {
-                const f32x4 v = acc[g] * cin + bias[g];
-                gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
-                gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
-              }
+              const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
+              gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
             }
           }
           GP_STAMP(2, t0);
-          if (t0 + CS < T) p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+          if (t0 + CS < T) {
+            // behind the requests: exactly the 16 stores of a full chunk
+            if constexpr (XF) gp_waitx16<16>(xq[0], xq[1], xq[2], xq[3]);
+            p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+          }
 #pragma unroll
           for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
           gp_barrier();
@@ -524,25 +573,20 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       }
       // gate pre-activations of this lane as granule pairs [gate][half], requested two steps ahead into two buffers that
       // take turns (no copies: whatever is requested behind this wave's stores returns behind their acknowledgement)
-      gp_u32x4 ga[6], gb[6];
+      gp_u32x4 ga[4], gb[4];
       const gp_desc ds_g = gp_make_desc(WS.gi[l] + size_t(reg) * T * GIS, unsigned(T) * GIS);
-      auto load_g = [&](gp_u32x4 (&gg)[6], int t) __attribute__((always_inline)) { gp_ld6(gg, min(t, T - 1) * GIS + gvo, ds_g); };
+      auto load_g = [&](gp_u32x4 (&gg)[4], int t) __attribute__((always_inline)) { gp_ld4(gg, min(t, T - 1) * GIS + gvo, ds_g); };
       // a time-packed first stage writes the columns of real streams only: the other lanes' granules never arrive
       const bool live = l > 0 || nb > 8 || l15 < nb;
-      auto tags_ok = [&](const gp_u32x4 (&gg)[6]) __attribute__((always_inline)) -> bool {
-        unsigned m = gp_min3(gg[0][1], gg[0][3], gg[1][1]);
-        m = gp_min3(m, gg[1][3], gg[2][1]);
-        m = gp_min3(m, gg[2][3], gg[3][1]);
-        m = gp_min3(m, gg[3][3], gg[4][1]);
-        m = gp_min3(m, gg[4][3], gg[5][1]);
-        m = min(m, gg[5][3]);
+      auto tags_ok = [&](const gp_u32x4 (&gg)[4]) __attribute__((always_inline)) -> bool {
+        const unsigned m = min(gp_min3(gg[0][3], gg[1][3], gg[2][3]), gg[3][3]);
         return !__builtin_amdgcn_ballot_w64(live && m != tag);   // tags only grow: min == tag <=> all == tag
       };
       load_g(ga, 0);
       load_g(gb, 1);
       __syncthreads();
       unsigned spins = 0;
-      auto step = [&](int t, gp_u32x4 (&g0)[6]) __attribute__((always_inline)) {
+      auto step = [&](int t, gp_u32x4 (&g0)[4]) __attribute__((always_inline)) {
         GP_STAMP(4 * l + 3, t);
         const char* hbp = gp_lds + (t & 1) * 2 * PH + frag;           // image of h(t-1)
         char* const hw = gp_lds + ((t + 1) & 1) * 2 * PH;             // image of h(t)
@@ -562,16 +606,16 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         if (my_head) put_y(acch, t - 1);
         GP_STAMP(4 * l + 4, t);
         // This step's gate values were requested at the end of step t - 2; behind them this wave has issued the stores of
-        // step t - 1 and six more requests (step t + 1; past the end, the last step again) -- which alone may still be out.
+        // step t - 1 and four more requests (step t + 1; past the end, the last step again) -- which alone may still be out.
         // ONE wait statement for every step: two (vmcnt(6) / vmcnt(0) in the arms of a branch) made the compiler COPY the
         // registers -- before the wait, i.e. before the data had landed -- on the last step (wrong h_n in one tile in ~20).
-        gp_wait6<6>(g0);
+        gp_wait4<4>(g0);
         // are they there?  (upstream runs ahead: normally yes)
         if (!tags_ok(g0)) {
           do {
             __builtin_amdgcn_s_sleep(2);
             load_g(g0, t);
-            gp_wait6<0>(g0);
+            gp_wait4<0>(g0);
             if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
           } while (!tags_ok(g0));
         }
@@ -580,9 +624,9 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         f32x4 hv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float gr = __uint_as_float(g0[0 + (r >> 1)][(r & 1) * 2]);
-          const float gz = __uint_as_float(g0[2 + (r >> 1)][(r & 1) * 2]);
-          const float gn = __uint_as_float(g0[4 + (r >> 1)][(r & 1) * 2]);
+          const float gr = __uint_as_float(g0[r / 3][r % 3]);                 // value i = 4 gate + r sits in granule i / 3
+          const float gz = __uint_as_float(g0[(4 + r) / 3][(4 + r) % 3]);
+          const float gn = __uint_as_float(g0[(8 + r) / 3][(8 + r) % 3]);
           const float rg = gru_sigmoid(fmaf(acc[0][r], chh, gr));
           const float zg = gru_sigmoid(fmaf(acc[1][r], chh, gz));
           const float ng = gru_tanh(gn + rg * fmaf(acc[2][r], chh, b_hn[r]));
@@ -608,15 +652,15 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           gp_st16(gp_pair(p0, p1, tag), rs_o, vo, near);
           gp_st16(gp_pair(p2, p3, tag), rs_o, vo + 16, near);
         }
-        load_g(g0, t + 2);   // (clamped to the last step: every step has six requests behind its own)
+        load_g(g0, t + 2);   // (clamped to the last step: every step has four requests behind its own)
         gp_barrier();      // h(t) is complete and every wave is done with h(t-1)
       };
       for (int t = 0; t < T; t += 2) {
         step(t, ga);
         if (t + 1 < T) step(t + 1, gb);
       }
-      gp_wait6<0>(ga);     // nothing of this tile may still be on its way into registers
-      gp_wait6<0>(gb);
+      gp_wait4<0>(ga);     // nothing of this tile may still be on its way into registers
+      gp_wait4<0>(gb);
       if (head_in && wave == (T & 7)) {                        // y(T - 1) from the image the last step left behind its barrier
         const char* hbp = gp_lds + (T & 1) * 2 * PH + frag;
         f32x4 acch = {0.f, 0.f, 0.f, 0.f};
@@ -744,9 +788,9 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       auto load_h = [&](int t) __attribute__((always_inline)) { gp_ld2(raw, t * HSS + pvo, ds_i); };
       unsigned spins = 0;
       // waits until this wave's share of step t is there, then writes it into plane buffer `buf`; `behind` = this wave has
-      // issued the step's six gate stores behind the request (they may stay out)
+      // issued the step's four gate stores behind the request (they may stay out)
       auto take = [&](int t, char* buf, bool behind) __attribute__((always_inline)) {
-        if (behind) gp_wait2<6>(raw);
+        if (behind) gp_wait2<4>(raw);
         else gp_wait2<0>(raw);
         if (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag)) {
           do {
@@ -782,13 +826,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
         }
         GP_STAMP(12, t);
-        const int vo = t * GIS + gvo;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const f32x4 v = acc[g] * cin + bias[g];
-          gp_st16(gp_pair(__float_as_uint(v[0]), __float_as_uint(v[1]), tag), rs_g, vo + (2 * g) * 1024, near);
-          gp_st16(gp_pair(__float_as_uint(v[2]), __float_as_uint(v[3]), tag), rs_g, vo + (2 * g + 1) * 1024, near);
-        }
+        const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
+        gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
         if (t + 1 < T) {
           take(t + 1, gp_lds + ((t + 1) & 1) * 2 * PH, true);
           if (t + 2 < T) load_h(t + 2);                       // in flight behind the next step's products
@@ -854,7 +893,8 @@ inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, co
   if (!gru_pipe_geom(Q.base.nlayers, B, T, cus, &g)) return -4;
   using G = GruF16Geom<1>;
   static DynLdsGrant grant2, grant4;
-  const bool k2 = Q.kpre16 <= 64;
+  // <2>: at most two K steps of features in whole, 16-byte aligned octets (the 40-d / 64-d front ends); <4>: anything else
+  const bool k2 = Q.kpre16 <= 64 && Q.base.idim % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
   auto kern = k2 ? gru_pipe_kernel<2> : gru_pipe_kernel<4>;
   if (grant_dynamic_lds(kern, int(G::LDS_BYTES), k2 ? grant2 : grant4)) return -3;
   hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn,

@@ -638,9 +638,10 @@ static bool gru_pipe_call(const wekws_hip_model* m, int B, int T) {
     return false;
   wekws::GruPipeGeom g;
   if (!wekws::gru_pipe_geom(d.num_layers, B, T, m->fsmn_cus, &g)) return false;
-  // more tiles than resident slots: every workgroup serves several tiles one after the other, and the layer-major kernels
-  // (all CUs on every pass) are faster -- measured 0.6 .. 0.75x at B = 4096 .. 16384; option value 2 runs the wavefront anyway
-  return g.tiles <= g.slots || m->gru_pipe == 2;
+  // many more tiles than resident slots: every workgroup serves several tiles one after the other, and from ~8 rounds on the
+  // layer-major kernels (all CUs on every pass, two tiles per workgroup) win -- measured 1.08x at B = 4096 (4 rounds), 0.94x at
+  // B = 16384 (16 rounds); option value 2 runs the wavefront anyway
+  return g.tiles <= 4 * g.slots || m->gru_pipe == 2;
 }
 // ... and the bytes of its granule buffer (a second per-stream buffer that holds nothing else)
 static size_t granule_need(const wekws_hip_model* m, int B, int T) {

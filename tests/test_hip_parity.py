@@ -289,7 +289,7 @@ def test_headline_persistent_tail_vs_oracle(B, error_report):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("name", ["ds_tcn_h256", "mdtc_h64"])
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "mdtc_h64", "ds_tcn_h64"])
 def test_lane_major_lengths_vs_oracle(name, precision, error_report):
     """The register-resident kernels keep frames lane-major (a lane owns NT consecutive frames; mdtc64_g4 aligns the
     utterance's END with a lane boundary): utterance lengths around every lane / tile boundary against the ORACLE (the T
@@ -1083,3 +1083,39 @@ def test_gru_wavefront_under_uneven_load():
         y1, c1 = pipe(x)
         assert torch.equal(y1, y0) and torch.equal(c1, c0), it
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ds_tcn_h64", "ds_tcn_h64_cmvn1"])
+def test_ds64_register_resident_kernel(name, error_report):
+    """ds64_g4.hip.h (DS-TCN hidden 64 without an incoming cache: one utterance per 4-wave workgroup, tile in registers)
+    against the oracle at batch sizes around the workgroup rounds of a 256-CU part and lengths in every tile size, and
+    against the generic LDS-tile kernel (option g16 = 0): same products and scales, so the returned cache agrees to the last
+    bits; then the cache it returns must continue a stream exactly like the generic kernel's does."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"])
+    if name.endswith("cmvn1"):                                   # the shape of the reference's shipped model: CMVN, one output
+        cfg["_cmvn"] = True
+    else:
+        cfg["output_dim"] = 2
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 2024)
+    fast, slow = build(cfg, sd), build(cfg, sd).set_option("g16", 0)
+    worst = 0.0
+    # (large batches: every row -- with several workgroups per CU a version of this kernel was wrong in ~3 % of them)
+    for B, T in ((1, 98), (3, 1), (5, 7), (2, 16), (4, 31), (7, 33), (3, 64), (301, 98), (1030, 98), (6, 112), (3, 150), (4096, 98),
+                 (2048, 49), (2048, 100)):
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=7 * B + T)
+        if cfg.get("_cmvn"):
+            x = (3 * x + 10).astype(np.float32)
+        y, c = run(fast, x)
+        ys, cs = run(slow, x)
+        assert max_abs(c, cs) <= 3e-6 * max(1.0, float(np.abs(cs).max())) and max_abs(y, ys) <= 2e-6, (B, T, max_abs(c, cs), max_abs(y, ys))
+        if B <= 301:
+            ry, rc = kws_oracle.forward(cfg, sd, x, None)
+            worst = max(worst, max_abs(y, ry))
+            assert max_abs(y, ry) <= POSTERIOR_TOL and max_abs(c, rc) <= tol_for(rc), (B, T)
+        x2 = synth.synth_feats(B, 10, cfg["input_dim"], seed=T)
+        y2, c2 = run(fast, x2, c)                               # (with a cache: the generic kernel in both models)
+        y2s, c2s = run(slow, x2, cs)
+        assert max_abs(y2, y2s) <= 2e-6 and max_abs(c2, c2s) <= 3e-6 * max(1.0, float(np.abs(c2s).max()))
+    error_report[f"ds64_g4/{name}"] = worst

@@ -113,6 +113,11 @@ __device__ __forceinline__ unsigned wave_umax63(unsigned x) {
 }
 // Publish this thread's partial max|.| (v >= 0; a NaN orders above everything and ends up disabling the scale): wave
 // reduction, then lane 63 merges into the cell.
+// The atomic is inline assembly, i.e. NOT in the compiler's LDS bookkeeping: a barrier behind the publish gets no
+// `s_waitcnt lgkmcnt(0)` from it, and a wave that passes the barrier can read the cell before the atomic has landed (found
+// in round 4 on ds64_g4.hip.h, four workgroups per CU: ~3 % of the utterances of a large batch were off by 1e-2 -- waves
+// of one workgroup had derived DIFFERENT power-of-two scales for rows of the same operand).  The wait is part of the
+// publish.
 __device__ __forceinline__ void amax_publish(AmaxCell* cell, float v) {
   const unsigned x = wave_umax63(__float_as_uint(v));
   // lane 63 alone issues the ds_max_u32: EXEC is narrowed by hand (five instructions; the compiler's lowering of a
@@ -124,7 +129,8 @@ __device__ __forceinline__ void amax_publish(AmaxCell* cell, float v) {
       "s_mov_b32 exec_lo, 0\n\t"
       "s_mov_b32 exec_hi, 0x80000000\n\t"
       "ds_max_u32 %1, %2\n\t"
-      "s_mov_b64 exec, %0"
+      "s_mov_b64 exec, %0\n\t"
+      "s_waitcnt lgkmcnt(0)"
       : "=&s"(saved)
       : "v"(addr), "v"(x)
       : "memory");

@@ -1,0 +1,262 @@
+// DS-TCN, hidden_dim 64 (examples/hey_snips/s0/conf/ds_tcn.yaml, examples/hi_xiaowen/s0/conf/ds_tcn.yaml; the trained model the
+// reference ships for Android is this shape), calls WITHOUT an incoming cache: REGISTER-RESIDENT kernel, one utterance per
+// 4-wave workgroup (round 4).  The recipe of mdtc64_g4.hip.h on the arithmetic of tcn.py:101-114 / :35-61:
+//
+//   block:  u = [zeros | h];  a = ReLU(BN1(dw_k8_dil_d(u)))  -> operand planes | barrier |
+//           p = ReLU(BN2(pointwise(a)))  (one 64 x 64 GEMM, two K steps);  h = p + h  (residual AFTER the ReLU, tcn.py:60) |
+//           barrier
+//
+// The generic 8-wave kernel (conv_stack_f16.hip.h) keeps the f32 tile in LDS and walks a 32-channel operand slab through
+// nine barriers per block with 512 threads in lockstep: at 4.1 MFLOP per utterance the model is all latency, and it ran at
+// 0.07 of the matrix roofline and 0.08 of HBM (round-3 review).  Here wave w owns output channels 16 w .. 16 w + 15 for all
+// frames in the accumulator layout of the 1x1 convolution, the residual tile lives in 4 NT registers, LDS holds the 28 KB of
+// operand planes, and FOUR independent workgroups share a CU (<= 128 registers): the overlap comes from the hardware scheduler.
+//   * frames lane-major with the utterance's END aligned to a lane boundary (mdtc64_g4.hip.h): the cache slices (the last
+//     7 d frames of every block's input) are whole lanes plus one lane's tail registers;
+//   * depthwise taps (k = 8): g16_dw_rows of ds256_g16.hip.h, one v_fmac_f32_dpp row_shr per tap and output;
+//   * the keyword head (per-frame linear, one or two outputs) from the registers.
+// Every other call (incoming cache, other heads, wider features): the generic kernel.  Same operand scaling, same products,
+// same sums per output as the generic kernel's (block floating point: conv_stack_f16.hip.h); the head's sum order differs.
+#pragma once
+#include "mdtc64_g4.hip.h"
+
+namespace wekws {
+
+template <int NT, bool SPLIT, bool ALIGNED>
+__global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParams P, const CallArgs A) {
+  constexpr int C = 64, TT = 16 * NT;
+  constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the 64-channel operand
+  constexpr int XI = (3 * 4 * TT + kG4Threads - 1) / kG4Threads;   // feature items per thread (<= 3 K steps)
+  extern __shared__ __attribute__((aligned(16))) float d4_lds[];
+  char* const planes = reinterpret_cast<char*>(d4_lds);      // [hi | lo][k-octet 0..7][column][8 halves]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int T = A.T;
+  const int b = blockIdx.x;                                  // one utterance per workgroup
+  const float* __restrict__ W = P.w;
+  const int Pc = P.cache_len;
+  const int o0 = wave * 16 + lq * 4;                         // this lane's 4 channels: rows of the o-tile AND of the tile h
+  const int off = ALIGNED ? 0 : (NT - T % NT) % NT;          // frame of column 16 tt + l: NT l + tt - off
+  const int frag_off = (lq * TT + l15) * 16;
+  char* const pst = planes + ((o0 >> 3) * TT + l15) * 16 + (o0 & 7) * 2;
+
+  f32x4 acc[NT], hv[NT];
+  __shared__ AmaxCell amax_cells[kAmaxCells];
+  __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  __shared__ __attribute__((aligned(16))) float taps[2][C * 12];   // taps + bias records of the current / next block
+  amax_zero<kG4Threads>(amax_cells, kAmaxCells);
+  stage_block_table<kG4Threads>(blk, P.blocks, P.nblocks);
+  // taps of a block: 3 KB copied from the weight image straight into LDS by waves 0 .. 2 (global_load_lds); nobody waits for
+  // the copy explicitly -- the issuing waves consume weight fragments they requested AFTER it before the barrier in front of
+  // the depthwise phase that reads the taps
+  auto stage_taps = [&](int bi, int ln) __attribute__((always_inline)) {
+    if (wave < 3)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + __builtin_amdgcn_readfirstlane(blk[bi].dw_pk) + (wave * 64 + ln) * 4),
+                                       (__attribute__((address_space(3))) void*)(&taps[bi & 1][0] + wave * 256), 16, 0, 0);
+  };
+
+  // ---- features (as mdtc64_g4): every thread owns up to XI items = 8 consecutive features of a frame
+  const int nk = P.kpre16 / 32;
+  const int nitems = nk * 4 * TT;
+  W16XItem xi[XI];
+  float xmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int e = tid + i * kG4Threads;
+    const int n = e % TT, q = e / TT;
+    const int f = NT * (n & 15) + (n >> 4) - off;
+    const int oct = q & 3, st = q >> 2;
+    const int kf = st * 32 + oct * 8;
+    const bool has = e < nitems;
+    xi[i].dst = has ? ((st & 1) * 4 + oct) * TT * 16 + n * 16 : -1;
+    w16_fetch_x(xi[i], A.x + int64_t(b) * A.xs_b + int64_t(f) * P.idim + kf, A.x, has && f >= 0 && f < T && kf < P.idim);
+    xmax = fmaxf(xmax, w16_x_amax(xi[i]));
+  }
+  __syncthreads();                                           // cells zeroed, table staged
+  stage_taps(0, lane);
+  amax_publish(amax_cells, xmax);
+
+  // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
+  {
+    const uint4* ap = reinterpret_cast<const uint4*>(W + P.pre_a16) + size_t(wave) * nk * 128 + lane;
+    const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                         // the feature maximum is published
+    float cpre;
+    const float sx = pow2_scale(amax_read(amax_cells), &cpre);
+    for (int k0 = 0; k0 < nk; k0 += 2) {
+      if (k0) __syncthreads();
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int st = (tid + i * kG4Threads) / (4 * TT);
+        if (st >= k0 && st < k0 + 2) w16_put_x<SPLIT>(xi[i], sx, planes, MPB);
+      }
+      __syncthreads();
+      for (int st = k0; st < min(k0 + 2, nk); ++st) {
+        F16Frag a;
+        a.h = __builtin_bit_cast(f16x8, ap[st * 128]);
+        a.l = __builtin_bit_cast(f16x8, ap[st * 128 + 64]);
+        const char* bh = planes + (st & 1) * 4 * TT * 16 + frag_off;
+        g16_mfma_step<NT, SPLIT>(acc, a, bh, bh + MPB);
+      }
+    }
+    cpre *= P.pre_inv_s;
+    float hmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaf(acc[tt][r], cpre, f4c(bias, r));
+        if (P.pre_relu) v = fmaxf(v, 0.f);
+        if (l15 == 0 && tt < off) v = 0.f;                   // frames below zero: the causal left context
+        hv[tt][r] = v;
+        hmax = fmaxf(hmax, fabsf(v));
+      }
+    }
+    amax_publish(amax_cells + 2, hmax);
+  }
+
+  // ======================================= residual blocks =======================================
+  auto frag_ptr = [&](uint32_t a16) __attribute__((always_inline)) {
+    return reinterpret_cast<const uint4*>(W + __builtin_amdgcn_readfirstlane(a16)) + size_t(wave) * 256;
+  };
+  auto load_frag = [&](F16Frag& a, const uint4* ap, int ln) __attribute__((always_inline)) {
+    a.h = __builtin_bit_cast(f16x8, ap[ln]);
+    a.l = __builtin_bit_cast(f16x8, ap[ln + 64]);
+  };
+  float yp[NT][2];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) yp[tt][0] = yp[tt][1] = 0.f;
+  F16Frag g1a;                                               // first K step of the block's GEMM: requested a block ahead
+  __syncthreads();                                           // (A) maximum published, planes free, table / taps visible
+  load_frag(g1a, frag_ptr(blk[0].a1_16), lane);
+  for (int bi = 0; bi < P.nblocks; ++bi) {
+    int o0b = o0, laneb = lane;                              // (opaque per block: see mdtc64_g4.hip.h)
+    asm volatile("" : "+v"(o0b), "+v"(laneb));
+
+    BlockDesc bd = blk[bi];
+    bd.pad = __builtin_amdgcn_readfirstlane(bd.pad);
+    bd.dil = __builtin_amdgcn_readfirstlane(bd.dil);
+    bd.cache_off = __builtin_amdgcn_readfirstlane(bd.cache_off);
+    bd.b1 = __builtin_amdgcn_readfirstlane(bd.b1);
+    const int pad = bd.pad;
+    if (bi + 1 < P.nblocks) stage_taps(bi + 1, laneb);
+    auto uni = [](float v) __attribute__((always_inline)) {
+      return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+    };
+    float c1v;
+    const float sa = uni(pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1v));
+    const float c1 = uni(c1v * bd.inv_s1);
+
+    // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h], from the registers
+    if (A.out_cache) {
+      float* const ocb = A.out_cache + int64_t(b) * C * Pc + bd.cache_off;
+      const int p0 = NT * l15 - off - (T - pad);             // slice column of this lane's first frame
+      if (p0 >= 0 && p0 + NT <= pad) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g16_store_run<NT>(ocb + unsigned((o0b + r) * Pc + p0), hv, r);
+      } else if (p0 < 0 && p0 + NT > 0) {
+        if constexpr (NT > 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g4_store_tail_n<NT>(p0 + NT, ocb + unsigned((o0b + r) * Pc), hv, r);
+        }
+      }
+      if (T + off < pad) {                                   // shorter than the slice: zero context in front
+        const int nz = pad - T - off;
+        for (int e = lane; e < 16 * nz; e += 64) {
+          const int cc = e / nz, p = e - cc * nz;
+          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+        }
+      }
+    }
+
+    // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-108), scaled, split, to the operand planes
+    {
+      const float* taps_o0 = &taps[bi & 1][0] + o0 * 12;
+      switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
+        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 8: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        default: break;
+      }
+    }
+    __syncthreads();                                         // (B1) the depthwise planes are written
+
+    // ---- pointwise conv over the full K = 64, + BN + ReLU, + residual (tcn.py:109-112, :60), registers only
+    const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0b);
+    F16Frag gb;                                              // second K step: arrives behind the first one's MFMAs
+    load_frag(gb, frag_ptr(bd.a1_16) + 128, laneb);
+    g16_mfma_step<NT, SPLIT, true>(acc, g1a, planes + frag_off, planes + MPB + frag_off);
+    g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
+    if (bi + 1 < P.nblocks) load_frag(g1a, frag_ptr(blk[bi + 1].a1_16), laneb);   // next block's first K step
+    float hmax = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(fmaf(acc[tt][r], c1, f4c(bias1, r)), 0.f) + hv[tt][r];
+        if (l15 == 0 && tt < off) v = 0.f;                   // frames below zero stay the (zero) left context
+        hv[tt][r] = v;
+        hmax = fmaxf(hmax, fabsf(v));
+      }
+    }
+    amax_publish(amax_cells + 3 + bi, hmax);                 // = the input tile of block bi + 1
+    __syncthreads();                                         // (B2) maximum published, planes free
+  }
+
+  // ---- the backbone's output enters the head: this lane's partial sums over its four channels.  (Computed HERE, behind the
+  //      last block's barrier: held in registers across that barrier -- computed inside the last block, like mdtc64_g4 does --
+  //      ~3 % of the utterances of a large batch came out 1e-2 off whenever several workgroups shared the CU, although the
+  //      tile and the partial sums themselves checked out; tests/test_hip_parity.py::test_ds64_register_resident_kernel compares
+  //      every row of a 4096-utterance batch.)
+  {
+    const int o0b = o0;
+    {
+      const int K = P.odim;
+      const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0b);
+      const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0b);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        float p0 = 0.f, p1 = 0.f;
+        p0 = fmaf(w0.x, hv[tt][0], p0); p1 = fmaf(w1.x, hv[tt][0], p1);
+        p0 = fmaf(w0.y, hv[tt][1], p0); p1 = fmaf(w1.y, hv[tt][1], p1);
+        p0 = fmaf(w0.z, hv[tt][2], p0); p1 = fmaf(w1.z, hv[tt][2], p1);
+        p0 = fmaf(w0.w, hv[tt][3], p0); p1 = fmaf(w1.w, hv[tt][3], p1);
+        yp[tt][0] = p0; yp[tt][1] = p1;
+      }
+    }
+  }
+  // ---- keyword head (per-frame linear, one or two outputs; classifier.py:63-67): the 16 partial sums per output (4 waves x 4
+  //      channel groups) meet in LDS
+  {
+    const int K = P.odim;
+    constexpr int PS = 32 * NT + 16;                          // floats per partial row: 16 lanes x (NT frames x 2 outputs), padded
+    float* const part = d4_lds;
+    int th = threadIdx.x;
+    asm volatile("" : "+v"(th));
+    float* dst = part + (th >> 4) * PS + 2 * NT * (th & 15);   // row = wave * 4 + lq
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+      *reinterpret_cast<float2*>(dst + 2 * tt) = float2{yp[tt][0], yp[tt][1]};   // column NT l15 + tt = frame NT l15 + tt - off
+    __syncthreads();
+    const int t = (th >> 1) - off, k = th & 1;               // thread = (column, output)
+    if (th < 2 * TT && t >= 0 && t < T && k < K) {
+      float v = W[P.head_b + k];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v += part[i * PS + th];
+      if (P.sigmoid) v = sigmoidf_(v);
+      A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+    }
+  }
+}
+
+// Usable when (the host checks the model side: DS-TCN, hidden_dim 64, kernel size 8, dilations 1 / 2 / 4 / 8): no incoming
+// cache, features of <= 96 dims in whole aligned 8-float items, a per-frame linear head with one or two outputs.  Returns -4
+// otherwise (the caller then runs the generic kernel).
+int launch_ds64_g4(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
+
+}  // namespace wekws

@@ -22,6 +22,7 @@
 #include "ds256_g16.hip.h"
 #include "ds256_g32.hip.h"
 #include "mdtc64_g4.hip.h"
+#include "ds64_g4.hip.h"
 #include "ds256_stream.hip.h"
 #include "ds256_mm.hip.h"
 #include "mdtc64_w16.hip.h"
@@ -1443,6 +1444,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache)
                      ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream, m->g16_one_pass ? (1 << 30) : m->fsmn_cus)                      // 16 waves, tile in registers
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
+               : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && !a.in_cache &&
+                  (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4)
+                     ? rc                                                                         // one utterance per 4-wave workgroup
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;
         case WEKWS_HIP_BACKBONE_TCN:

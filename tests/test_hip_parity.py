@@ -289,7 +289,7 @@ def test_headline_persistent_tail_vs_oracle(B, error_report):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("name", ["ds_tcn_h256", "mdtc_h64", "ds_tcn_h64"])
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "mdtc_h64", "ds_tcn_h64", "mdtc_small", "mdtc_small_global12"])
 def test_lane_major_lengths_vs_oracle(name, precision, error_report):
     """The register-resident kernels keep frames lane-major (a lane owns NT consecutive frames; mdtc64_g4 aligns the
     utterance's END with a lane boundary): utterance lengths around every lane / tile boundary against the ORACLE (the T
@@ -1119,3 +1119,28 @@ def test_ds64_register_resident_kernel(name, error_report):
         y2s, c2s = run(slow, x2, cs)
         assert max_abs(y2, y2s) <= 2e-6 and max_abs(c2, c2s) <= 3e-6 * max(1.0, float(np.abs(c2s).max()))
     error_report[f"ds64_g4/{name}"] = worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mdtc_small", "mdtc_small_global12", "mdtc_small_last12", "mdtc_h64", "mdtc_h64_global12"])
+def test_mdtc_register_resident_kernels_all_rows(name, error_report):
+    """mdtc64_g4.hip.h at C = 64 and (round 4) C = 32 (mdtc_small.yaml: two waves per utterance, eight workgroups per CU)
+    against the generic LDS-tile kernel (option g16 = 0), EVERY row of batches that put several rounds of workgroups on every
+    CU, all tile sizes, aligned and unaligned lengths; a sample of rows against the oracle."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 31)
+    fast, slow = build(cfg, sd), build(cfg, sd).set_option("g16", 0)
+    worst = 0.0
+    for B, T in ((4099, 98), (2048, 49), (2050, 100), (1030, 28), (515, 9), (3, 150)):
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=B + T)
+        y, c = run(fast, x)
+        ys, cs = run(slow, x)
+        scale = max(1.0, float(np.abs(ys).max()))
+        assert max_abs(c, cs) <= 3e-6 * max(1.0, float(np.abs(cs).max())), (B, T, max_abs(c, cs))
+        assert max_abs(y, ys) <= 3e-6 * scale, (B, T, max_abs(y, ys))
+        idx = np.linspace(0, B - 1, 24).astype(int)
+        ry, rc = kws_oracle.forward(cfg, sd, x[idx], None)
+        worst = max(worst, max_abs(y[idx], ry) / max(1.0, float(np.abs(ry).max())))
+        assert max_abs(y[idx], ry) <= tol_for(ry) and max_abs(c[idx], rc) <= tol_for(rc), (B, T)
+    error_report[f"mdtc_g4_all_rows/{name}"] = worst

@@ -13,7 +13,7 @@ from wekws_amd.utils import synth  # noqa: E402
 
 
 def main():
-    for name in sys.argv[1:] or ["ds_tcn_h64", "mdtc_small", "mdtc_h64"]:
+    for name in sys.argv[1:] or ["ds_tcn_h64", "mdtc_small", "mdtc_small_global12", "mdtc_h64"]:
         cfg, m = build(name)
         for B in (1024, 8192):
             x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=1)).cuda()

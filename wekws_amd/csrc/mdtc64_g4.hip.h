@@ -108,11 +108,15 @@ __device__ __forceinline__ void g4_store_tail_n(int s, float* dst, const f32x4 (
 // POOLED: the head is GlobalClassifier / LastClassifier (classifier.py:26-28, :38-40) instead of the per-frame linear one.
 // ALIGNED: NT divides T (the 98-frame utterance at NT = 7), i.e. off = 0 at compile time: no frames below zero, so none of
 // the masks that keep them at zero (28 compare-selects per block).
-template <int NT, bool SPLIT, bool POOLED, bool ALIGNED>
-__global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackParams P, const CallArgs A) {
-  constexpr int C = 64, TT = 16 * NT;
-  constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the 64-channel operand
-  constexpr int XI = (3 * 4 * TT + kG4Threads - 1) / kG4Threads;   // feature items per thread (<= 3 K steps)
+// C = 64 (mdtc.yaml; four waves) or 32 (mdtc_small.yaml, round 4: two waves per utterance, eight workgroups per CU).
+template <int C, int NT, bool SPLIT, bool POOLED, bool ALIGNED>
+__global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, const CallArgs A) {
+  constexpr int TT = 16 * NT;
+  constexpr int NTHR = C * 4;                                // one wave per o-tile of 16 channels
+  constexpr int KS = C / 32;                                 // K steps of the block GEMMs = K steps of features staged per pass
+  constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the C-channel operand
+  constexpr int XK = C == 64 ? 3 : 2;                        // K steps of features at most (96 / 64 dims)
+  constexpr int XI = (XK * 4 * TT + NTHR - 1) / NTHR;        // feature items per thread
   extern __shared__ __attribute__((aligned(16))) float g4_lds[];
   char* const planes = reinterpret_cast<char*>(g4_lds);      // [hi | lo][k-octet 0..7][column][8 halves]
 
@@ -142,13 +146,13 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
   __shared__ __attribute__((aligned(16))) float taps[2][C * 8];   // taps + bias records of the current / next block
-  amax_zero<kG4Threads>(amax_cells, kAmaxCells);
-  stage_block_table<kG4Threads>(blk, P.blocks, P.nblocks);
-  // taps of a block: 2 KB copied from the weight image straight into LDS by waves 0 and 1 (global_load_lds); nobody waits
+  amax_zero<NTHR>(amax_cells, kAmaxCells);
+  stage_block_table<NTHR>(blk, P.blocks, P.nblocks);
+  // taps of a block: C * 32 bytes copied from the weight image straight into LDS by waves 0 (and 1) (global_load_lds); nobody waits
   // for the copy explicitly -- the issuing waves consume weight fragments they requested AFTER it (loads return in order)
   // before the barrier in front of the depthwise phase that reads the taps
   auto stage_taps = [&](int bi, int ln) __attribute__((always_inline)) {
-    if (wave < 2)
+    if (wave < C / 32)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + __builtin_amdgcn_readfirstlane(blk[bi].dw_pk) + (wave * 64 + ln) * 4),
                                        (__attribute__((address_space(3))) void*)(&taps[bi & 1][0] + wave * 256), 16, 0, 0);
   };
@@ -161,13 +165,13 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
   float xmax = 0.f;
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int e = tid + i * kG4Threads;
+    const int e = tid + i * NTHR;
     const int n = e % TT, q = e / TT;
     const int f = NT * (n & 15) + (n >> 4) - off;
     const int oct = q & 3, st = q >> 2;
     const int kf = st * 32 + oct * 8;
     const bool has = e < nitems;
-    xi[i].dst = has ? ((st & 1) * 4 + oct) * TT * 16 + n * 16 : -1;   // (a third K step is staged where the first was)
+    xi[i].dst = has ? ((st % KS) * 4 + oct) * TT * 16 + n * 16 : -1;   // (KS K steps fit the planes: later ones are staged where earlier ones were)
     w16_fetch_x(xi[i], A.x + int64_t(b) * A.xs_b + int64_t(f) * P.idim + kf, A.x, has && f >= 0 && f < T && kf < P.idim);
     xmax = fmaxf(xmax, w16_x_amax(xi[i]));
   }
@@ -184,19 +188,19 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     __syncthreads();                                         // the feature maximum is published
     float cpre;
     const float sx = pow2_scale(amax_read(amax_cells), &cpre);
-    for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps (= the planes) per pass
-      if (k0) __syncthreads();                               // the first two K steps have been multiplied
+    for (int k0 = 0; k0 < nk; k0 += KS) {                    // KS K steps (= the planes) per pass
+      if (k0) __syncthreads();                               // the K steps before have been multiplied
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const int st = (tid + i * kG4Threads) / (4 * TT);    // the item's K step
-        if (st >= k0 && st < k0 + 2) w16_put_x<SPLIT>(xi[i], sx, planes, MPB);
+        const int st = (tid + i * NTHR) / (4 * TT);          // the item's K step
+        if (st >= k0 && st < k0 + KS) w16_put_x<SPLIT>(xi[i], sx, planes, MPB);
       }
       __syncthreads();
-      for (int st = k0; st < min(k0 + 2, nk); ++st) {
+      for (int st = k0; st < min(k0 + KS, nk); ++st) {
         F16Frag a;
         a.h = __builtin_bit_cast(f16x8, ap[st * 128]);
         a.l = __builtin_bit_cast(f16x8, ap[st * 128 + 64]);
-        const char* bh = planes + (st & 1) * 4 * TT * 16 + frag_off;
+        const char* bh = planes + (st % KS) * 4 * TT * 16 + frag_off;
         g16_mfma_step<NT, SPLIT>(acc, a, bh, bh + MPB);
       }
     }
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
 
   // ======================================= residual blocks =======================================
   auto frag_ptr = [&](uint32_t a16) __attribute__((always_inline)) {
-    return reinterpret_cast<const uint4*>(W + __builtin_amdgcn_readfirstlane(a16)) + size_t(wave) * 256;
+    return reinterpret_cast<const uint4*>(W + __builtin_amdgcn_readfirstlane(a16)) + size_t(wave) * (KS * 128);
   };
   auto load_frag = [&](F16Frag& a, const uint4* ap, int ln) __attribute__((always_inline)) {   // one K step: hi | lo
     a.h = __builtin_bit_cast(f16x8, ap[ln]);
@@ -305,12 +309,12 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     }
     __syncthreads();                                         // (B1) the depthwise planes are written
 
-    // ---- GEMM 1 (pointwise) over the full K = 64
+    // ---- GEMM 1 (pointwise) over the full K = C
     const float4 bias1 = *reinterpret_cast<const float4*>(W + bd.b1 + o0b);
     F16Frag gb;                                              // second K step: arrives behind the first one's MFMAs
-    load_frag(gb, frag_ptr(bd.a1_16) + 128, laneb);
+    if constexpr (KS == 2) load_frag(gb, frag_ptr(bd.a1_16) + 128, laneb);
     g16_mfma_step<NT, SPLIT, true>(acc, g1a, planes + frag_off, planes + MPB + frag_off);   // (C = 0: no cleared accumulators)
-    g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
+    if constexpr (KS == 2) g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
     F16Frag g2a;                                             // GEMM 2, first K step: arrives behind the mid epilogue
     load_frag(g2a, frag_ptr(bd.a2_16), laneb);
     __syncthreads();                                         // (B2) every wave is done reading the depthwise planes
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     const float4 bias2 = *reinterpret_cast<const float4*>(W + bd.b2 + o0b);   // (arrives behind GEMM 2)
 
     // ---- conv2 (1x1) + BN2, residual BEFORE the ReLU (mdtc.py:115-118), registers only
-    load_frag(gb, frag_ptr(bd.a2_16) + 128, laneb);
+    if constexpr (KS == 2) load_frag(gb, frag_ptr(bd.a2_16) + 128, laneb);
     g16_mfma_step<NT, SPLIT, true>(acc, g2a, planes + frag_off, planes + MPB + frag_off);
-    g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
+    if constexpr (KS == 2) g16_mfma_step<NT, SPLIT>(acc, gb, planes + 4 * TT * 16 + frag_off, planes + 4 * TT * 16 + MPB + frag_off);
     if (bi + 1 < P.nblocks) load_frag(g1a, frag_ptr(blk[bi + 1].a1_16), laneb);   // next block's GEMM 1: behind its depthwise phase
     float hmax = 0.f;
 #pragma unroll
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
   if constexpr (POOLED) {
     // ---- pooled heads: m = mean_t / last frame of the stack sum -> W2 ReLU(W1 m + b1) + b2.  The 16 lanes of a row add
     //      their channel sums (xor butterfly), the 64 pooled values meet in LDS, one small MLP on the vector units.
-    float* const mvec = g4_lds;                              // [64] pooled channels, then [head_hidden]
+    float* const mvec = g4_lds;                              // [C] pooled channels, then [head_hidden]
     float* const hid = g4_lds + C;
     int th = threadIdx.x;
     asm volatile("" : "+v"(th));
@@ -418,14 +422,14 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     __syncthreads();
     if (A.last_tile) {
       const int HH = P.head_hidden, K = P.odim;
-      for (int j = th; j < HH; j += kG4Threads) {
+      for (int j = th; j < HH; j += NTHR) {
         const float* w1 = W + P.head_w + j * C;
         float v = W[P.head_b + j];
         for (int c = 0; c < C; ++c) v = fmaf(w1[c], mvec[c], v);
         hid[j] = fmaxf(v, 0.f);
       }
       __syncthreads();
-      for (int k = th; k < K; k += kG4Threads) {
+      for (int k = th; k < K; k += NTHR) {
         const float* w2 = W + P.head_w2 + k * HH;
         float v = W[P.head_b2 + k];
         for (int j = 0; j < HH; ++j) v = fmaf(w2[j], hid[j], v);
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     }
   } else
   // ---- keyword head (per-frame linear, one or two outputs; classifier.py:63-67) on the sum of the stack outputs
-  //      (mdtc.py:270-273): the 16 partial sums per output (4 waves x 4 channel groups) meet in LDS
+  //      (mdtc.py:270-273): the C / 4 partial sums per output (waves x 4 channel groups) meet in LDS
   {
     const int K = P.odim;
     constexpr int PS = 32 * NT + 16;                          // floats per partial row: 16 lanes x (NT frames x 2 outputs), padded
@@ -447,13 +451,15 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
     for (int tt = 0; tt < NT; ++tt)
       *reinterpret_cast<float2*>(dst + 2 * tt) = float2{yp[tt][0], yp[tt][1]};   // column NT l15 + tt = frame NT l15 + tt - off
     __syncthreads();
-    const int t = (th >> 1) - off, k = th & 1;               // thread = (column, output)
-    if (th < 2 * TT && t >= 0 && t < T && k < K) {
-      float v = W[P.head_b + k];
+    for (int e = th; e < 2 * TT; e += NTHR) {                // item = (column, output)
+      const int t = (e >> 1) - off, k = e & 1;
+      if (t >= 0 && t < T && k < K) {
+        float v = W[P.head_b + k];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v += part[i * PS + th];
-      if (P.sigmoid) v = sigmoidf_(v);
-      A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+        for (int i = 0; i < NTHR / 16; ++i) v += part[i * PS + e];
+        if (P.sigmoid) v = sigmoidf_(v);
+        A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
+      }
     }
   }
 }
@@ -463,5 +469,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void mdtc64_g4_kernel(const StackPar
 // (Global / Last) head whose hidden layer fits the LDS left over.
 // Returns -4 otherwise (the caller then runs mdtc64_w16).
 int launch_mdtc64_g4(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
+// ... and hidden_dim 32 (mdtc_small.yaml): features of <= 64 dims
+int launch_mdtc32_g4(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream);
 
 }  // namespace wekws

@@ -154,21 +154,52 @@ __device__ __forceinline__ int rev4_256(int k) {  // reverse the four base-4 dig
   return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
 }
 
-__device__ __forceinline__ int pz(int e) { return e + (e >> 2); }   // padded position of element e of the FFT strip
+// Position of element e of the FFT strip: an XOR swizzle instead of round 1's padding e + (e >> 2).  The 8-byte accesses of
+// a wave are served in two groups of 32 lanes over 32 bank pairs; with bits 5 and 6 of e folded into the low five bits (6 =
+// 0b00110, 25 = 0b11001) every access pattern of the four radix-4 stages -- runs of 64 (stage 0, untangle), 16-runs 64
+// apart (q = 16), 4-runs 16 apart (q = 4), stride 4 (q = 1), the digit-reversed last stores -- hits 32 different pairs
+// (derivation: tools/probe/fbank_swizzle.py; only the reversed untangle reads keep one 2-way pair).  PMC, round 3 layout:
+// 10.4 M of 32.1 M LDS-active cycles were bank conflicts.
+__device__ __forceinline__ int pz(int e) { return e ^ (((e >> 5) & 1) * 6) ^ (((e >> 6) & 1) * 25); }
 
-constexpr int kFbankStrip = 832;   // floats per wave: 320 complex (padded 256) + 192 slot sums
+constexpr int kFbankStrip = 704;   // floats per frame in flight: 256 complex + 192 slot sums
+
+// DPP forms of the wave-level exchanges (round 3 used __shfl_*: ds_bpermute, i.e. 13 of the 61 LDS instructions of a frame)
+template <int CTRL, int RMASK, bool BC>
+__device__ __forceinline__ float fb_dppx(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, BC));
+}
+// sum over the wave, the same value in every lane (uniform: it comes back through a scalar register)
+__device__ __forceinline__ float fb_wave_sum(float s) {
+  s += fb_dppx<0xB1, 0xf, true>(s);                         // quad_perm [1,0,3,2]
+  s += fb_dppx<0x4E, 0xf, true>(s);                         // quad_perm [2,3,0,1]
+  s += fb_dppx<0x141, 0xf, true>(s);                        // row_half_mirror
+  s += fb_dppx<0x140, 0xf, true>(s);                        // row_mirror: every lane holds its row's sum
+  s += fb_dppx<0x142, 0xa, false>(s);                       // row_bcast:15 -> rows 1 and 3 take in rows 0 and 2
+  s += fb_dppx<0x143, 0xc, false>(s);                       // row_bcast:31 -> rows 2 and 3 take in row 1: lane 63 holds the sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
+}
+#ifndef WEKWS_FBANK_FW
+#define WEKWS_FBANK_FW 2
+#endif
+constexpr int kFbankFW = WEKWS_FBANK_FW;   // frames per wave, interleaved through every phase (round 4)
 
 // S: sample type of the PCM in device memory -- float (int16 scale, what wav.h:98-102 hands over) or int16_t (what
 // FeaturePipeline::AcceptWaveform(const std::vector<int16_t>&), feature_pipeline.cc:49-55, receives: converted here,
 // in registers, so the upload and the HBM read are 2 bytes per sample)
+//
+// Round 4: a wave works on TWO frames at a time (g, g + 1), phase by phase.  The kernel is bound by neither unit (by
+// instruction counts ~40 % vector, ~50 % LDS) but by the chain load -> butterfly -> store -> wave-level sync of every FFT
+// stage; with two independent frames between two syncs each lane has twice the work to cover the LDS round trips, the syncs
+// per frame halve, and the window / twiddle / mel-weight registers serve both frames.  Same arithmetic per frame, bit for bit.
 template <int ROUNDS, typename S>
 __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
                                                                  int B, int nsamp, int nframes,
                                                                  float* __restrict__ feats) {
+  constexpr int FW = kFbankFW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float2* const z = reinterpret_cast<float2*>(lds + wave * kFbankStrip);
-  float* const melacc = lds + wave * kFbankStrip + 640;
+  float* const strip = lds + wave * FW * kFbankStrip;       // [FW] strips of this wave
   const float* __restrict__ tab = P.tables;
   const float2* tw256 = reinterpret_cast<const float2*>(tab);
   const float2* tw512 = reinterpret_cast<const float2*>(tab + 512);
@@ -215,141 +246,190 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
   // where the last stage puts its four outputs: X[64 m + rev3(lane)], natural order
   const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
 
+  // Frame g of the launch is frame g % nframes of utterance g / nframes.  The wave walks g = g0, g0 + stride, ...: the pair
+  // (utterance, frame) is carried and advanced by (stride / nframes, stride % nframes) with a carry -- round 3 divided a
+  // 64-bit index twice per frame (~100 of its ~450 instructions, tools/probe PMC + ISA).
   const int64_t total = int64_t(B) * nframes;
-  const int64_t stride = int64_t(gridDim.x) * kFbankWaves;
-  // the sample pairs of a wave's NEXT frame are requested before the current frame is processed
-  float2 vn[4];
+  const int64_t stride = int64_t(gridDim.x) * kFbankWaves * FW;
+  const int sq = int(stride / nframes), sr = int(stride - int64_t(sq) * nframes);
+  const int64_t f_first = (int64_t(blockIdx.x) * kFbankWaves + wave) * FW;
+  int ub = int(f_first / nframes), ufr = int(f_first - int64_t(ub) * nframes);     // of the wave's CURRENT first frame
+  // the sample pairs of a wave's NEXT frames are requested before the current ones are processed
+  float2 vn[FW][4];
   const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % (2 * sizeof(S)) == 0);
-  auto fetch = [&](int64_t f) __attribute__((always_inline)) {
-    const int64_t b = f / nframes;
-    const int fr = int(f - b * nframes);
-    const S* src = pcm + b * nsamp + int64_t(fr) * P.frame_shift;
+  auto fetch = [&](int b0, int fr0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int i = 2 * (lane + 64 * m);
-      float2 v = make_float2(0.f, 0.f);
-      if (f < total) {
-        if (pair_ok && i + 1 < FL) {
-          if constexpr (sizeof(S) == 4) {
-            v = *reinterpret_cast<const float2*>(src + i);
+    for (int w = 0; w < FW; ++w) {
+      int b = b0, fr = fr0 + w;
+      if (fr >= nframes) { fr -= nframes; ++b; }             // (FW <= nframes: at most one carry)
+      const bool live = b < B;
+      const S* src = pcm + int64_t(b) * nsamp + int64_t(fr) * P.frame_shift;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i = 2 * (lane + 64 * m);
+        float2 v = make_float2(0.f, 0.f);
+        if (live) {
+          if (pair_ok && i + 1 < FL) {
+            if constexpr (sizeof(S) == 4) {
+              v = *reinterpret_cast<const float2*>(src + i);
+            } else {
+              const short2 q = *reinterpret_cast<const short2*>(src + i);
+              v = make_float2(float(q.x), float(q.y));
+            }
           } else {
-            const short2 q = *reinterpret_cast<const short2*>(src + i);
-            v = make_float2(float(q.x), float(q.y));
+            if (i < FL) v.x = float(src[i]);
+            if (i + 1 < FL) v.y = float(src[i + 1]);
           }
-        } else {
-          if (i < FL) v.x = float(src[i]);
-          if (i + 1 < FL) v.y = float(src[i + 1]);
         }
+        vn[w][m] = v;
       }
-      vn[m] = v;
     }
   };
-  fetch(int64_t(blockIdx.x) * kFbankWaves + wave);
-  for (int64_t f = int64_t(blockIdx.x) * kFbankWaves + wave; f < total; f += stride) {
-    const int64_t b = f / nframes;
-    const int fr = int(f - b * nframes);
+  fetch(ub, ufr);
+  for (int64_t f = f_first; f < total; f += stride) {
+    // (utterance, frame) of the wave's next first frame
+    int nb = ub + sq, nfr = ufr + sr;
+    if (nfr >= nframes) { nfr -= nframes; ++nb; }
     // ---- DC removal (fbank.h:155-160)
-    float2 v[4];
-    float s = 0.f;
+    float2 v[FW][4];
+    float mean[FW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      v[m] = vn[m];
-      s += v[m].x + v[m].y;
+    for (int w = 0; w < FW; ++w) {
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        v[w][m] = vn[w][m];
+        s += v[w][m].x + v[w][m].y;
+      }
+      mean[w] = s;
     }
-    fetch(f + stride);
+    fetch(nb, nfr);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const float mean = s / float(FL);
+    for (int w = 0; w < FW; ++w) mean[w] = fb_wave_sum(mean[w]);
     // ---- pre-emphasis 0.97 (fbank.h:122-127: y[i] = x[i] - 0.97 x[i-1], y[0] = x[0] - 0.97 x[0]), window
     //      (fbank.h:130-135).  x[2n-1] is the odd sample of element n-1: the lane below (lane 0: lane 63 of m-1)
-    float2 a[4];
+    float2 a[FW][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int i = 2 * (lane + 64 * m);
-      const float xe = (i < FL) ? v[m].x - mean : 0.f;
-      const float xo = (i + 1 < FL) ? v[m].y - mean : 0.f;
-      const float od = (i + 1 < FL) ? v[m].y - mean : 0.f;
-      float prev = __shfl_up(od, 1);                                        // odd sample of element n - 1
-      if (m > 0) {
-        const float top = (2 * (63 + 64 * (m - 1)) + 1 < FL) ? v[m - 1].y - mean : 0.f;
-        const float wrap = __shfl(top, 63);
-        prev = lane == 0 ? wrap : prev;
-      } else {
-        prev = lane == 0 ? xe : prev;                                       // i = 0: its own value
+    for (int w = 0; w < FW; ++w) {
+      const float mu = mean[w] / float(FL);
+      // (no range masks: samples past the frame were fetched as zeros and their window values ARE zero -- whatever the
+      //  mean subtraction and the pre-emphasis make of them is multiplied away; round 3 spent 27 selects per frame on them)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float xe = v[w][m].x - mu;
+        const float xo = v[w][m].y - mu;
+        float prev = fb_dppx<0x138, 0xf, true>(xo);                           // wave_shr:1: odd sample of element n - 1
+        if (m > 0) {
+          const float top = v[w][m - 1].y - mu;                                // lane 0: lane 63 of the row of elements before
+          const float wrap = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, top), 63));
+          prev = lane == 0 ? wrap : prev;
+        } else {
+          prev = lane == 0 ? xe : prev;                                       // i = 0: its own value
+        }
+        a[w][m].x = (xe - 0.97f * prev) * wn[2 * m];
+        a[w][m].y = (xo - 0.97f * xe) * wn[2 * m + 1];
       }
-      a[m].x = (i < FL) ? (xe - 0.97f * prev) * wn[2 * m] : 0.f;
-      a[m].y = (i + 1 < FL) ? (xo - 0.97f * xe) * wn[2 * m + 1] : 0.f;
     }
-    // ---- 256-point complex FFT, radix-4 DIF, 4 stages
-    float2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    // ---- 256-point complex FFT, radix-4 DIF, 4 stages; both frames between two syncs
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int q = 64 >> (2 * st);        // quarter size: 64, 16, 4, 1
       const int L = 4 * q;                 // block size
       const int blk = lane / q, j = lane - blk * q;
       const int base = blk * L + j;
-      if (st > 0) {
-        a0 = z[pz(base)]; a1 = z[pz(base + q)]; a2 = z[pz(base + 2 * q)]; a3 = z[pz(base + 3 * q)];
-      }
-      const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-      const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-      const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-      const float2 d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-      const float2 t3 = make_float2(d13.y, -d13.x);  // -i * (a1 - a3)
-      float2 o0 = make_float2(t0.x + t2.x, t0.y + t2.y);
-      float2 o1 = make_float2(t1.x + t3.x, t1.y + t3.y);
-      float2 o2 = make_float2(t0.x - t2.x, t0.y - t2.y);
-      float2 o3 = make_float2(t1.x - t3.x, t1.y - t3.y);
-      if (st < 3) {
-        o1 = cmul(o1, tws[st][0]);
-        o2 = cmul(o2, tws[st][1]);
-        o3 = cmul(o3, tws[st][2]);
-        z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
-      } else {
-        // positions 4 lane + m hold X[rev4(4 lane + m)] = X[64 m + rev3(lane)]: stored in natural order
-        z[pz(rev3)] = o0; z[pz(64 + rev3)] = o1; z[pz(128 + rev3)] = o2; z[pz(192 + rev3)] = o3;
+#pragma unroll
+      for (int w = 0; w < FW; ++w) {
+        float2* const z = reinterpret_cast<float2*>(strip + w * kFbankStrip);
+        float2 a0 = a[w][0], a1 = a[w][1], a2 = a[w][2], a3 = a[w][3];
+        if (st > 0) {
+          a0 = z[pz(base)]; a1 = z[pz(base + q)]; a2 = z[pz(base + 2 * q)]; a3 = z[pz(base + 3 * q)];
+        }
+        const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+        const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+        const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+        const float2 d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+        const float2 t3 = make_float2(d13.y, -d13.x);  // -i * (a1 - a3)
+        float2 o0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+        float2 o1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+        float2 o2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+        float2 o3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+        if (st < 3) {
+          o1 = cmul(o1, tws[st][0]);
+          o2 = cmul(o2, tws[st][1]);
+          o3 = cmul(o3, tws[st][2]);
+          z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
+        } else {
+          // positions 4 lane + m hold X[rev4(4 lane + m)] = X[64 m + rev3(lane)]: stored in natural order
+          z[pz(rev3)] = o0; z[pz(64 + rev3)] = o1; z[pz(128 + rev3)] = o2; z[pz(192 + rev3)] = o3;
+        }
       }
       wave_sync();
     }
     // ---- real-FFT untangle + power (fbank.h:173-175): X[k] = (Zk + conj(Zn))/2 - i w^k (Zk - conj(Zn))/2
-    float pw[4];
+    float pw[FW][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int k = lane + 64 * m;
-      const float2 zk = z[pz(k)];
-      const float2 zn = z[pz((256 - k) & 255)];
-      const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      const float2 o = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-      const float2 wo = cmul(twu[m], o);
-      const float xr = e.x + wo.y, xi = e.y - wo.x;  // e - i*wo
-      pw[m] = xr * xr + xi * xi;
+    for (int w = 0; w < FW; ++w) {
+      const float2* const z = reinterpret_cast<const float2*>(strip + w * kFbankStrip);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = lane + 64 * m;
+        const float2 zk = z[pz(k)];
+        const float2 zn = z[pz((256 - k) & 255)];
+        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 o = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+        const float2 wo = cmul(twu[m], o);
+        const float xr = e.x + wo.y, xi = e.y - wo.x;  // e - i*wo
+        pw[w][m] = xr * xr + xi * xi;
+      }
     }
-    wave_sync();                                          // every lane has read its Z values: the strip is free
-    float* const pwr = reinterpret_cast<float*>(z);         // 256 power bins (+ 16 zeros of slack for the padded slots)
+    wave_sync();                                          // every lane has read its Z values: the strips are free
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pwr[lane + 64 * m] = pw[m];
-    if (lane < 16) pwr[256 + lane] = 0.f;
+    for (int w = 0; w < FW; ++w) {
+      float* const pwr = strip + w * kFbankStrip;            // 256 power bins (+ 16 zeros of slack for the padded slots)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) pwr[lane + 64 * m] = pw[w][m];
+      if (lane < 16) pwr[256 + lane] = 0.f;
+    }
     wave_sync();
     // ---- mel (fbank.h:179-186): one slot per lane and round, ascending k, then the slots of a filter in order
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      float e = 0.f;
+    for (int w = 0; w < FW; ++w) {
+      const float* const pwr = strip + w * kFbankStrip;
+      float* const melacc = strip + w * kFbankStrip + 512;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) e = fmaf(sw[r][u], pwr[sfirst[r] + u], e);
-      melacc[lane + 64 * r] = e;                            // slot sums (slots past nslots: 0)
+      for (int r = 0; r < ROUNDS; ++r) {
+        float e = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e = fmaf(sw[r][u], pwr[sfirst[r] + u], e);
+        melacc[lane + 64 * r] = e;                            // slot sums (slots past nslots: 0)
+      }
     }
     wave_sync();
     // ---- log (fbank.h:187-190), store.  Slots are sorted by filter: a filter's slots are neighbours.
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int slot = lane + 64 * r;
-      if (scount[r] > 0) {
-        float e = melacc[slot];
-        for (int n = 1; n < scount[r]; ++n) e += melacc[slot + n];
-        feats[(b * nframes + fr) * P.num_bins + sbin[r]] = logf(fmaxf(e, FLT_EPSILON));
+    for (int w = 0; w < FW; ++w) {
+      int b = ub, fr = ufr + w;
+      if (fr >= nframes) { fr -= nframes; ++b; }
+      if (b < B) {
+        const int64_t g = int64_t(b) * nframes + fr;
+        const float* const melacc = strip + w * kFbankStrip + 512;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+          const int slot = lane + 64 * r;
+          if (scount[r] > 0) {
+            float e = melacc[slot];
+            for (int n = 1; n < scount[r]; ++n) e += melacc[slot + n];
+#ifdef WEKWS_FBANK_FASTLOG
+            feats[g * P.num_bins + sbin[r]] = __logf(fmaxf(e, FLT_EPSILON));
+#else
+            feats[g * P.num_bins + sbin[r]] = logf(fmaxf(e, FLT_EPSILON));
+#endif
+          }
+        }
       }
     }
     wave_sync();
+    ub = nb; ufr = nfr;
   }
 }
 
@@ -359,7 +439,7 @@ template <typename S>
 inline int fbank_resident_groups(const FbankParams& P) {
   const int rounds = (P.nslots + 63) / 64;
   if (rounds < 1 || rounds > 3) return 0;
-  const size_t lds = size_t(kFbankWaves * kFbankStrip) * sizeof(float);
+  const size_t lds = size_t(kFbankWaves * kFbankFW * kFbankStrip) * sizeof(float);
   auto kern = rounds == 1 ? fbank_kernel<1, S> : rounds == 2 ? fbank_kernel<2, S> : fbank_kernel<3, S>;
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
@@ -374,9 +454,9 @@ inline int launch_fbank(const FbankParams& P, const S* pcm, int B, int nsamp, in
                         hipStream_t stream) {
   const int rounds = (P.nslots + 63) / 64;
   if (rounds < 1 || rounds > 3) return -4;
-  const size_t lds = size_t(kFbankWaves * kFbankStrip) * sizeof(float);
+  const size_t lds = size_t(kFbankWaves * kFbankFW * kFbankStrip) * sizeof(float);
   const int64_t total = int64_t(B) * nframes;
-  int64_t grid = (total + kFbankWaves - 1) / kFbankWaves;
+  int64_t grid = (total + kFbankWaves * kFbankFW - 1) / (kFbankWaves * kFbankFW);
   auto kern = rounds == 1 ? fbank_kernel<1, S> : rounds == 2 ? fbank_kernel<2, S> : fbank_kernel<3, S>;
   if (resident > 0 && grid > resident) grid = resident;
   hipLaunchKernelGGL(kern, dim3(unsigned(grid)), dim3(64 * kFbankWaves), lds, stream, P, pcm, B, nsamp, nframes, feats);

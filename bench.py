@@ -284,6 +284,37 @@ def cpu_pinned_rows(model_name, T, budget_s=3.0):
     return rows, len(cores)
 
 
+def cpu_sharded_row(model_name, T, budget_s=4.0, threads=4, max_procs=64):
+    """The CPU deployment that corresponds to the GPU ranks: P worker PROCESSES, each with `threads` OpenMP threads pinned to
+    its own physical cores, every process running its own share of the utterances (no cross-process traffic, like the
+    forward across GPUs).  utts/s = all utterances / the slowest worker's time."""
+    cores = physical_cores()
+    P = min(max_procs, len(cores) // threads)
+    if P < 2:
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", MKL_NUM_THREADS=str(threads))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{model_name},{threads},{T},{budget_s}"]
+    procs = []
+    try:
+        for i in range(P):
+            sel = cores[i * threads:(i + 1) * threads]
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                          preexec_fn=(lambda s=sel: os.sched_setaffinity(0, s))))
+        utts, secs = 0, 0.0
+        for pr in procs:
+            out, _ = pr.communicate(timeout=180)
+            rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+            utts += rec["utts"]
+            secs = max(secs, rec["seconds"])
+        return {"processes": P, "threads_per_process": threads, "cores": P * threads, "utts_per_s": round(utts / secs, 1),
+                "sample_s": round(secs, 2)}
+    except Exception as e:                                    # (report, do not fail the bench line)
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        return {"processes": P, "threads_per_process": threads, "error": str(e)[:200]}
+
+
 def cpu_baseline(cfg, sd, T, idim, model_name="ds_tcn_h256"):
     """The reference's CPU path on this box's host cores, bounded to ~25 s: oracle/torch_ref.py issues the
     ATen CPU operator sequence of the reference's PyTorch forward (the reference tree does not travel to the GPU box)."""
@@ -331,10 +362,18 @@ def cpu_baseline(cfg, sd, T, idim, model_name="ds_tcn_h256"):
         if r.get("utts_per_s", 0) > value:
             value, vcores, how = r["utts_per_s"], int(k), (f"{k} threads pinned one per physical core "
                                                            "(OMP_PROC_BIND=close, OMP_PLACES=cores, affinity set)")
+    sharded = cpu_sharded_row(model_name, T)
+    if sharded:
+        rows["process_sharded"] = sharded
+        if sharded.get("utts_per_s", 0) > value:
+            value, vcores = sharded["utts_per_s"], int(sharded["cores"])
+            how = (f"{sharded['processes']} processes x {sharded['threads_per_process']} pinned threads, utterances split over the "
+                   "processes as over GPU ranks")
     return {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port",
             "sample": f"batches of T={T} utterances through oracle/torch_ref.py -- the reference's PyTorch CPU operator sequence "
                       f"(F.linear / conv1d / batch_norm, fp32) -- for 3 .. 8 s per row; reported: {how}; host has {ncpu} hardware "
-                      f"threads on {nphys} physical cores (of those this process may use)",
+                      f"threads on {nphys} physical cores (of those this process may use); the port against the real "
+                      "KWSModel.forward on the build box: profiles/r04_cpu_port_vs_reference.json",
             "rows": rows}
 
 

@@ -59,7 +59,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832, "gru_2x128": 39_588_864}  # SURVEY.md 8d (T = 98)
+FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832, "gru_2x128": 39_588_864,  # SURVEY.md 8d (T = 98)
+                "mdtc_small": 5_889_408,
+                "ds_tcn_h64": 2 * 98 * (40 * 64 + 4 * (8 * 64 + 64 * 64) + 64)}                # = 4,126,976 (hey_snips ds_tcn.yaml)
 BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4          # features in + posteriors out = 16,464 B
 CACHE_BYTES_PER_UTT = 256 * 105 * 4                # the (256, 105) streaming cache forward() also returns
 CACHE_BYTES = {"ds_tcn_h256": 256 * 105 * 4, "mdtc_h64": 64 * 244 * 4, "gru_2x128": 2 * 128 * 4}   # per utterance / stream
@@ -546,6 +548,10 @@ def main():
             # the DS-TCN: the DS-TCN is `value`; the MDTC 4x4 h64 recipe on the same batch is reported beside it.
             out["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
             out["score_only"] = secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", B, T, score_only=True)
+            # BASELINE config 3's model as a batch (the layer wavefront, gru_pipe.hip.h) and the small recipes (hey_snips
+            # ds_tcn.yaml, mdtc_small.yaml: the register-resident kernels of round 4), each with its own roofline
+            out["gru"] = secondary(torch, init_model, pack, synth, dev, "gru_2x128", B, T)
+            out["small_recipes"] = {n: secondary(torch, init_model, pack, synth, dev, n, B, T) for n in ("ds_tcn_h64", "mdtc_small")}
             # ---- the other half of the metric: per-frame streaming latency, 10-frame chunks, carried cache
             lat = {"unit": "us per frame (10-frame chunks; median / p10 / p90 over 1000 consecutive chunks, HIP events)"}
             for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):

@@ -34,8 +34,8 @@
 //     so whatever a wave requests behind its own stores waits for their acknowledgement: with write-through stores the
 //     recurrence's step became the acknowledgement latency.  (Observed placement: block b runs on XCD b % 8, so with the
 //     slots padded to a multiple of 8 a slot's stages share an XCD; nothing relies on it.)
-//   * tag = (launch epoch + 1) + round.  The epoch is a word in the workspace that the LAST workgroup to finish advances by
-//     the launch's rounds (one relaxed agent-scope counter) -- nothing depends on a per-launch kernel argument, so a captured
+//   * tag = (launch epoch + 1) + round.  The epoch is a word in the workspace that the LAST workgroup to start advances by
+//     the launch's rounds (one relaxed agent-scope counter; everybody reads the epoch before counting itself in) -- nothing depends on a per-launch kernel argument, so a captured
 //     graph replays correctly.  Granule buffers hold nothing but granules (every odd dword is a tag written by some launch, or
 //     the zero the allocation was cleared to; tags start at 1), so a stale or foreign word cannot pass for the current tag.
 //   * granule buffers are per slot and round parity; before round r >= 2 a producer checks ONE acknowledgement word (the tag of
@@ -58,6 +58,8 @@ constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 *
 constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
 constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
 constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
+constexpr int kGruPipeLds = 128 * 1024;                       // dynamic LDS of a workgroup (one per CU anyway): staging buffers
+                                                              // of stage 0; 16 steps of planes of a time-packed tile
 
 struct GruPipeWorkspace {
   unsigned* ctl;                // control words
@@ -194,6 +196,17 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   unsigned* const ack_out = ctl + 16 + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
   const unsigned* const ack_in = ctl + 16 + slot * kGruPipeStages + stage;                    // what its consumer has finished reading
   const unsigned tag0 = gp_ld_ctl(ctl) + 1u;                // tag of round 0
+  // The LAST workgroup to get here advances the epoch by the tags this launch uses.  Every workgroup has read the epoch
+  // (above: the value is back before the atomic is issued) before it counts itself in, so the one that counts last knows
+  // that nobody will read it again in this launch -- and no atomic round trip sits at the END of the launch, where a
+  // 10-frame chunk would pay ~1 us for it.
+  if (tid == 0) {
+    const unsigned nwg = unsigned(2 * P.nlayers * slots);
+    if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1u) {
+      __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl, tag0 - 1u + unsigned(rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
   unsigned* const where = ctl + 16 + (kGruPipeMaxSlots + slot) * kGruPipeStages;   // [stage] of this slot
@@ -235,18 +248,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x200u + unsigned(stage); break; }
     }
   };
-  auto finish = [&]() __attribute__((always_inline)) {
-    // the last workgroup to finish advances the epoch by the tags this launch used
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned nwg = unsigned(2 * L * slots);
-      if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1u) {
-        __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ctl, tag0 - 1u + unsigned(rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
-
   if (stage == 0) {
     // ============ stage PI: in0[t] = [ReLU](Wpre x[t] + b) (subsampling.py:53-57), gi0[t] = W_ih0 in0[t] + b ============
     F16Frag a[NKP];
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;
         const int TP = 16 >> psh;
         const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
-        char* const seq0 = WS.seq_in + size_t(slot) * T * SEQ;
+        // (the planes between P and I0: in LDS when all T steps fit -- the streaming chunks --, else in the workspace)
+        char* const seq0 = size_t(T) * SEQ <= size_t(kGruPipeLds) ? gp_lds : WS.seq_in + size_t(slot) * T * SEQ;
         float* const sc = WS.sc + size_t(slot) * T * 16;
         for (int t0 = 0; t0 < T; t0 += TP) {
           const int t = t0 + pdt;
@@ -492,7 +494,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       }
       __syncthreads();                                        // (staging buffers free for the next tile)
     }
-    finish();
     return;
   }
 
@@ -839,7 +840,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  finish();
 }
 
 // ---- geometry of one call: stream slots per workgroup, tiles, resident slots ----
@@ -896,8 +896,9 @@ inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, co
   // <2>: at most two K steps of features in whole, 16-byte aligned octets (the 40-d / 64-d front ends); <4>: anything else
   const bool k2 = Q.kpre16 <= 64 && Q.base.idim % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
   auto kern = k2 ? gru_pipe_kernel<2> : gru_pipe_kernel<4>;
-  if (grant_dynamic_lds(kern, int(G::LDS_BYTES), k2 ? grant2 : grant4)) return -3;
-  hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), G::LDS_BYTES, stream, Q, ws, x, B, T, h0, y, hn,
+  static_assert(kGruPipeLds >= int(G::LDS_BYTES), "staging buffers");
+  if (grant_dynamic_lds(kern, kGruPipeLds, k2 ? grant2 : grant4)) return -3;
+  hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), kGruPipeLds, stream, Q, ws, x, B, T, h0, y, hn,
                      g.tiles, g.slots, g.slots_p, g.spw);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

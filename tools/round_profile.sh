@@ -16,10 +16,16 @@ tools/pmc.sh hl python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup
 tools/pmc.sh hl32 python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 --precision f32 > /dev/null
 tools/pmc.sh md python bench.py --model mdtc_h64 --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
 tools/pmc.sh gru python bench.py --model gru_2x128 --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
+tools/pmc.sh d64 python bench.py --model ds_tcn_h64 --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
+tools/pmc.sh m32 python bench.py --model mdtc_small --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
+tools/pmc.sh fb python tools/probe/run_fbank.py > /dev/null
 python tools/prof_summary.py $(find $out -path "*prof_hl_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h256_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_gru_*" -name "*_results.db" | sort) > $out/${tag}_gru_2x128_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_md_*" -name "*_results.db" | sort) > $out/${tag}_mdtc_h64_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_hl32_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h256_f32.txt
+python tools/prof_summary.py $(find $out -path "*prof_d64_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h64_f16x3.txt
+python tools/prof_summary.py $(find $out -path "*prof_m32_*" -name "*_results.db" | sort) > $out/${tag}_mdtc_small_f16x3.txt
+python tools/prof_summary.py $(find $out -path "*prof_fb_*" -name "*_results.db" | sort) > $out/${tag}_fbank.txt
 python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=profiles/${tag}_ds_tcn_h256_f16x3.txt ds_tcn_h256/B1024/f32=hl32=profiles/${tag}_ds_tcn_h256_f32.txt mdtc_h64/B1024/f16x3=md=profiles/${tag}_mdtc_h64_f16x3.txt > $out/${tag}_pmc_traffic.log 2>&1
 cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 # streaming kernels: kernel trace of the many-streams sweep and of the GRU rows

@@ -58,8 +58,9 @@ constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 *
 constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
 constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
 constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
-constexpr int kGruPipeLds = 128 * 1024;                       // dynamic LDS of a workgroup (one per CU anyway): staging buffers
-                                                              // of stage 0; 16 steps of planes of a time-packed tile
+constexpr int kGruPipePlanes = 128 * 1024;                    // staging buffers of stage 0; 16 steps of planes of a time-packed tile
+constexpr int kGruPipeLds = kGruPipePlanes + 1024;            // dynamic LDS of a workgroup (one per CU anyway): the planes, and
+                                                              // behind them the per-column scales of a time-packed tile
 
 struct GruPipeWorkspace {
   unsigned* ctl;                // control words
@@ -117,6 +118,31 @@ __device__ __forceinline__ void gp_ld4(gp_u32x4 (&g)[4], int voff, gp_desc rs) {
 template <int N>
 __device__ __forceinline__ void gp_wait4(gp_u32x4 (&g)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "i"(N) : "memory");
+}
+// The same three with a wave-uniform switch INSIDE the statement (the last layer's early tag check): `if (on) wait` written as
+// two statements in the arms of a branch is what made the compiler move in-flight registers (see the step loop).
+template <int N>
+__device__ __forceinline__ void gp_wait4_if(gp_u32x4 (&g)[4], unsigned on) {           // on ? vmcnt(N) : nothing
+  asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 .Lgpw%=\n\ts_waitcnt vmcnt(%5)\n.Lgpw%=:"
+               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "s"(__builtin_amdgcn_readfirstlane(int(on))), "i"(N) : "memory", "scc");
+}
+__device__ __forceinline__ void gp_ld4_if(gp_u32x4 (&g)[4], int voff, gp_desc rs, unsigned on) {   // on ? request again : nothing
+  asm volatile(
+      "s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lgpl%=\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\t"
+      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
+      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\t"
+      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1\n.Lgpl%=:"
+      : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])
+      : "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(int(on)))
+      : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void gp_wait4_sel(gp_u32x4 (&g)[4], unsigned all) {         // all ? vmcnt(0) : vmcnt(N)
+  asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 .Lgpa%=\n\ts_waitcnt vmcnt(0)\n\ts_branch .Lgpb%=\n"
+               ".Lgpa%=:\n\ts_waitcnt vmcnt(%5)\n.Lgpb%=:"
+               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "s"(__builtin_amdgcn_readfirstlane(int(all))), "i"(N) : "memory", "scc");
 }
 // two 16-byte items at voff, voff + 16
 __device__ __forceinline__ void gp_ld2(gp_u32x4 (&g)[2], int voff, gp_desc rs) {
@@ -250,6 +276,39 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   };
   if (stage == 0) {
     // ============ stage PI: in0[t] = [ReLU](Wpre x[t] + b) (subsampling.py:53-57), gi0[t] = W_ih0 in0[t] + b ============
+    const bool xvec = (idim % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    // this lane's 8 features of K step ks of (stream s, step t); zeros outside
+    auto load_x8 = [&](int s, int t, int ks, bool ok) __attribute__((always_inline)) -> gru_f32x8 {
+      gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int k0 = ks * 32 + lq * 8;
+      if (ok && k0 < idim) {
+        const float* src = x + (int64_t(s) * T + t) * idim + k0;
+        if (xvec && k0 + 8 <= idim) {
+          const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+          v = gru_f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (k0 + j < idim) v[j] = src[j];
+        }
+      }
+      return v;
+    };
+    // A chunk of a few streams is served in ONE time-packed pass, and the whole launch waits for it: its features are the
+    // first thing this stage asks for -- in front of 100 KB of weight fragments and of the handshake (measured at B = 1,
+    // T = 10: layer 0 had its first gate values 4.2 us into the launch, 2.4 us after it was ready for them).
+    gru_f32x8 xfirst[NKP];
+    {
+      const int b0 = slot * spw, nb = min(B, b0 + spw) - b0;
+      const int psh = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : 3;
+      const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
+      const bool cv = slot < tiles && nb <= 8 && pdt < T && pcs < nb;
+#pragma unroll
+      for (int ks = 0; ks < NKP; ++ks) xfirst[ks] = load_x8(b0 + pcs, pdt, ks, cv);
+    }
+    // (... and the consumer's "where" word is requested here and looked at in front of the first store: by then it has
+    // normally been written, and the chunk does not wait for a control word's round trip between its two products)
+    const unsigned where_early = __hip_atomic_load(where + stage + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     F16Frag a[NKP];
     {
       const int nkp = Q.kpre16 / 32;                          // K steps the packed matrix really has (<= NKP: the launcher)
@@ -274,11 +333,17 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     bias[0] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + u0);
     bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
     bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
-    const bool xvec = (idim % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     const float ih_inv = Q.ih_inv_s[0];
-    const bool near = consumer_here();
-    GP_STAMP(15, stage);
-    GP_STAMP(14, near ? 100 + stage : 200 + stage);
+    // (the handshake is asked for in front of the first store: a packed tile has its products to do first)
+    bool near = false, near_known = false;
+    auto ask_near = [&]() __attribute__((always_inline)) {
+      if (near_known) return;
+      const unsigned w = unsigned(__builtin_amdgcn_readfirstlane(int(where_early)));
+      near = (w >> 4) == (tag0 & 0x0fffffffu) ? (w & 15u) == xcc : consumer_here();
+      near_known = true;
+      GP_STAMP(15, stage);
+      GP_STAMP(14, near ? 100 + stage : 200 + stage);
+    };
 
     int round = 0;
 #pragma unroll 1
@@ -288,23 +353,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       const int reg = (round & 1) * slots + slot;
       const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[0] + size_t(reg) * T * GIS, 0, T * GIS, 0x00020000);
       wait_ack(round);
-      // this lane's 8 features of K step ks of (stream s, step t); zeros outside
-      auto load_x8 = [&](int s, int t, int ks, bool ok) __attribute__((always_inline)) -> gru_f32x8 {
-        gru_f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int k0 = ks * 32 + lq * 8;
-        if (ok && k0 < idim) {
-          const float* src = x + (int64_t(s) * T + t) * idim + k0;
-          if (xvec && k0 + 8 <= idim) {
-            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
-            v = gru_f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (k0 + j < idim) v[j] = src[j];
-          }
-        }
-        return v;
-      };
       const bool packed = nb <= 8;
       if (packed) {
         // TIME-PACKED tile (gru_f16.hip.h): the 16 MFMA columns are (step, stream) pairs; P for all steps into the workspace
@@ -313,8 +361,11 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const int TP = 16 >> psh;
         const int pcs = l15 & ((1 << psh) - 1), pdt = l15 >> psh;
         // (the planes between P and I0: in LDS when all T steps fit -- the streaming chunks --, else in the workspace)
-        char* const seq0 = size_t(T) * SEQ <= size_t(kGruPipeLds) ? gp_lds : WS.seq_in + size_t(slot) * T * SEQ;
-        float* const sc = WS.sc + size_t(slot) * T * 16;
+        // (... and with them the columns' scales: read back from the workspace they cost the chunk a store's acknowledgement
+        // plus a load's round trip between the two products)
+        const bool in_lds = size_t(T) * SEQ <= size_t(kGruPipePlanes);
+        char* const seq0 = in_lds ? gp_lds : WS.seq_in + size_t(slot) * T * SEQ;
+        float* const sc = in_lds ? reinterpret_cast<float*>(gp_lds + kGruPipePlanes) : WS.sc + size_t(slot) * T * 16;
         for (int t0 = 0; t0 < T; t0 += TP) {
           const int t = t0 + pdt;
           const bool cv = t < T && pcs < nb;                    // this column exists
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           float ax = 0.f;
 #pragma unroll
           for (int ks = 0; ks < NKP; ++ks) {
-            xr[ks] = load_x8(b0 + pcs, t, ks, cv);
+            xr[ks] = (round == 0 && t0 == 0) ? xfirst[ks] : load_x8(b0 + pcs, t, ks, cv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xr[ks][j]));
           }
@@ -353,6 +404,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         }
         __threadfence_block();
         __syncthreads();
+        ask_near();
         for (int t0 = 0; t0 < T; t0 += TP) {
           const int t = t0 + pdt, tc = min(t, T - 1);
           const bool cv = t < T && pcs < nb;
@@ -374,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           }
         }
       } else {
+        ask_near();
         // CS steps at a time through LDS staging buffers (operand planes): while I0 multiplies chunk c, P makes chunk c + 1 in
         // the other buffer -- one barrier per chunk
         constexpr int CS = G::CS, CHUNK = CS * SEQ;
@@ -512,6 +565,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     }
     const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
     const bool near = !last && consumer_here();
+    // (Two waves share a SIMD, and a step is 36 MFMAs followed by ~25 transcendental and ~60 plain VALU instructions per
+    // wave; a priority for one of the two -- its cell math under the other's products -- measured nothing.)
     // Last layer with a keyword-sized head (K <= 16: one o-tile): y(t - 1) = [sigmoid](Wc h(t - 1) + bc) needs exactly the B
     // fragments of h(t - 1) every wave reads for its recurrent product anyway -- wave t mod 8 adds the head's 12 MFMAs to
     // step t.  No separate head pass, no copy of the sequence in global memory, no trip to L2 behind the last step.
@@ -587,9 +642,25 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       load_g(gb, 1);
       __syncthreads();
       unsigned spins = 0;
+      // The LAST layer's gate values come from a stage that is barely one step ahead when a single chunk is being served
+      // (B = 1, T = 10: the request two steps ahead returned the previous launch's granules on EVERY step, and the second
+      // request cost the step its round trip behind the products: 1.48 us per step against 1.16 in layer 0).  It therefore
+      // looks at the tags BEFORE the products and, if they are old, asks again at once -- the round trip runs under the
+      // MFMAs.  Other layers keep the late look: their state stores sit in front of the requests in vmcnt's order, and an
+      // early wait would expose the acknowledgement the products hide.
+      const unsigned early = last ? 1u : 0u;
       auto step = [&](int t, gp_u32x4 (&g0)[4]) __attribute__((always_inline)) {
         GP_STAMP(4 * l + 3, t);
-        const char* hbp = gp_lds + (t & 1) * 2 * PH + frag;           // image of h(t-1)
+        const char* hbp = gp_lds + (t & 1) * 2 * PH + frag;           // image of h(t-1); requested in front of the look
+        f16x8 hh[4], hl[4];                                           // (K steps 0 and 1: registers for more there are not)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          hh[ks] = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
+          hl[ks] = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
+        }
+        gp_wait4_if<4>(g0, early);
+        const unsigned again = (early && !tags_ok(g0)) ? 1u : 0u;
+        gp_ld4_if(g0, t * GIS + gvo, ds_g, again);
         char* const hw = gp_lds + ((t + 1) & 1) * 2 * PH;             // image of h(t)
         f32x4 acc[3];
 #pragma unroll
@@ -597,12 +668,15 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const bool my_head = head_in && t > 0 && (t & 7) == wave;     // (wave-uniform)
         f32x4 acch = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const f16x8 hh = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
-          const f16x8 hl = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
+        for (int ks = 2; ks < 4; ++ks) {
+          hh[ks] = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
+          hl[ks] = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
+        }
 #pragma unroll
-          for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wh[g][ks], hh, hl);
-          if (my_head) gru_mfma1(acch, ahd[ks], hh, hl);
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wh[g][ks], hh[ks], hl[ks]);
+          if (my_head) gru_mfma1(acch, ahd[ks], hh[ks], hl[ks]);
         }
         if (my_head) put_y(acch, t - 1);
         GP_STAMP(4 * l + 4, t);
@@ -610,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         // step t - 1 and four more requests (step t + 1; past the end, the last step again) -- which alone may still be out.
         // ONE wait statement for every step: two (vmcnt(6) / vmcnt(0) in the arms of a branch) made the compiler COPY the
         // registers -- before the wait, i.e. before the data had landed -- on the last step (wrong h_n in one tile in ~20).
-        gp_wait4<4>(g0);
+        gp_wait4_sel<4>(g0, again);
         // are they there?  (upstream runs ahead: normally yes)
         if (!tags_ok(g0)) {
           do {

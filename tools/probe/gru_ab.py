@@ -18,7 +18,7 @@ def main():
     for name in names:
         cfg, m = build(name)
         L = cfg["backbone"]["num_layers"]
-        for B, T in ((1, 10), (256, 10), (1024, 98)):
+        for B, T in ((1, 10), (256, 10), (256, 98), (1024, 98), (4096, 98)):
             x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=1)).cuda()
             h = torch.zeros(L, B, 128, device="cuda")
             row = dict(model=name, B=B, T=T)

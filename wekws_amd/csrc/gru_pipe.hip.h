@@ -177,6 +177,13 @@ __device__ __forceinline__ void gp_waitx16(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (
                : "i"(N)
                : "memory");
 }
+// one step's four: exact ? vmcnt(N) : vmcnt(0), one statement (see gp_wait4_sel)
+template <int N>
+__device__ __forceinline__ void gp_waitx4_sel(f32x4 (&a)[4], unsigned exact) {
+  asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 .Lgpx%=\n\ts_waitcnt vmcnt(%5)\n\ts_branch .Lgpy%=\n"
+               ".Lgpx%=:\n\ts_waitcnt vmcnt(0)\n.Lgpy%=:"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "s"(__builtin_amdgcn_readfirstlane(int(exact))), "i"(N) : "memory", "scc");
+}
 // 16-byte store: default policy (the consumer shares this XCD's L2) or write-through
 __device__ __forceinline__ void gp_st16(gp_u32x4 v, __amdgpu_buffer_rsrc_t rs, int off, bool same_xcd) {
   if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
@@ -472,9 +479,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         float inv_c[CS], inv_n[CS];
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) inv_n[dt] = 1.f;
-        auto p_chunk = [&](int t0, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
-#pragma unroll
-          for (int dt = 0; dt < CS; ++dt) {
+        auto p_step = [&](int t0, int dt, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
+          {
             const int t = t0 + dt;
             inv[dt] = 1.f;
             if (t < T) {
@@ -507,42 +513,77 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             }
           }
         };
-        GP_STAMP(0, 0);
-        p_chunk(0, gp_lds, inv_c);
-        gp_barrier();
-        for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
-          const char* const buf = gp_lds + (c & 1) * CHUNK;
-          GP_STAMP(1, t0);
-          if (t0 + CS < T) x_chunk(t0 + CS);
+        auto p_chunk = [&](int t0, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int dt = 0; dt < CS; ++dt) {
-            const int t = t0 + dt;
-            if (t < T) {
-              f32x4 acc[3];
+          for (int dt = 0; dt < CS; ++dt) p_step(t0, dt, buf, inv);
+        };
+        // gi0 of step t0 + dt from the planes of chunk buffer `buf`
+        auto i_step = [&](int t0, int dt, const char* buf) __attribute__((always_inline)) {
+          const int t = t0 + dt;
+          if (t < T) {
+            f32x4 acc[3];
 #pragma unroll
-              for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-              const char* p = buf + dt * SEQ + frag;
+            for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* p = buf + dt * SEQ + frag;
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
+            for (int ks = 0; ks < 4; ++ks) {
+              const f16x8 bh = *reinterpret_cast<const f16x8*>(p + ks * KSB);
+              const f16x8 bl = *reinterpret_cast<const f16x8*>(p + PH + ks * KSB);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
-              }
-              const float cin = inv_c[dt] * ih_inv;
-              const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
-              gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
+              for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
             }
+            const float cin = inv_c[dt] * ih_inv;
+            const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
+            gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
           }
-          GP_STAMP(2, t0);
-          if (t0 + CS < T) {
-            // behind the requests: exactly the 16 stores of a full chunk
-            if constexpr (XF) gp_waitx16<16>(xq[0], xq[1], xq[2], xq[3]);
-            p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
-          }
-#pragma unroll
-          for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
+        };
+        p_chunk(0, gp_lds, inv_c);
+        if constexpr (XF) {
+          // P(c + 1) and I0(c) do not depend on each other: they are INTERLEAVED step by step.  Measured at B = 1024 with the
+          // two as separate phases (stamps, round 4): the stage was the slowest of the pipeline at 9.8 us per chunk -- I0 is
+          // bound by the CU's store issue (128 wave-stores, the next chunk's feature requests queueing behind them for 2 us),
+          // P by the vector pipe with the matrix pipe idle, and 1.5 us of every chunk went into the skew at the barrier.
+          // A step's four feature requests are re-issued as soon as P has consumed the registers -- for the step one chunk on
+          // -- so a request is a whole iteration old when it is waited for: behind it the wave has issued exactly
+          // 4 stores + 3 x (4 requests + 4 stores) + the dt x (4 + 4) of this iteration = 28 operations whatever dt is.  (The
+          // first iteration's requests come from the prologue, with fewer behind them: it waits for everything.)
+          if (CS < T) x_chunk(CS);
           gp_barrier();
+          for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
+            const char* const buf = gp_lds + (c & 1) * CHUNK;
+            char* const nbuf = gp_lds + ((c + 1) & 1) * CHUNK;
+            const bool more = t0 + CS < T;                        // (then this chunk is a full one: all its stores are issued)
+            GP_STAMP(1, t0);
+#pragma unroll
+            for (int dt = 0; dt < CS; ++dt) {
+              if (more) {
+                gp_waitx4_sel<28>(xq[dt], c > 0 ? 1u : 0u);
+                p_step(t0 + CS, dt, nbuf, inv_n);
+                const int64_t to = int64_t(min(t0 + 2 * CS + dt, T - 1)) * idim;
+                gp_ldx4(xq[dt], xp0 + to, xp1 + to);
+              }
+              i_step(t0, dt, buf);
+            }
+            GP_STAMP(2, t0);
+#pragma unroll
+            for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
+            gp_barrier();
+          }
+          gp_waitx16<0>(xq[0], xq[1], xq[2], xq[3]);            // (the last iteration's requests: nothing may still be landing)
+        } else {
+          gp_barrier();
+          for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
+            const char* const buf = gp_lds + (c & 1) * CHUNK;
+            GP_STAMP(1, t0);
+            if (t0 + CS < T) x_chunk(t0 + CS);
+#pragma unroll
+            for (int dt = 0; dt < CS; ++dt) i_step(t0, dt, buf);
+            GP_STAMP(2, t0);
+            if (t0 + CS < T) p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+#pragma unroll
+            for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
+            gp_barrier();
+          }
         }
       }
       __syncthreads();                                        // (staging buffers free for the next tile)

@@ -50,10 +50,14 @@ namespace wekws {
 
 constexpr int kGruPipeStages = 2 * kGruMaxLayers;
 constexpr int kGruPipeMaxSlots = 128;
+// Granule buffers are RINGS of kGruPipeRing steps per slot (round 4: with one buffer position per step of the call, B = 1024 x
+// 98 frames wrote 504 MB and fetched 524 MB per launch -- PMC -- i.e. 5 TB/s of HBM traffic for intermediates that live a few
+// microseconds; a ring of 16 steps is 1.25 MB per slot and stays in L2 / the memory-side cache).
+constexpr int kGruPipeRingLog = 4, kGruPipeRing = 1 << kGruPipeRingLog;
 // control words (their own allocation per stream, zero when made, never re-allocated): [0] epoch, [1] workgroups done, [2] error,
-// [16 + slot * stages + stage] acknowledgements,
-// [16 + (slots + slot) * stages + stage] where the workgroup runs: tag0 << 4 | XCD
-constexpr int kGruPipeCtlWords = 16 + 2 * kGruPipeMaxSlots * kGruPipeStages;
+// [16 + 2 (slot * stages + stage)] 64-bit credits: {tag0, steps of this launch the stage's consumer has finished reading},
+// [16 + 2 slots * stages + slot * stages + stage] where the workgroup runs: tag0 << 4 | XCD
+constexpr int kGruPipeCtlWords = 16 + 3 * kGruPipeMaxSlots * kGruPipeStages;
 constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
 constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
 constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
@@ -67,7 +71,7 @@ struct GruPipeWorkspace {
   char* seq_in;                 // [slot][T] time-packed tiles only: preprocessing output planes (stage 0 internal)
   char* seq_top;                // [slot][T] last layer's output planes (read back by its own workgroup's head pass)
   float* sc;                    // [slot][T][16] time-packed tiles only: 1 / scale of the preprocessing output
-  char* gi[kGruMaxLayers];      // granules [region][T][kGruPipeGiStep]: gate pre-activations of layer l
+  char* gi[kGruMaxLayers];      // granules [slot][kGruPipeRing][kGruPipeGiStep]: gate pre-activations of layer l
   char* hs[kGruMaxLayers];      // granules [region][T][kGruPipeHStep]: output sequence of layer l (l < L - 1)
 };
 
@@ -85,6 +89,11 @@ constexpr int kGpSc1 = 16;                                    // buffer aux bit:
 __device__ __forceinline__ unsigned gp_min3(unsigned a, unsigned b, unsigned c) { return min(a, min(b, c)); }
 __device__ __forceinline__ unsigned gp_ld_ctl(const unsigned* p) {
   return unsigned(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+}
+__device__ __forceinline__ unsigned long long gp_ld_ctl64(const unsigned long long* p) {
+  const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(v)))) |
+         ((unsigned long long)unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(v >> 32)))) << 32);
 }
 // Barrier of the per-step loops: orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0)` + s_barrier on
 // this target (the workgroup-scope fence covers global memory): every step then waited for the gate values requested two
@@ -226,9 +235,11 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   const int gvo = wave * 4096 + lane * 16;                  // this lane's first gate granule inside a step (+ item * 1024)
   const int rounds = (tiles + slots - 1) / slots;
   unsigned* const ctl = WS.ctl;
-  unsigned* const ack_out = ctl + 16 + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
-  const unsigned* const ack_in = ctl + 16 + slot * kGruPipeStages + stage;                    // what its consumer has finished reading
-  const unsigned tag0 = gp_ld_ctl(ctl) + 1u;                // tag of round 0
+  constexpr int RING = kGruPipeRing, RLOG = kGruPipeRingLog;
+  unsigned long long* const cred = reinterpret_cast<unsigned long long*>(ctl + 16);
+  unsigned long long* const cred_out = cred + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
+  const unsigned long long* const cred_in = cred + slot * kGruPipeStages + stage;                    // what its consumer has finished reading
+  const unsigned tag0 = gp_ld_ctl(ctl) + 1u;                // tag of this launch's first lap of the rings
   // The LAST workgroup to get here advances the epoch by the tags this launch uses.  Every workgroup has read the epoch
   // (above: the value is back before the atomic is issued) before it counts itself in, so the one that counts last knows
   // that nobody will read it again in this launch -- and no atomic round trip sits at the END of the launch, where a
@@ -237,22 +248,55 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     const unsigned nwg = unsigned(2 * P.nlayers * slots);
     if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1u) {
       __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctl, tag0 - 1u + unsigned(rounds), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned laps = unsigned((rounds * T - 1) >> RLOG) + 1u;   // a slot's steps are numbered g = round * T + t
+      __hip_atomic_store(ctl, tag0 - 1u + laps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  unsigned* const where = ctl + 16 + (kGruPipeMaxSlots + slot) * kGruPipeStages;   // [stage] of this slot
+  unsigned* const where = ctl + 16 + (2 * kGruPipeMaxSlots + slot) * kGruPipeStages;   // [stage] of this slot
   if (tid == 0) __hip_atomic_store(where + stage, (tag0 << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // does this stage's consumer run on this XCD?  asked after the weights have been requested; gives up after ~20 us (the
   // consumer may not be resident yet: write-through stores are right wherever it turns up)
-  auto consumer_here = [&]() __attribute__((always_inline)) -> bool {
+  auto peer_here = [&](int st) __attribute__((always_inline)) -> bool {
     for (int i = 0; i < 48; ++i) {
-      const unsigned w = gp_ld_ctl(where + stage + 1);
+      const unsigned w = gp_ld_ctl(where + st);
       if ((w >> 4) == (tag0 & 0x0fffffffu)) return (w & 15u) == xcc;
       __builtin_amdgcn_s_sleep(8);
     }
     return false;
+  };
+  auto consumer_here = [&]() __attribute__((always_inline)) -> bool { return peer_here(stage + 1); };
+  // Step g (= round * T + t) of a slot lives at ring position g mod RING and carries the tag of its lap; a position is
+  // written again RING steps later, when the consumer has said that it is through with it: a CREDIT word per (slot, stage)
+  // = {tag0 of the launch, steps finished}, published every few steps.  A word of another launch never matches tag0; the
+  // first RING steps of a launch need no credit (what the ring holds then is of earlier launches: finished, in stream order).
+  auto lap_tag = [&](int g) __attribute__((always_inline)) -> unsigned { return tag0 + unsigned(g >> RLOG); };
+  auto ring_pos = [&](int g) __attribute__((always_inline)) -> int { return g & (RING - 1); };
+  unsigned credit = 0;                                        // steps the consumer is known to have finished
+  auto wait_credit = [&](int g) __attribute__((always_inline)) {   // before step g is written
+    const unsigned need = unsigned(g - RING + 1);
+    if (g < RING || credit >= need) return;
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned long long c = gp_ld_ctl64(cred_in);
+      if (unsigned(c >> 32) == tag0) {
+        credit = unsigned(c);
+        if (credit >= need) break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x200u + unsigned(stage); break; }
+    }
+  };
+  // this stage has finished reading its input up to (not including) step g; the store goes where the producer's loads look
+  const auto rs_cred = __builtin_amdgcn_make_buffer_rsrc(cred_out, 0, 8, 0x00020000);
+  auto publish = [&](int g, bool same_xcd) __attribute__((always_inline)) {
+    if (tid == 0) {
+      typedef unsigned gp_u32x2 __attribute__((ext_vector_type(2)));
+      const gp_u32x2 v = {unsigned(g), tag0};
+      if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(v, rs_cred, 0, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b64(v, rs_cred, 0, 0, kGpSc1);
+    }
   };
 
   __shared__ AmaxCell gp_cell;
@@ -270,16 +314,6 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     amax_publish(&gp_cell, m);
     __syncthreads();
     return fmaxf(1.f, amax_read(&gp_cell));
-  };
-  // before writing round r >= 2 into the region of round r - 2: the consumer must have finished that round
-  auto wait_ack = [&](int r) __attribute__((always_inline)) {
-    if (r < 2) return;
-    const unsigned need = tag0 + unsigned(r) - 2u;
-    unsigned spins = 0;
-    while (int(gp_ld_ctl(ack_in) - need) < 0) {
-      __builtin_amdgcn_s_sleep(32);
-      if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x200u + unsigned(stage); break; }
-    }
   };
   if (stage == 0) {
     // ============ stage PI: in0[t] = [ReLU](Wpre x[t] + b) (subsampling.py:53-57), gi0[t] = W_ih0 in0[t] + b ============
@@ -356,10 +390,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
 #pragma unroll 1
     for (int tile = slot; tile < tiles; tile += slots, ++round) {
       const int b0 = tile * spw, bend = min(B, b0 + spw), nb = bend - b0;
-      const unsigned tag = tag0 + unsigned(round);
-      const int reg = (round & 1) * slots + slot;
-      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[0] + size_t(reg) * T * GIS, 0, T * GIS, 0x00020000);
-      wait_ack(round);
+      const int gb0 = round * T;                                // number of this tile's step 0 in the slot's stream of steps
+      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[0] + size_t(slot) * RING * GIS, 0, RING * GIS, 0x00020000);
       const bool packed = nb <= 8;
       if (packed) {
         // TIME-PACKED tile (gru_f16.hip.h): the 16 MFMA columns are (step, stream) pairs; P for all steps into the workspace
@@ -427,9 +459,10 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             for (int g = 0; g < 3; ++g) gru_mfma1(acc[g], wi[g][ks], bh, bl);
           }
           const float cin = sc[tc * 16 + pcs] * ih_inv;
+          wait_credit(gb0 + min(t0 + TP, T) - 1);
           if (cv) {                                             // into the slot the recurrence's lane (stream pcs, same lq) reads
             const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
-            gp_st_gates(v, tag, rs_g, t * GIS + wave * 4096 + (lq * 16 + pcs) * 16, near);
+            gp_st_gates(v, lap_tag(gb0 + t), rs_g, ring_pos(gb0 + t) * GIS + wave * 4096 + (lq * 16 + pcs) * 16, near);
           }
         }
       } else {
@@ -534,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             }
             const float cin = inv_c[dt] * ih_inv;
             const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
-            gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
+            gp_st_gates(v, lap_tag(gb0 + t), rs_g, ring_pos(gb0 + t) * GIS + gvo, near);
           }
         };
         p_chunk(0, gp_lds, inv_c);
@@ -554,15 +587,28 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             char* const nbuf = gp_lds + ((c + 1) & 1) * CHUNK;
             const bool more = t0 + CS < T;                        // (then this chunk is a full one: all its stores are issued)
             GP_STAMP(1, t0);
+            wait_credit(gb0 + min(t0 + CS, T) - 1);               // (a poll's loads only add to what is behind the requests)
+            // Waves w and w + 4 share a SIMD: one of the two does its products first and its preprocessing second, the other
+            // the other way round -- P is vector work, I0 matrix work and stores, and with both waves in the same phase the
+            // three times simply added up (1.9 us per step at B = 1024: 0.56 MFMA + 0.8 store issue + 0.53 vector).  The count
+            // behind a step's requests is 28 in either order (16 stores + 12 requests).
+            const bool i_first = wave >= 4;
+            if (i_first) {
 #pragma unroll
-            for (int dt = 0; dt < CS; ++dt) {
-              if (more) {
+              for (int dt = 0; dt < CS; ++dt) i_step(t0, dt, buf);
+            }
+            if (more) {
+#pragma unroll
+              for (int dt = 0; dt < CS; ++dt) {
                 gp_waitx4_sel<28>(xq[dt], c > 0 ? 1u : 0u);
                 p_step(t0 + CS, dt, nbuf, inv_n);
                 const int64_t to = int64_t(min(t0 + 2 * CS + dt, T - 1)) * idim;
                 gp_ldx4(xq[dt], xp0 + to, xp1 + to);
               }
-              i_step(t0, dt, buf);
+            }
+            if (!i_first) {
+#pragma unroll
+              for (int dt = 0; dt < CS; ++dt) i_step(t0, dt, buf);
             }
             GP_STAMP(2, t0);
 #pragma unroll
@@ -575,6 +621,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
             const char* const buf = gp_lds + (c & 1) * CHUNK;
             GP_STAMP(1, t0);
+            wait_credit(gb0 + min(t0 + CS, T) - 1);
             if (t0 + CS < T) x_chunk(t0 + CS);
 #pragma unroll
             for (int dt = 0; dt < CS; ++dt) i_step(t0, dt, buf);
@@ -606,6 +653,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     }
     const f32x4 b_hn = *reinterpret_cast<const f32x4*>(W + gl.b_hh + 2 * H + u0);
     const bool near = !last && consumer_here();
+    const bool near_up = peer_here(stage - 1);                // (credits go the other way: to the producer of this stage's input)
     // (Two waves share a SIMD, and a step is 36 MFMAs followed by ~25 transcendental and ~60 plain VALU instructions per
     // wave; a priority for one of the two -- its cell math under the other's products -- measured nothing.)
     // Last layer with a keyword-sized head (K <= 16: one o-tile): y(t - 1) = [sigmoid](Wc h(t - 1) + bc) needs exactly the B
@@ -631,15 +679,13 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
 #pragma unroll 1
     for (int tile = slot; tile < tiles; tile += slots, ++round) {
       const int b0 = tile * spw, bend = min(B, b0 + spw), nb = bend - b0;
-      const unsigned tag = tag0 + unsigned(round);
-      const int reg = (round & 1) * slots + slot;
+      const int gb0 = round * T;
       const float hb = h_bound(l, b0, bend);
       float chh;
       const float shl = pow2_scale(hb, &chh);
       chh *= Q.hh_inv_s[l];
       char* const sout = WS.seq_top + size_t(slot) * T * SEQ;
-      const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(WS.hs[last ? 0 : l] + size_t(last ? 0 : reg) * T * HSS, 0, last ? 0 : T * HSS, 0x00020000);
-      if (!last) wait_ack(round);
+      const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(WS.hs[last ? 0 : l] + size_t(last ? 0 : slot) * RING * HSS, 0, last ? 0 : RING * HSS, 0x00020000);
       float chd;
       (void)pow2_scale(hb, &chd);
       chd *= Q.head_inv_s;
@@ -671,13 +717,13 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       // gate pre-activations of this lane as granule pairs [gate][half], requested two steps ahead into two buffers that
       // take turns (no copies: whatever is requested behind this wave's stores returns behind their acknowledgement)
       gp_u32x4 ga[4], gb[4];
-      const gp_desc ds_g = gp_make_desc(WS.gi[l] + size_t(reg) * T * GIS, unsigned(T) * GIS);
-      auto load_g = [&](gp_u32x4 (&gg)[4], int t) __attribute__((always_inline)) { gp_ld4(gg, min(t, T - 1) * GIS + gvo, ds_g); };
+      const gp_desc ds_g = gp_make_desc(WS.gi[l] + size_t(slot) * RING * GIS, unsigned(RING) * GIS);
+      auto load_g = [&](gp_u32x4 (&gg)[4], int t) __attribute__((always_inline)) { gp_ld4(gg, ring_pos(gb0 + min(t, T - 1)) * GIS + gvo, ds_g); };
       // a time-packed first stage writes the columns of real streams only: the other lanes' granules never arrive
       const bool live = l > 0 || nb > 8 || l15 < nb;
-      auto tags_ok = [&](const gp_u32x4 (&gg)[4]) __attribute__((always_inline)) -> bool {
+      auto tags_ok = [&](const gp_u32x4 (&gg)[4], unsigned tag) __attribute__((always_inline)) -> bool {
         const unsigned m = min(gp_min3(gg[0][3], gg[1][3], gg[2][3]), gg[3][3]);
-        return !__builtin_amdgcn_ballot_w64(live && m != tag);   // tags only grow: min == tag <=> all == tag
+        return !__builtin_amdgcn_ballot_w64(live && m != tag);   // a position's tags only grow: min == tag <=> all == tag
       };
       load_g(ga, 0);
       load_g(gb, 1);
@@ -699,9 +745,11 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           hh[ks] = *reinterpret_cast<const f16x8*>(hbp + ks * KSB);
           hl[ks] = *reinterpret_cast<const f16x8*>(hbp + PH + ks * KSB);
         }
+        const unsigned tag = lap_tag(gb0 + t);
+        const int g_off = ring_pos(gb0 + t) * GIS + gvo;
         gp_wait4_if<4>(g0, early);
-        const unsigned again = (early && !tags_ok(g0)) ? 1u : 0u;
-        gp_ld4_if(g0, t * GIS + gvo, ds_g, again);
+        const unsigned again = (early && !tags_ok(g0, tag)) ? 1u : 0u;
+        gp_ld4_if(g0, g_off, ds_g, again);
         char* const hw = gp_lds + ((t + 1) & 1) * 2 * PH;             // image of h(t)
         f32x4 acc[3];
 #pragma unroll
@@ -727,15 +775,22 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         // registers -- before the wait, i.e. before the data had landed -- on the last step (wrong h_n in one tile in ~20).
         gp_wait4_sel<4>(g0, again);
         // are they there?  (upstream runs ahead: normally yes)
-        if (!tags_ok(g0)) {
+        if (!tags_ok(g0, tag)) {
+          // about to wait for the producer: it may be waiting for THIS stage's credit (a producer that writes a ring's worth of
+          // steps at once -- the time-packed first stage -- needs every step before this one acknowledged)
+          publish(gb0 + t, near_up);
           do {
             __builtin_amdgcn_s_sleep(2);
             load_g(g0, t);
             gp_wait4<0>(g0);
             if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
-          } while (!tags_ok(g0));
+          } while (!tags_ok(g0, tag));
         }
         GP_STAMP(4 * l + 5, t);
+        // every wave is through with the steps before this one (the barrier that ended step t - 1): tell the producer every
+        // fourth step.  Here -- in front of the cell math -- the store is older than the next request, so the counted waits
+        // stay exact, and it is acknowledged long before the next of them.
+        if ((t & 3) == 0 && t > 0) publish(gb0 + t, near_up);
         // cell math, register-local (PyTorch formulation, gate order r, z, n)
         f32x4 hv;
 #pragma unroll
@@ -764,7 +819,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           const gp_u32x4 hl4 = __builtin_bit_cast(gp_u32x4, __builtin_shufflevector(vh, vl, 0, 1, 2, 3, 4, 5, 6, 7));
           const unsigned p0 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x05040100u), p1 = __builtin_amdgcn_perm(hl4[2], hl4[0], 0x07060302u);
           const unsigned p2 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x05040100u), p3 = __builtin_amdgcn_perm(hl4[3], hl4[1], 0x07060302u);
-          const int vo = t * HSS + (((u0 >> 3) * 16 + l15) * 8 + (u0 & 7)) * 8;
+          const int vo = ring_pos(gb0 + t) * HSS + (((u0 >> 3) * 16 + l15) * 8 + (u0 & 7)) * 8;
+          wait_credit(gb0 + t);
           gp_st16(gp_pair(p0, p1, tag), rs_o, vo, near);
           gp_st16(gp_pair(p2, p3, tag), rs_o, vo + 16, near);
         }
@@ -792,8 +848,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const int s = b0 + l15;
         if (s < bend) *reinterpret_cast<f32x4*>(hn + (int64_t(l) * B + s) * H + u0) = hreg;
       }
-      // every gate value of this round has been read
-      if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      publish(gb0 + T, near_up);                                // every gate value of this tile has been read
       if (last && !head_in) {
         // ================= head: y[t] = [sigmoid](Wc h_top[t] + bc), waves take steps round-robin =================
         __threadfence_block();
@@ -877,6 +932,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     bias[1] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + H + u0) + *reinterpret_cast<const f32x4*>(W + gl.b_hh + H + u0);
     bias[2] = *reinterpret_cast<const f32x4*>(W + gl.b_ih + 2 * H + u0);
     const bool near = consumer_here();
+    const bool near_up = peer_here(stage - 1);
     GP_STAMP(15, stage);
     GP_STAMP(14, near ? 100 + stage : 200 + stage);
 
@@ -884,13 +940,11 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
 #pragma unroll 1
     for (int tile = slot; tile < tiles; tile += slots, ++round) {
       const int b0 = tile * spw, bend = min(B, b0 + spw);
-      const unsigned tag = tag0 + unsigned(round);
-      const int reg = (round & 1) * slots + slot;
+      const int gb0 = round * T;
       float inv_in;
       (void)pow2_scale(h_bound(l - 1, b0, bend), &inv_in);    // scale of the previous layer's planes
       const float cin = inv_in * Q.ih_inv_s[l];
-      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[l] + size_t(reg) * T * GIS, 0, T * GIS, 0x00020000);
-      wait_ack(round);
+      const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[l] + size_t(slot) * RING * GIS, 0, RING * GIS, 0x00020000);
       // One step of the previous layer's state is 16 KB of granules; EVERY wave needs all of it as its B operand.  Eight waves
       // pulling it through the CU's 64 B/clk vector-memory path was 128 KB per step (measured: ~0.9 us of the stage's step), so
       // each wave fetches ONE EIGHTH -- k-octets 2 w and 2 w + 1: lane = (octet, stream, half), four granules = 32 bytes --,
@@ -900,15 +954,17 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       const int pvo = (po * 16 + ps) * 64 + phf * 32;         // this lane's 32 bytes inside a step of granules
       const int pwr = ((po * MB + ps) * 8 + phf * 4) * 2;     // ... and its 4 halves inside a plane
       gp_u32x4 raw[2];
-      const gp_desc ds_i = gp_make_desc(WS.hs[l - 1] + size_t(reg) * T * HSS, unsigned(T) * HSS);
-      auto load_h = [&](int t) __attribute__((always_inline)) { gp_ld2(raw, t * HSS + pvo, ds_i); };
+      const gp_desc ds_i = gp_make_desc(WS.hs[l - 1] + size_t(slot) * RING * HSS, unsigned(RING) * HSS);
+      auto load_h = [&](int t) __attribute__((always_inline)) { gp_ld2(raw, ring_pos(gb0 + t) * HSS + pvo, ds_i); };
       unsigned spins = 0;
       // waits until this wave's share of step t is there, then writes it into plane buffer `buf`; `behind` = this wave has
       // issued the step's four gate stores behind the request (they may stay out)
       auto take = [&](int t, char* buf, bool behind) __attribute__((always_inline)) {
+        const unsigned tag = lap_tag(gb0 + t);
         if (behind) gp_wait2<4>(raw);
         else gp_wait2<0>(raw);
         if (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag)) {
+          publish(gb0 + t, near_up);                            // (as in the recurrence: never wait without having said so)
           do {
             __builtin_amdgcn_s_sleep(2);
             load_h(t);
@@ -930,6 +986,9 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       __syncthreads();
       for (int t = 0; t < T; ++t) {
         GP_STAMP(11, t);
+        // every wave has taken the steps <= t (the barrier that ended the last iteration): tell the producer every fourth
+        // step -- here, so that the store's acknowledgement comes back under the products
+        if ((t & 3) == 3) publish(gb0 + t + 1, near_up);
         const char* p = gp_lds + (t & 1) * 2 * PH + frag;
         f32x4 acc[3];
 #pragma unroll
@@ -943,7 +1002,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         }
         GP_STAMP(12, t);
         const f32x4 v[3] = {acc[0] * cin + bias[0], acc[1] * cin + bias[1], acc[2] * cin + bias[2]};
-        gp_st_gates(v, tag, rs_g, t * GIS + gvo, near);
+        wait_credit(gb0 + t);
+        gp_st_gates(v, lap_tag(gb0 + t), rs_g, ring_pos(gb0 + t) * GIS + gvo, near);
         if (t + 1 < T) {
           take(t + 1, gp_lds + ((t + 1) & 1) * 2 * PH, true);
           if (t + 2 < T) load_h(t + 2);                       // in flight behind the next step's products
@@ -951,15 +1011,15 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         GP_STAMP(13, t);
         gp_barrier();                                         // the planes of step t + 1 are complete; those of step t are free
       }
-      __syncthreads();                                        // every wave has read the whole round
-      if (tid == 0) __hip_atomic_store(ack_out, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();                                        // every wave has read the whole tile
+      publish(gb0 + T, near_up);
     }
   }
 }
 
 // ---- geometry of one call: stream slots per workgroup, tiles, resident slots ----
 struct GruPipeGeom {
-  int stages, spw, tiles, slots, slots_p, regions;
+  int stages, spw, tiles, slots, slots_p;
 };
 inline bool gru_pipe_geom(int nlayers, int B, int T, int cus, GruPipeGeom* g) {
   g->stages = 2 * nlayers;
@@ -976,11 +1036,10 @@ inline bool gru_pipe_geom(int nlayers, int B, int T, int cus, GruPipeGeom* g) {
   g->tiles = (B + spw - 1) / spw;
   g->slots = g->tiles < smax ? g->tiles : smax;
   g->slots_p = (g->slots + 7) / 8 * 8;                       // block b runs on XCD b % 8: a slot's stages share an XCD
-  g->regions = g->tiles > g->slots ? 2 * g->slots : g->slots;
   return true;
 }
 // bytes of one call: the plain workspace behind the control words (seq_in, seq_top, sc: each per slot) and the granule
-// workspace (gi per layer, state granules per layer below the top: each per region)
+// workspace (gi per layer, state granules per layer below the top: a ring per slot each)
 struct GruPipeBytes {
   size_t seq, sc, gi, hs;
   size_t plain() const { return 2 * seq + sc; }
@@ -992,13 +1051,13 @@ inline bool gru_pipe_bytes(int nlayers, int B, int T, int cus, GruPipeBytes* b) 
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   b->seq = al(size_t(g.slots) * T * GruF16Geom<1>::SEQ_STEP);
   b->sc = al(size_t(g.slots) * T * 16 * sizeof(float));
-  b->gi = al(size_t(g.regions) * T * kGruPipeGiStep);
-  b->hs = al(size_t(g.regions) * T * kGruPipeHStep);
+  b->gi = al(size_t(g.slots) * kGruPipeRing * kGruPipeGiStep);
+  b->hs = al(size_t(g.slots) * kGruPipeRing * kGruPipeHStep);
   return true;
 }
-// one region of one buffer must stay below 2 GiB (32-bit buffer offsets)
+// (a slot's steps of one launch are numbered in an int)
 inline bool gru_pipe_supported(const GruF16Params& Q, int T) {
-  return gru_f16_supported(Q) && size_t(T) * kGruPipeGiStep < (size_t(1) << 31);
+  return gru_f16_supported(Q) && T < (1 << 24);
 }
 
 inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, const float* x, int B, int T, const float* h0,

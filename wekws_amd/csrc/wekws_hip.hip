@@ -1251,7 +1251,7 @@ static void reserve_need(const wekws_hip_model* m, int B, int T, size_t* plain, 
     if (k * wgs < B) bs[nb++] = k * wgs;
   if (16 * 256 < B) bs[nb++] = 16 * 256;
   if (m->desc.backbone == WEKWS_HIP_BACKBONE_GRU) {
-    // the wavefront's geometry (gru_pipe_geom): most slots with one stream per tile, most regions beyond 16 streams x slots
+    // the wavefront's geometry (gru_pipe_geom): most slots (= most rings) with one stream per tile
     wekws::GruPipeGeom g;
     if (wekws::gru_pipe_geom(m->desc.num_layers, 1 << 30, 1, m->fsmn_cus, &g)) {
       if (g.slots < B) bs[nb++] = g.slots;

@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from wekws_amd import _capi  # noqa: E402
+if os.environ.get('WEKWS_DBG_LIB'):
+    _capi._LIB_PATH = os.environ['WEKWS_DBG_LIB']
 from tools.bench_configs import build, timeit  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 
@@ -18,7 +21,7 @@ def main():
     for name in names:
         cfg, m = build(name)
         L = cfg["backbone"]["num_layers"]
-        for B, T in ((1, 10), (256, 10), (256, 98), (1024, 98), (4096, 98)):
+        for B, T in ((1, 10), (1, 10), (256, 10), (1024, 98)):
             x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=1)).cuda()
             h = torch.zeros(L, B, 128, device="cuda")
             row = dict(model=name, B=B, T=T)

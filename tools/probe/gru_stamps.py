@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from wekws_amd import _capi  # noqa: E402
-_capi._LIB_PATH = os.path.join(ROOT, "build", "var", "libwekws_stamps.so")
+_capi._LIB_PATH = os.environ.get("WEKWS_DBG_LIB") or os.path.join(ROOT, "build", "var", "libwekws_stamps.so")
 from tools.bench_configs import build  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 

@@ -208,7 +208,11 @@ __device__ __forceinline__ void gp_st_gates(const f32x4 (&v)[3], unsigned tag, _
 // two granules {a, tag}, {b, tag}
 __device__ __forceinline__ gp_u32x4 gp_pair(unsigned a, unsigned b, unsigned tag) { return gp_u32x4{a, tag, b, tag}; }
 
-template <int NKP>                                            // K steps of the preprocessing product (idim <= 32 NKP)
+// NKP: K steps of the preprocessing product (idim <= 32 NKP).  PK: every tile has at most 8 streams (the launches that serve
+// streaming chunks: spw <= 8) -- the first stage then consists of its time-packed path alone.  One kernel with both paths kept
+// a spilled value of the chunked path's 250 registers in the packed path's prologue, reloaded from scratch between the
+// chunk's two products (+0.5 us on a 10-frame chunk).
+template <int NKP, bool PK>
 __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q, const GruPipeWorkspace WS,
                                                             const float* __restrict__ x, int B, int T,
                                                             const float* __restrict__ h0, float* __restrict__ y,
@@ -290,8 +294,10 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   };
   // this stage has finished reading its input up to (not including) step g; the store goes where the producer's loads look
   const auto rs_cred = __builtin_amdgcn_make_buffer_rsrc(cred_out, 0, 8, 0x00020000);
+  // (a launch of at most RING steps per slot -- the streaming chunks -- needs no credits at all)
+  const bool credits = rounds * T > RING;
   auto publish = [&](int g, bool same_xcd) __attribute__((always_inline)) {
-    if (tid == 0) {
+    if (credits && tid == 0) {
       typedef unsigned gp_u32x2 __attribute__((ext_vector_type(2)));
       const gp_u32x2 v = {unsigned(g), tag0};
       if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(v, rs_cred, 0, 0, 0);
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       const int b0 = tile * spw, bend = min(B, b0 + spw), nb = bend - b0;
       const int gb0 = round * T;                                // number of this tile's step 0 in the slot's stream of steps
       const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(WS.gi[0] + size_t(slot) * RING * GIS, 0, RING * GIS, 0x00020000);
-      const bool packed = nb <= 8;
+      const bool packed = PK || nb <= 8;
       if (packed) {
         // TIME-PACKED tile (gru_f16.hip.h): the 16 MFMA columns are (step, stream) pairs; P for all steps into the workspace
         // (this workgroup's own stores and loads), then I0
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             gp_st_gates(v, lap_tag(gb0 + t), rs_g, ring_pos(gb0 + t) * GIS + wave * 4096 + (lq * 16 + pcs) * 16, near);
           }
         }
-      } else {
+      } else if constexpr (!PK) {
         ask_near();
         // CS steps at a time through LDS staging buffers (operand planes): while I0 multiplies chunk c, P makes chunk c + 1 in
         // the other buffer -- one barrier per chunk
@@ -589,9 +595,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             GP_STAMP(1, t0);
             wait_credit(gb0 + min(t0 + CS, T) - 1);               // (a poll's loads only add to what is behind the requests)
             // Waves w and w + 4 share a SIMD: one of the two does its products first and its preprocessing second, the other
-            // the other way round -- P is vector work, I0 matrix work and stores, and with both waves in the same phase the
-            // three times simply added up (1.9 us per step at B = 1024: 0.56 MFMA + 0.8 store issue + 0.53 vector).  The count
-            // behind a step's requests is 28 in either order (16 stores + 12 requests).
+            // the other way round -- P is vector work, I0 matrix work and stores.  The count behind a step's requests is 28
+            // in either order (16 stores + 12 requests).  (+4 % at B = 1024.)
             const bool i_first = wave >= 4;
             if (i_first) {
 #pragma unroll
@@ -1066,12 +1071,13 @@ inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, co
   GruPipeGeom g;
   if (!gru_pipe_geom(Q.base.nlayers, B, T, cus, &g)) return -4;
   using G = GruF16Geom<1>;
-  static DynLdsGrant grant2, grant4;
+  static DynLdsGrant grant[4];
   // <2>: at most two K steps of features in whole, 16-byte aligned octets (the 40-d / 64-d front ends); <4>: anything else
   const bool k2 = Q.kpre16 <= 64 && Q.base.idim % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-  auto kern = k2 ? gru_pipe_kernel<2> : gru_pipe_kernel<4>;
+  const bool pk = g.spw <= 8;
+  auto kern = k2 ? (pk ? gru_pipe_kernel<2, true> : gru_pipe_kernel<2, false>) : (pk ? gru_pipe_kernel<4, true> : gru_pipe_kernel<4, false>);
   static_assert(kGruPipeLds >= int(G::LDS_BYTES), "staging buffers");
-  if (grant_dynamic_lds(kern, kGruPipeLds, k2 ? grant2 : grant4)) return -3;
+  if (grant_dynamic_lds(kern, kGruPipeLds, grant[(k2 ? 0 : 2) + (pk ? 1 : 0)])) return -3;
   hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), kGruPipeLds, stream, Q, ws, x, B, T, h0, y, hn,
                      g.tiles, g.slots, g.slots_p, g.spw);
   return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -26,7 +26,7 @@ python tools/prof_summary.py $(find $out -path "*prof_hl32_*" -name "*_results.d
 python tools/prof_summary.py $(find $out -path "*prof_d64_*" -name "*_results.db" | sort) > $out/${tag}_ds_tcn_h64_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_m32_*" -name "*_results.db" | sort) > $out/${tag}_mdtc_small_f16x3.txt
 python tools/prof_summary.py $(find $out -path "*prof_fb_*" -name "*_results.db" | sort) > $out/${tag}_fbank.txt
-python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=profiles/${tag}_ds_tcn_h256_f16x3.txt ds_tcn_h256/B1024/f32=hl32=profiles/${tag}_ds_tcn_h256_f32.txt mdtc_h64/B1024/f16x3=md=profiles/${tag}_mdtc_h64_f16x3.txt > $out/${tag}_pmc_traffic.log 2>&1
+python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=profiles/${tag}_ds_tcn_h256_f16x3.txt ds_tcn_h256/B1024/f32=hl32=profiles/${tag}_ds_tcn_h256_f32.txt mdtc_h64/B1024/f16x3=md=profiles/${tag}_mdtc_h64_f16x3.txt gru_2x128/B1024/f16x3=gru=profiles/${tag}_gru_2x128_f16x3.txt ds_tcn_h64/B1024/f16x3=d64=profiles/${tag}_ds_tcn_h64_f16x3.txt mdtc_small/B1024/f16x3=m32=profiles/${tag}_mdtc_small_f16x3.txt > $out/${tag}_pmc_traffic.log 2>&1
 cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 # streaming kernels: kernel trace of the many-streams sweep and of the GRU rows
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/prof_strm_a -o t -- bash -c "cd $root && python tools/bench_configs.py manystreams" > $out/prof_strm_a.log 2>&1)

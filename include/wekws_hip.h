@@ -189,7 +189,7 @@ enum wekws_hip_option {
   WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
   WEKWS_HIP_OPT_HEAD_SLICES = 4,/* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
   WEKWS_HIP_OPT_G16 = 5,        /* calls without an incoming cache: 1 (default) the register-resident kernels -- DS-TCN hidden 256: ds256_g16.hip.h (split fp16 / fp16) and ds256_g32.hip.h (precision F32), MDTC hidden 64: mdtc64_g4.hip.h --, 0 the LDS-tile kernels, 2 like 1 but one workgroup per utterance instead of persistent ones (a measurement aid) */
-  WEKWS_HIP_OPT_GRU_PIPE = 7,   /* GRU: 1 (default) the layer wavefront -- one launch, the stages of all layers running at the same time on different CUs (gru_pipe.hip.h) -- up to four rounds of stream tiles per resident slot (B <= 64 x CUs / (2 x layers)), the layer-major kernels (gru_f16.hip.h) beyond; 2 the wavefront always; 0 never; bit-identical results */
+  WEKWS_HIP_OPT_GRU_PIPE = 7,   /* GRU: 1 (default) the layer wavefront -- one launch, the stages of all layers running at the same time on different CUs (gru_pipe.hip.h) -- up to eight rounds of stream tiles per resident slot (B <= 128 x CUs / (2 x layers)), the layer-major kernels (gru_f16.hip.h) beyond; 2 the wavefront always; 0 never; bit-identical results */
   WEKWS_HIP_OPT_ENVELOPE = 6    /* weights outside the split-fp16 envelope (wekws_hip_weight_spread_log2): 1 (default) run the exact-f32 kernels, 0 keep the split-fp16 kernels (to MEASURE where the envelope ends; accuracy is then not promised) */
 };
 int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
@@ -230,6 +230,16 @@ float wekws_hip_weight_spread_log2(const wekws_hip_model* m);
 size_t wekws_hip_workspace_bytes(const wekws_hip_model* m, int B, int T);
 int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream);
 int wekws_hip_release(wekws_hip_model* m, void* stream);
+/*
+ * Device-side health of the forwards issued on `stream` so far.  The GRU wavefront (WEKWS_HIP_OPT_GRU_PIPE) hands sequences
+ * between workgroups inside one launch; every wait in it is bounded, and a wait that gives up (a bug, or a device in trouble)
+ * leaves an error code in the stream's control words and garbage in the outputs instead of hanging the GPU.  This call
+ * SYNCHRONISES the stream, reads the code, clears it and returns WEKWS_HIP_EDEVICE (wekws_hip_last_error names the stage)
+ * if any forward since the last check gave up; WEKWS_HIP_OK otherwise (and for models / streams without such launches).
+ * Nothing in the reference corresponds to it (ORT's Run is synchronous and throws); call it wherever results are consumed
+ * in bulk -- the C++ runtime does after every Forward that already synchronises, the Python mirror in KWSModel.check().
+ */
+int wekws_hip_forward_status(wekws_hip_model* m, void* stream);
 
 /*
  * Replaces: KWSModel.forward(x, in_cache) -> (y, out_cache)   (kws_model.py:65-76) and the body

@@ -82,7 +82,9 @@ void KeywordSpotting::Forward(const std::vector<std::vector<float>>& feats, std:
   have_cache_ = true;
   h_y_.resize(size_t(T) * odim_);
   WEKWS_CHECK(hipMemcpyAsync(h_y_.data(), d_y_, h_y_.size() * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
-  WEKWS_CHECK(hipStreamSynchronize(st) == hipSuccess);   // the caller reads *prob next (the one sync of a Forward)
+  // the caller reads *prob next: the one sync of a Forward -- inside the status query, which also says whether a bounded
+  // device-side wait of the forward gave up (the reference's ORT Run would have thrown)
+  WEKWS_CHECK(wekws_hip_forward_status(model_, stream_) == WEKWS_HIP_OK) << wekws_hip_last_error();
   prob->resize(T);  // keyword_spotting.cc:89-94
   for (int t = 0; t < T; ++t) (*prob)[t].assign(h_y_.begin() + size_t(t) * odim_, h_y_.begin() + size_t(t + 1) * odim_);
 }

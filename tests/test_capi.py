@@ -117,6 +117,15 @@ def test_create_without_gpu_fails_loudly():
     assert lib.wekws_hip_fbank_create(C.byref(fc), 0, C.byref(f)) == -1
 
 
+def test_handle_queries_reject_null():
+    """Entry points that take a model handle say EINVAL for NULL instead of dereferencing it (no GPU needed)."""
+    lib = _capi.load()
+    assert lib.wekws_hip_forward_status(None, None) == -1 and "NULL" in _capi.last_error()
+    assert lib.wekws_hip_release(None, None) == -1
+    assert lib.wekws_hip_reserve(None, 1, 1, None) == -1
+    assert lib.wekws_hip_effective_precision(None) == -1
+
+
 def test_model_refuses_cpu_tensors_and_missing_library(monkeypatch):
     import torch
     from wekws_amd.model.kws_model import init_model

@@ -1039,8 +1039,11 @@ def test_gru_wavefront_equals_layer_major(layers, error_report):
     pipe, major = build(cfg, sd).set_option("gru_pipe", 2), build(cfg, sd).set_option("gru_pipe", 0)
     rng = np.random.default_rng(7)
     slots = 256 // (2 * layers)
+    # (round 4: the hand-over buffers are rings of 16 steps with credits -- T around and beyond a lap, one stream whose first
+    # stage writes a whole lap at once (the case that deadlocked before consumers announced progress before waiting), rounds
+    # whose boundaries do not coincide with laps)
     shapes = [(1, 10), (1, 1), (3, 2), (5, 3), (16, 7), (19, 40), (8 * slots, 12), (8 * slots + 1, 12), (16 * slots, 21),
-              (16 * slots + 17, 9), (48 * slots + 5, 6), (2, 150)]
+              (16 * slots + 17, 9), (48 * slots + 5, 6), (2, 150), (1, 33), (1, 98), (4, 16), (4, 17), (40 * slots + 3, 37)]
     for rep, (B, T) in enumerate(shapes):
         x = synth.synth_feats(B, T, cfg["input_dim"], seed=50 + rep)
         h0 = None if rep % 3 == 0 else (rng.standard_normal((layers, B, 128)) * (0.5 if rep % 3 == 1 else 3.0)).astype(np.float32)
@@ -1060,6 +1063,8 @@ def test_gru_wavefront_equals_layer_major(layers, error_report):
     assert max_abs(ys, yo) <= 2e-5 and max_abs(cs, co) <= 2e-5
     ym, cm = run(major, x, chunks=[10, 10, 10, 10, 7])
     assert np.array_equal(ys, ym) and np.array_equal(cs, cm)
+    pipe.check()                                              # no bounded wait of any of these launches gave up
+    major.check()
 
 
 @pytest.mark.gpu
@@ -1083,6 +1088,7 @@ def test_gru_wavefront_under_uneven_load():
         y1, c1 = pipe(x)
         assert torch.equal(y1, y0) and torch.equal(c1, c0), it
     torch.cuda.synchronize()
+    pipe.check()
 
 
 @pytest.mark.gpu

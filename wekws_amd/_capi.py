@@ -43,6 +43,7 @@ SIGNATURES = {
     "wekws_hip_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "wekws_hip_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wekws_hip_release": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wekws_hip_forward_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wekws_hip_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_void_p]),
     "wekws_hip_fbank_create": (C.c_int, [C.POINTER(FbankCfg), C.c_int, C.POINTER(C.c_void_p)]),

@@ -34,12 +34,24 @@
 //     so whatever a wave requests behind its own stores waits for their acknowledgement: with write-through stores the
 //     recurrence's step became the acknowledgement latency.  (Observed placement: block b runs on XCD b % 8, so with the
 //     slots padded to a multiple of 8 a slot's stages share an XCD; nothing relies on it.)
-//   * tag = (launch epoch + 1) + round.  The epoch is a word in the workspace that the LAST workgroup to start advances by
-//     the launch's rounds (one relaxed agent-scope counter; everybody reads the epoch before counting itself in) -- nothing depends on a per-launch kernel argument, so a captured
-//     graph replays correctly.  Granule buffers hold nothing but granules (every odd dword is a tag written by some launch, or
-//     the zero the allocation was cleared to; tags start at 1), so a stale or foreign word cannot pass for the current tag.
-//   * granule buffers are per slot and round parity; before round r >= 2 a producer checks ONE acknowledgement word (the tag of
-//     the last round its consumer has finished reading) -- once per ~100 us.
+//   * the buffers are RINGS of kGruPipeRing (16) steps per slot: a slot's steps are numbered g = round * T + t, step g lives at
+//     position g mod 16 and carries tag = (launch epoch + 1) + g / 16, the tag of its lap.  (One position per step of the call was
+//     504 MB written + 524 MB fetched per launch at B = 1024 x 98 frames -- PMC -- i.e. 5 TB/s of HBM traffic for values that live
+//     a few microseconds; the rings are 80 MB for 64 slots and stay in the 256 MB memory-side cache -- sc1 loads are served
+//     from the fabric, not from L2, so the byte counts at the L2 boundary did not change, only where they are served from:
+//     4.8 -> 5.7 M utt/s.  Group-scope loads -- sc0 -- for a producer on the same XCD were tried: they hit stale L1 lines.)
+//     The epoch is a word in the control block that the LAST workgroup to start advances by the launch's laps (one relaxed
+//     agent-scope counter; everybody reads the epoch before counting itself in) -- nothing depends on a per-launch kernel
+//     argument, so a captured graph replays correctly.  Granule buffers hold nothing but granules (every tag word was written by
+//     some launch, or is the zero the allocation was cleared to; tags start at 1), so a stale or foreign word cannot pass for
+//     the current tag, and a position's tags only grow.
+//   * a position is written again 16 steps later, when its consumer is through with it: a 64-bit CREDIT word per (slot, stage)
+//     = {tag0 of the launch, steps the consumer has finished reading}, published every fourth step (behind the consumer's
+//     barrier: every wave has the step in registers), read by the producer only when its cached copy does not cover the
+//     step it is about to write, never for a launch's first 16 steps (what the ring holds then belongs to launches that are
+//     finished, in stream order) and never in launches of <= 16 steps (the streaming chunks).  A word of another launch
+//     never matches tag0.  A consumer that has to wait for data publishes first: the producer it waits for may be waiting
+//     for exactly that credit (the time-packed first stage writes a whole lap at once).
 // No deadlock: producers have lower workgroup indices than their consumers and the grid is at most one workgroup per CU, so
 // whenever a consumer is resident its producers are resident or done (in-order dispatch); every spin is bounded anyway
 // (error word; the kernel then terminates with garbage instead of hanging the GPU).

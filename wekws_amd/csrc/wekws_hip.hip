@@ -639,10 +639,11 @@ static bool gru_pipe_call(const wekws_hip_model* m, int B, int T) {
     return false;
   wekws::GruPipeGeom g;
   if (!wekws::gru_pipe_geom(d.num_layers, B, T, m->fsmn_cus, &g)) return false;
-  // many more tiles than resident slots: every workgroup serves several tiles one after the other, and from ~8 rounds on the
-  // layer-major kernels (all CUs on every pass, two tiles per workgroup) win -- measured 1.08x at B = 4096 (4 rounds), 0.94x at
+  // many more tiles than resident slots: every workgroup serves several tiles one after the other (each round fills and drains
+  // the pipeline), and beyond ~8 rounds the layer-major kernels (all CUs on every pass, two tiles per workgroup) win --
+  // measured with the ring buffers, 2 layers: 1.65x at B = 2048 (2 rounds), 1.31x at 4096, 1.09x at 8192 (8 rounds), 0.96x at
   // B = 16384 (16 rounds); option value 2 runs the wavefront anyway
-  return g.tiles <= 4 * g.slots || m->gru_pipe == 2;
+  return g.tiles <= 8 * g.slots || m->gru_pipe == 2;
 }
 // ... and the bytes of its granule buffer (a second per-stream buffer that holds nothing else)
 static size_t granule_need(const wekws_hip_model* m, int B, int T) {
@@ -1296,6 +1297,28 @@ int wekws_hip_release(wekws_hip_model* m, void* stream_) {
       break;
     }
   return WEKWS_HIP_OK;
+}
+
+int wekws_hip_forward_status(wekws_hip_model* m, void* stream_) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
+  unsigned* ctl = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(m->ws_mu);
+    for (auto& e : m->ws) if (e.stream == stream) ctl = e.ctl;
+  }
+  if (!ctl) return WEKWS_HIP_OK;
+  unsigned code = 0;
+  if (hipMemcpyAsync(&code, ctl + 2, sizeof(code), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return fail(WEKWS_HIP_EDEVICE, "reading the wavefront's status word: %s", hipGetErrorString(hipGetLastError()));
+  if (!code) return WEKWS_HIP_OK;
+  (void)hipMemsetAsync(ctl + 2, 0, sizeof(code), stream);
+  return fail(WEKWS_HIP_EDEVICE, "a bounded wait of the GRU wavefront gave up (code 0x%x: %s of stage %u): the outputs of the "
+              "forwards issued on this stream since the last check are not valid", code,
+              (code >> 8) == 1 ? "data" : "credit", code & 0xffu);
 }
 
 int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,

@@ -240,6 +240,15 @@ class KWSModel(nn.Module):
         _capi.check(_capi.load().wekws_hip_reserve(h.ptr, int(B), int(T), ctypes.c_void_p(stream)), "wekws_hip_reserve")
         return self
 
+    def check(self, device: Optional[torch.device] = None) -> "KWSModel":
+        """Synchronise the current stream and raise if a device-side wait of an earlier forward gave up
+        (wekws_hip_forward_status; only the GRU wavefront has such waits).  Cheap where results are read anyway."""
+        dev = device or next(self.parameters()).device
+        h = self._get_handle(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(_capi.load().wekws_hip_forward_status(h.ptr, ctypes.c_void_p(stream)), "wekws_hip_forward_status")
+        return self
+
     def packed(self) -> Tuple[dict, np.ndarray]:
         """(descriptor, folded float32 blob) -- what wekws_hip_create consumes; used by the multi-GPU
         weight broadcast (wekws_amd/parallel.py) and the model-file writer."""

@@ -147,7 +147,8 @@ def attach_profile(roof, model_name, B, precision):
             roof["traffic_unit"] = ("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes: "
                                     "FETCH corrected x2 as MI355X_MICROARCH.md prescribes for gfx950, WRITE as reported "
                                     "(calibrated: exact on three store patterns of known size incl. the cache's 28-byte runs, "
-                                    "profiles/r03_write_size_calibration.txt)")
+                                    "profiles/r03_write_size_calibration.txt); both count at the L2 - fabric boundary, so traffic "
+                                    "the 256 MB memory-side cache absorbs is included (the GRU wavefront's hand-over rings)")
             roof["traffic_source"] = rec.get("profile") or pm.get("profile")
             roof["kernel_avg_ms_rocprof"] = rec.get("kernel_avg_ms")
             return

@@ -156,8 +156,13 @@ def test_heterogeneous_scales(case, hetero_golden, error_report):
     gy = hetero_golden[case["name"] + "/y"]
     x = case_input(case)
     model = build(cfg, sd2)
-    y, _ = run(model, x, case_in_cache(case, cfg), chunks=case.get("chunks"))
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:      # the switch to the f32 kernels is announced, once per handle
+        warnings.simplefilter("always")
+        y, _ = run(model, x, case_in_cache(case, cfg), chunks=case.get("chunks"))
     spread, eff = model.weight_spread_log2(), model.effective_precision()
+    said = [w for w in caught if issubclass(w.category, RuntimeWarning) and "exact-f32 kernels" in str(w.message)]
+    assert (len(said) >= 1) == (eff == "f32" and cfg.get("_precision", "default") in ("default", "f16x3")), (eff, len(said))
     if kind == "kcol":
         # factors on the K axis of a matrix are absorbed at wekws_hip_create (balance_operand_channels: every column
         # maximum in [1, 2), the inverse factor folded into the per-channel stage in front): no spread left, no routing

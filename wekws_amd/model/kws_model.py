@@ -15,6 +15,7 @@ missing library or an unsupported configuration raises.
 from __future__ import annotations
 
 import ctypes
+import warnings
 import math
 import sys
 from typing import Mapping, Optional, Tuple
@@ -75,6 +76,17 @@ class _HipHandle:
                                          ctypes.byref(self.ptr)), "wekws_hip_create")
         for name, value in (options or {}).items():
             _capi.check(lib.wekws_hip_set_option(self.ptr, _capi.OPTIONS[name], int(value)), "wekws_hip_set_option")
+        # A DEFAULT / F16X3 request whose weights leave the split-fp16 envelope is served by the exact-f32 kernels (several
+        # times slower for the conv backbones): say so once instead of leaving it to effective_precision() to be asked.
+        req = int(desc_fields.get("precision", 0))
+        if req in (pack.PRECISION["default"], pack.PRECISION["f16x3"]) and \
+                lib.wekws_hip_effective_precision(self.ptr) == pack.PRECISION["f32"]:
+            spread = float(lib.wekws_hip_weight_spread_log2(self.ptr))
+            if spread > 20:
+                warnings.warn(f"wekws_amd: the row / column magnitudes of a weight matrix spread over 2^{spread:.1f} "
+                              f"(> 2^20): this model runs the exact-f32 kernels, not the split-fp16 ones "
+                              f"(wekws_hip_effective_precision; set_option('envelope', 0) keeps the fast kernels at "
+                              f"reduced accuracy in the small rows)", RuntimeWarning, stacklevel=3)
 
     def __del__(self):
         try:

@@ -1081,6 +1081,30 @@ def test_gru_wavefront_equals_layer_major(layers, error_report):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("idim", [80, 23, 64])
+def test_gru_wavefront_other_feature_widths(idim, error_report):
+    """The wavefront has two first-stage code paths per feature layout: <= 64 features in whole 16-byte-aligned octets
+    (counted assembly loads, what every 40-d test exercises) and everything else (80-d MFCC front ends: three K steps;
+    odd widths: scalar tails; plain loads).  Both against the layer-major kernels (bit for bit) and the oracle, one
+    stream, time-packed tiles, full tiles, several rounds, T below / beyond a lap of the hand-over rings."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"], input_dim=idim)
+    if "cmvn" in cfg:
+        cfg.pop("cmvn")
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 5200 + idim)
+    pipe, major = build(cfg, sd).set_option("gru_pipe", 2), build(cfg, sd).set_option("gru_pipe", 0)
+    for rep, (B, T) in enumerate([(1, 10), (5, 37), (40, 21), (700, 12), (2100, 33)]):
+        x = synth.synth_feats(B, T, idim, seed=300 + rep)
+        (y1, c1), (y0, c0) = run(pipe, x), run(major, x)
+        assert np.array_equal(y1, y0) and np.array_equal(c1, c0), (idim, B, T, max_abs(y1, y0), max_abs(c1, c0))
+        if B <= 64:
+            ry, rc = kws_oracle.forward(cfg, sd, x, None)
+            error_report[f"gru_pipe/idim{idim}/B{B}_T{T}"] = max_abs(y1, ry)
+            assert max_abs(y1, ry) <= POSTERIOR_TOL and max_abs(c1, rc) <= tol_for(rc)
+    pipe.check()
+
+
+@pytest.mark.gpu
 def test_gru_wavefront_under_uneven_load():
     """The hand-over must not depend on timing: the same call while another stream keeps part of the GPU busy with a
     long-running kernel of another model, many times, every word compared."""

@@ -1105,6 +1105,26 @@ def test_gru_wavefront_other_feature_widths(idim, error_report):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("odim", [17, 300])
+def test_gru_wavefront_wide_heads(odim, error_report):
+    """More than 16 outputs: the last layer cannot fold the head into its step loop (one o-tile) and runs the separate head
+    pass over the sequence it kept (gru_pipe.hip.h: `last && !head_in`) -- with softmax on top for the CTC-shaped one."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["gru_2x128"], output_dim=odim)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 6100 + odim)
+    pipe, major = build(cfg, sd).set_option("gru_pipe", 2), build(cfg, sd).set_option("gru_pipe", 0)
+    for rep, (B, T) in enumerate([(1, 10), (6, 40), (48, 21), (1500, 19)]):
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=400 + rep)
+        (y1, c1), (y0, c0) = run(pipe, x), run(major, x)
+        assert np.array_equal(y1, y0) and np.array_equal(c1, c0), (odim, B, T, max_abs(y1, y0), max_abs(c1, c0))
+        if B <= 64:
+            ry, rc = kws_oracle.forward(cfg, sd, x, None)
+            error_report[f"gru_pipe/odim{odim}/B{B}_T{T}"] = max_abs(y1, ry)
+            assert max_abs(y1, ry) <= POSTERIOR_TOL and max_abs(c1, rc) <= tol_for(rc)
+    pipe.check()
+
+
+@pytest.mark.gpu
 def test_gru_wavefront_under_uneven_load():
     """The hand-over must not depend on timing: the same call while another stream keeps part of the GPU busy with a
     long-running kernel of another model, many times, every word compared."""

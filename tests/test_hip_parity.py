@@ -438,11 +438,15 @@ def test_posteriors_only_equals_forward():
     """KWSModel.posteriors (C ABI out_cache = NULL: no cache hand-over) returns the very y of forward."""
     from wekws_amd import pack
     for name, T in (("ds_tcn_h256", 98), ("mdtc_h64", 98), ("tcn_h64", 40), ("gru_2x128", 20), ("fsmn_small", 25),
-                    ("ds_tcn_h256", 200), ("ds_tcn_h256_ctc300", 50)):
+                    ("ds_tcn_h256", 200), ("ds_tcn_h256_ctc300", 50),
+                    # round 4: the register-resident small-recipe kernels (ds64_g4, mdtc_g4<32>) and the GRU wavefront at
+                    # a full tile / beyond a lap of its rings
+                    ("ds_tcn_h64", 98), ("ds_tcn_h64", 45), ("mdtc_small", 98), ("mdtc_small", 33), ("gru_2x128", 98)):
         cfg = dict(synth.MODEL_CONFIGS[name])
         model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234))
-        x = torch.from_numpy(synth.synth_feats(3, T, cfg["input_dim"], seed=6)).cuda()
-        assert torch.equal(model.posteriors(x), model(x)[0]), name
+        for B in (3, 300):
+            x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=6)).cuda()
+            assert torch.equal(model.posteriors(x), model(x)[0]), (name, T, B)
 
 
 def test_forward_is_graph_capturable():

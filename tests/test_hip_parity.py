@@ -1011,7 +1011,7 @@ def test_reserve_covers_every_smaller_shape():
     with torch.cuda.stream(s):
         model.reserve(256, 20)
     torch.cuda.synchronize()
-    for B, T in ((256, 10), (128, 10), (3, 16), (256, 20), (200, 1)):
+    for B, T in ((256, 10), (128, 10), (3, 16), (256, 20), (200, 1), (1, 20), (40, 19)):   # (the last three: beyond a lap of the rings)
         x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=B + T)).cuda()
         h0 = torch.from_numpy(synth.synth_feats(2, B, 128, seed=3)).cuda().contiguous()
         y_ref, c_ref = model(x, h0)
@@ -1020,10 +1020,12 @@ def test_reserve_covers_every_smaller_shape():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             y_static, c_static = model(x, h0)
-        y_static.zero_()
-        g.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), (B, T)
+        for rep in range(3):         # (every replay is a launch of its own epoch: the hand-over tags come from the device)
+            y_static.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, y_ref) and torch.equal(c_static, c_ref), (B, T, rep)
+    model.check()
 
 
 def _gru_cfg(layers):

@@ -24,8 +24,8 @@
 //     leans on naturally aligned 16-byte stores and loads being single transactions (tools/probe/tear16.hip: no torn item in
 //     3.9e10 concurrent reads, both store policies); vector stores are ISSUE-bound on this part (~60 cycles per
 //     wave-instruction on a CU), and with 8-byte gate granules the six stores per wave and step were the first stage's time.  The data IS the flag: a consumer
-//     requests a step's granules ahead of time, checks the tags when it needs the values (one v_min3_u32 per two tags: tags
-//     only grow, so min == tag means all equal) and re-requests until they are there.  Nobody waits for a store to complete,
+//     requests a step's granules ahead of time, checks the tags when it needs the values (all equal to the step's tag: xor / or, one compare)
+//     and re-requests until they are there.  Nobody waits for a store to complete,
 //     there is no fence, no flag and no poll on the fast path, and a producer never waits for its consumer inside a round.
 //   * where the stores go: a workgroup announces the XCD it runs on (HW_REG_XCC_ID) in a control word; a producer that finds its
 //     consumer on ITS OWN XCD within a few microseconds stores with the default policy -- the two share one L2, which then
@@ -44,7 +44,7 @@
 //     agent-scope counter; everybody reads the epoch before counting itself in) -- nothing depends on a per-launch kernel
 //     argument, so a captured graph replays correctly.  Granule buffers hold nothing but granules (every tag word was written by
 //     some launch, or is the zero the allocation was cleared to; tags start at 1), so a stale or foreign word cannot pass for
-//     the current tag, and a position's tags only grow.
+//     the current tag (compared for equality: the 32-bit epoch may wrap; 0 is never a tag).
 //   * a position is written again 16 steps later, when its consumer is through with it: a 64-bit CREDIT word per (slot, stage)
 //     = {tag0 of the launch, steps the consumer has finished reading}, published every fourth step (behind the consumer's
 //     barrier: every wave has the step in registers), read by the producer only when its cached copy does not cover the
@@ -98,7 +98,6 @@ __device__ unsigned long long gp_stamps[16 * 1024];
 typedef unsigned gp_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGpSc1 = 16;                                    // buffer aux bit: sc1 (write-through store / L2-served load)
 
-__device__ __forceinline__ unsigned gp_min3(unsigned a, unsigned b, unsigned c) { return min(a, min(b, c)); }
 __device__ __forceinline__ unsigned gp_ld_ctl(const unsigned* p) {
   return unsigned(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
 }
@@ -271,13 +270,13 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
   unsigned* const where = ctl + 16 + (2 * kGruPipeMaxSlots + slot) * kGruPipeStages;   // [stage] of this slot
-  if (tid == 0) __hip_atomic_store(where + stage, (tag0 << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(where + stage, (tag0 << 4) | 8u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // does this stage's consumer run on this XCD?  asked after the weights have been requested; gives up after ~20 us (the
   // consumer may not be resident yet: write-through stores are right wherever it turns up)
   auto peer_here = [&](int st) __attribute__((always_inline)) -> bool {
     for (int i = 0; i < 48; ++i) {
       const unsigned w = gp_ld_ctl(where + st);
-      if ((w >> 4) == (tag0 & 0x0fffffffu)) return (w & 15u) == xcc;
+      if ((w & 8u) && (w >> 4) == (tag0 & 0x0fffffffu)) return (w & 7u) == xcc;   // (bit 3: written at all)
       __builtin_amdgcn_s_sleep(8);
     }
     return false;
@@ -287,7 +286,12 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   // written again RING steps later, when the consumer has said that it is through with it: a CREDIT word per (slot, stage)
   // = {tag0 of the launch, steps finished}, published every few steps.  A word of another launch never matches tag0; the
   // first RING steps of a launch need no credit (what the ring holds then is of earlier launches: finished, in stream order).
-  auto lap_tag = [&](int g) __attribute__((always_inline)) -> unsigned { return tag0 + unsigned(g >> RLOG); };
+  // (the epoch is a 32-bit counter that wraps -- after ~30 h of back-to-back single-chunk launches --: tags are compared for
+  // EQUALITY, never for order, and 0 -- what a cleared buffer holds -- is never a tag)
+  auto lap_tag = [&](int g) __attribute__((always_inline)) -> unsigned {
+    const unsigned r = tag0 + unsigned(g >> RLOG);
+    return r ? r : 0x80000000u;
+  };
   auto ring_pos = [&](int g) __attribute__((always_inline)) -> int { return g & (RING - 1); };
   unsigned credit = 0;                                        // steps the consumer is known to have finished
   auto wait_credit = [&](int g) __attribute__((always_inline)) {   // before step g is written
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     auto ask_near = [&]() __attribute__((always_inline)) {
       if (near_known) return;
       const unsigned w = unsigned(__builtin_amdgcn_readfirstlane(int(where_early)));
-      near = (w >> 4) == (tag0 & 0x0fffffffu) ? (w & 15u) == xcc : consumer_here();
+      near = ((w & 8u) && (w >> 4) == (tag0 & 0x0fffffffu)) ? (w & 7u) == xcc : consumer_here();
       near_known = true;
       GP_STAMP(15, stage);
       GP_STAMP(14, near ? 100 + stage : 200 + stage);
@@ -739,8 +743,8 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       // a time-packed first stage writes the columns of real streams only: the other lanes' granules never arrive
       const bool live = l > 0 || nb > 8 || l15 < nb;
       auto tags_ok = [&](const gp_u32x4 (&gg)[4], unsigned tag) __attribute__((always_inline)) -> bool {
-        const unsigned m = min(gp_min3(gg[0][3], gg[1][3], gg[2][3]), gg[3][3]);
-        return !__builtin_amdgcn_ballot_w64(live && m != tag);   // a position's tags only grow: min == tag <=> all == tag
+        const unsigned d = (gg[0][3] ^ tag) | (gg[1][3] ^ tag) | (gg[2][3] ^ tag) | (gg[3][3] ^ tag);
+        return !__builtin_amdgcn_ballot_w64(live && d != 0u);    // all four granules carry this step's tag
       };
       load_g(ga, 0);
       load_g(gb, 1);
@@ -980,14 +984,18 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         const unsigned tag = lap_tag(gb0 + t);
         if (behind) gp_wait2<4>(raw);
         else gp_wait2<0>(raw);
-        if (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag)) {
+        auto stale = [&]() __attribute__((always_inline)) -> bool {
+          const unsigned d = (raw[0][1] ^ tag) | (raw[0][3] ^ tag) | (raw[1][1] ^ tag) | (raw[1][3] ^ tag);
+          return __builtin_amdgcn_ballot_w64(d != 0u) != 0;
+        };
+        if (stale()) {
           publish(gb0 + t, near_up);                            // (as in the recurrence: never wait without having said so)
           do {
             __builtin_amdgcn_s_sleep(2);
             load_h(t);
             gp_wait2<0>(raw);
             if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
-          } while (__builtin_amdgcn_ballot_w64(gp_min3(raw[0][1], raw[0][3], min(raw[1][1], raw[1][3])) != tag));
+          } while (stale());
         }
         gp_u32x4 hl;                                            // granule data: hi | lo << 16 of one unit
         hl[0] = __builtin_amdgcn_perm(raw[0][2], raw[0][0], 0x05040100u);

@@ -1321,6 +1321,21 @@ int wekws_hip_forward_status(wekws_hip_model* m, void* stream_) {
               (code >> 8) == 1 ? "data" : "credit", code & 0xffu);
 }
 
+// Test hook (not part of the ABI in include/wekws_hip.h): set the launch epoch of the stream's wavefront control block, so that
+// a test can walk the 32-bit tag counter across its wrap (tests/test_hip_parity.py::test_gru_wavefront_epoch_wrap).
+extern "C" int wekws_hip_debug_set_gru_epoch(wekws_hip_model* m, void* stream_, unsigned epoch) {
+  if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(m->device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
+  unsigned* ctl = stream_ctl(m, stream);
+  if (!ctl) return WEKWS_HIP_ENOMEM;
+  if (hipMemcpyAsync(ctl, &epoch, sizeof(epoch), hipMemcpyHostToDevice, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return fail(WEKWS_HIP_EDEVICE, "setting the epoch: %s", hipGetErrorString(hipGetLastError()));
+  return WEKWS_HIP_OK;
+}
+
 int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
                       float* out_cache, int softmax, void* stream_) {
   if (!m || !x || !y) return fail(WEKWS_HIP_EINVAL, "NULL argument");

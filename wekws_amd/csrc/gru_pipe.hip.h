@@ -58,6 +58,16 @@
 #pragma once
 #include "gru_f16.hip.h"
 
+// Experiment switch of the granule loads (next round: DESIGN.md section 7).  What ships: sc1 loads, served from the fabric.
+// -DWEKWS_GRU_PIPE_L2 builds the candidate for an L2-resident hand-over between stages on one XCD: an L1 invalidate in front
+// of plain loads (only valid while every slot's stages share an XCD -- the observed placement; not selected at run time yet).
+#ifdef WEKWS_GRU_PIPE_L2
+#define GP_LDPOL ""
+#define GP_LDINV "buffer_inv sc0\n\t"
+#else
+#define GP_LDPOL "sc1"
+#define GP_LDINV ""
+#endif
 namespace wekws {
 
 constexpr int kGruPipeStages = 2 * kGruMaxLayers;
@@ -126,11 +136,11 @@ __device__ __forceinline__ gp_desc gp_make_desc(const void* base, unsigned bytes
 // four 16-byte items at voff + {0, 1, 2, 3} KiB
 __device__ __forceinline__ void gp_ld4(gp_u32x4 (&g)[4], int voff, gp_desc rs) {
   asm volatile(
-      "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\t"
-      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
-      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\t"
-      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1"
+      GP_LDINV "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_LDPOL
       : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
       : "v"(voff), "s"(rs)
       : "memory");
@@ -149,11 +159,11 @@ __device__ __forceinline__ void gp_wait4_if(gp_u32x4 (&g)[4], unsigned on) {    
 __device__ __forceinline__ void gp_ld4_if(gp_u32x4 (&g)[4], int voff, gp_desc rs, unsigned on) {   // on ? request again : nothing
   asm volatile(
       "s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lgpl%=\n\t"
-      "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\t"
-      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
-      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\t"
-      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1\n.Lgpl%=:"
+      GP_LDINV "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_LDPOL "\n.Lgpl%=:"
       : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])
       : "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(int(on)))
       : "memory", "scc");
@@ -167,9 +177,9 @@ __device__ __forceinline__ void gp_wait4_sel(gp_u32x4 (&g)[4], unsigned all) {  
 // two 16-byte items at voff, voff + 16
 __device__ __forceinline__ void gp_ld2(gp_u32x4 (&g)[2], int voff, gp_desc rs) {
   asm volatile(
-      "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\t"
-      "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1"
+      GP_LDINV "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %2, %3, 0 offen " GP_LDPOL "\n\t"
+      "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 " GP_LDPOL
       : "=&v"(g[0]), "=&v"(g[1])
       : "v"(voff), "s"(rs)
       : "memory");

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define WEKWS_HIP_ABI_VERSION 1
+#define WEKWS_HIP_ABI_VERSION 2 /* 2: wekws_hip_forward_status; failures of a stream surface on its next call */
 
 /* frames one kernel launch keeps resident in LDS; longer inputs are processed as a sequence of
  * tiles that hand the causal left context over through the streaming cache */
@@ -232,12 +232,17 @@ int wekws_hip_reserve(wekws_hip_model* m, int B, int T, void* stream);
 int wekws_hip_release(wekws_hip_model* m, void* stream);
 /*
  * Device-side health of the forwards issued on `stream` so far.  The GRU wavefront (WEKWS_HIP_OPT_GRU_PIPE) hands sequences
- * between workgroups inside one launch; every wait in it is bounded, and a wait that gives up (a bug, or a device in trouble)
- * leaves an error code in the stream's control words and garbage in the outputs instead of hanging the GPU.  This call
- * SYNCHRONISES the stream, reads the code, clears it and returns WEKWS_HIP_EDEVICE (wekws_hip_last_error names the stage)
- * if any forward since the last check gave up; WEKWS_HIP_OK otherwise (and for models / streams without such launches).
- * Nothing in the reference corresponds to it (ORT's Run is synchronous and throws); call it wherever results are consumed
- * in bulk -- the C++ runtime does after every Forward that already synchronises, the Python mirror in KWSModel.check().
+ * between workgroups inside one launch; every wait in it is bounded (~0.1 s), and a wait that gives up (a bug, or a device
+ * whose other tenants keep the launch's later workgroups off the CUs for that long) ends the launch with garbage in the
+ * outputs instead of hanging the GPU, and leaves a code in a word of pinned HOST memory owned by (model, stream).
+ *   - the NEXT wekws_hip_forward on that (model, stream) reads the word (no synchronisation), launches nothing, clears it and
+ *     returns WEKWS_HIP_EDEVICE: a caller that only ever calls forward -- the reference's scripts with the one-line import
+ *     change -- cannot keep consuming garbage silently; wekws_hip_release returns it and wekws_hip_destroy leaves it in
+ *     wekws_hip_last_error() if nobody asked before;
+ *   - this call SYNCHRONISES the stream (for every model and stream, with or without such launches), then does the same
+ *     check: WEKWS_HIP_EDEVICE (wekws_hip_last_error names the stage) if any forward since the last report gave up, else OK.
+ * Nothing in the reference corresponds to it (ORT's Run is synchronous and throws, keyword_spotting.cc:77-79); call it
+ * where results are consumed -- the C++ runtime does after every Forward (its one synchronisation), KWSModel.check() in Python.
  */
 int wekws_hip_forward_status(wekws_hip_model* m, void* stream);
 

@@ -8,7 +8,7 @@ from typing import Optional
 
 _LIB_PATH = os.environ.get("WEKWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                       "libwekws_hip.so")  # override: kernel experiments only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):
@@ -85,6 +85,15 @@ def load() -> C.CDLL:
         lib = C.CDLL(_LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 not found
         raise HipLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+    # the version first: a stale library then fails with the ABI message, not with a missing-symbol error of a newer entry
+    try:
+        lib.wekws_hip_abi_version.restype = C.c_int
+        lib.wekws_hip_abi_version.argtypes = []
+        have = lib.wekws_hip_abi_version()
+    except AttributeError as e:
+        raise HipLibraryError(f"{_LIB_PATH} does not export wekws_hip_abi_version; rebuild it") from e
+    if have != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {have}, binding {ABI_VERSION}; rebuild with `make -C wekws_amd/csrc`")
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -92,8 +101,6 @@ def load() -> C.CDLL:
             raise HipLibraryError(f"{_LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.wekws_hip_abi_version() != ABI_VERSION:
-        raise HipLibraryError(f"ABI version mismatch: library {lib.wekws_hip_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -52,9 +52,12 @@
 //     finished, in stream order) and never in launches of <= 16 steps (the streaming chunks).  A word of another launch
 //     never matches tag0.  A consumer that has to wait for data publishes first: the producer it waits for may be waiting
 //     for exactly that credit (the time-packed first stage writes a whole lap at once).
-// No deadlock: producers have lower workgroup indices than their consumers and the grid is at most one workgroup per CU, so
-// whenever a consumer is resident its producers are resident or done (in-order dispatch); every spin is bounded anyway
-// (error word; the kernel then terminates with garbage instead of hanging the GPU).
+// No deadlock, also with other launches on the device (round 5; the workgroup numbering in the kernel says why): a consumer's
+// producers have lower workgroup indices ON ITS XCD, so whenever it is resident they are resident or done (in-order dispatch
+// per XCD); a producer waits for its consumer's credits, and the numbering keeps a launch's resident workgroups to complete
+// slots plus at most one incomplete slot per XCD -- complete slots finish on their own and free the CUs the incomplete ones
+// wait for.  Every wait is bounded anyway (~0.1 s; error word in device AND host memory: the launch then ends with garbage
+// instead of hanging the GPU, and the next library call on the stream returns WEKWS_HIP_EDEVICE).
 #pragma once
 #include "gru_f16.hip.h"
 
@@ -81,7 +84,11 @@ constexpr int kGruPipeRingLog = 4, kGruPipeRing = 1 << kGruPipeRingLog;
 // [16 + 2 slots * stages + slot * stages + stage] where the workgroup runs: tag0 << 4 | XCD
 constexpr int kGruPipeCtlWords = 16 + 3 * kGruPipeMaxSlots * kGruPipeStages;
 constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
-constexpr unsigned kGruPipeSpinLimit = 1u << 24;              // re-requests (~1 us each) before a consumer gives up
+// Bound of ONE wait, in re-requests (~1 .. 2 us each: a load's round trip plus the sleep): ~0.1 s of EXECUTED waiting -- a count,
+// not a wall-clock reading, so that a queue the scheduler pre-empts in favour of another process does not time out while its
+// waves are saved.  A wait that gives up marks the whole launch dead (every later wait of every workgroup falls through at
+// once: the launch ends within a few of these bounds), and the host hears of it on its next call (GruPipeWorkspace::err).
+constexpr unsigned kGruPipeSpinLimit = 1u << 16;
 constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
 constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
 constexpr int kGruPipePlanes = 128 * 1024;                    // staging buffers of stage 0; 16 steps of planes of a time-packed tile
@@ -90,6 +97,8 @@ constexpr int kGruPipeLds = kGruPipePlanes + 1024;            // dynamic LDS of 
 
 struct GruPipeWorkspace {
   unsigned* ctl;                // control words
+  unsigned* err;                // device address of a word in HOST (pinned, mapped) memory: a wait that gave up leaves its code
+                                // here too, where the next library call on the stream finds it without synchronising anything
   char* seq_in;                 // [slot][T] time-packed tiles only: preprocessing output planes (stage 0 internal)
   char* seq_top;                // [slot][T] last layer's output planes (read back by its own workgroup's head pass)
   float* sc;                    // [slot][T][16] time-packed tiles only: 1 / scale of the preprocessing output
@@ -248,7 +257,19 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   const GruParams& P = Q.base;
   extern __shared__ __attribute__((aligned(16))) char gp_lds[];
 
-  const int stage = blockIdx.x / slots_p, slot = blockIdx.x - stage * slots_p;
+  // Workgroup -> (slot, stage), GROUP-major: eight slots x all stages are 8 x stages consecutive workgroups, stage-major inside
+  // the group.  (i) Workgroup b runs on XCD b % 8 (static round-robin), so a slot's stages share an XCD -- and its L2 -- as
+  // before.  (ii) Every XCD dispatches ITS workgroups in index order, and in this numbering that order is slot after slot,
+  // producers first: at any moment the resident workgroups of a launch are complete slots plus at most one slot per XCD whose
+  // later stages are still waiting for a CU.  Complete slots depend on nobody and finish; what they free goes to the next
+  // workgroups in order.  So several wavefront launches sharing the device (streams, models, processes) cannot starve each
+  // other into a deadlock as long as launches x (stages - 1) < CUs per XCD -- round 4's stage-major numbering put ALL
+  // producers first, and two launches that each got their producer half resident waited for consumers that had no CU
+  // (their ring credits never came).
+  const int nstg = 2 * Q.base.nlayers;
+  const int grp = blockIdx.x / (8 * nstg), gr = blockIdx.x - grp * (8 * nstg);
+  const int stage = gr >> 3, slot = grp * 8 + (gr & 7);
+  (void)slots_p;
   if (slot >= slots) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
@@ -265,6 +286,10 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   unsigned long long* const cred_out = cred + slot * kGruPipeStages + (stage > 0 ? stage - 1 : 0);   // what this stage has finished reading
   const unsigned long long* const cred_in = cred + slot * kGruPipeStages + stage;                    // what its consumer has finished reading
   const unsigned tag0 = gp_ld_ctl(ctl) + 1u;                // tag of this launch's first lap of the rings
+  // (the epoch load must have RETURNED before this workgroup counts itself in below: the statement consumes the value -- the
+  // wave waits for it here -- and, as a memory clobber, keeps the compiler from moving the atomic above it; the memory
+  // pipeline issues in program order)
+  asm volatile("" :: "s"(tag0) : "memory");
   // The LAST workgroup to get here advances the epoch by the tags this launch uses.  Every workgroup has read the epoch
   // (above: the value is back before the atomic is issued) before it counts itself in, so the one that counts last knows
   // that nobody will read it again in this launch -- and no atomic round trip sits at the END of the launch, where a
@@ -303,6 +328,19 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     return r ? r : 0x80000000u;
   };
   auto ring_pos = [&](int g) __attribute__((always_inline)) -> int { return g & (RING - 1); };
+  // One more re-request of a bounded wait: true = stop waiting (the launch is dead: this wait ran out, or another workgroup's
+  // did -- looked up every 64th time; the results are garbage then and the error word says so).
+  unsigned dead = 0;
+  auto give_up = [&](unsigned& spins, unsigned what) __attribute__((always_inline)) -> bool {
+    if (dead) return true;
+    ++spins;
+    if ((spins & 63u) == 0u && gp_ld_ctl(ctl + 2) != 0u) { dead = 1u; return true; }
+    if (spins <= kGruPipeSpinLimit) return false;
+    dead = 1u;
+    __hip_atomic_store(ctl + 2, what + unsigned(stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (WS.err) __hip_atomic_store(WS.err, what + unsigned(stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  };
   unsigned credit = 0;                                        // steps the consumer is known to have finished
   auto wait_credit = [&](int g) __attribute__((always_inline)) {   // before step g is written
     const unsigned need = unsigned(g - RING + 1);
@@ -315,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         if (credit >= need) break;
       }
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x200u + unsigned(stage); break; }
+      if (give_up(spins, 0x200u)) break;
     }
   };
   // this stage has finished reading its input up to (not including) step g; the store goes where the producer's loads look
@@ -810,11 +848,12 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           // about to wait for the producer: it may be waiting for THIS stage's credit (a producer that writes a ring's worth of
           // steps at once -- the time-packed first stage -- needs every step before this one acknowledged)
           publish(gb0 + t, near_up);
+          spins = 0;
           do {
             __builtin_amdgcn_s_sleep(2);
             load_g(g0, t);
             gp_wait4<0>(g0);
-            if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
+            if (give_up(spins, 0x100u)) break;
           } while (!tags_ok(g0, tag));
         }
         GP_STAMP(4 * l + 5, t);
@@ -1000,11 +1039,12 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         };
         if (stale()) {
           publish(gb0 + t, near_up);                            // (as in the recurrence: never wait without having said so)
+          spins = 0;
           do {
             __builtin_amdgcn_s_sleep(2);
             load_h(t);
             gp_wait2<0>(raw);
-            if (++spins > kGruPipeSpinLimit) { ctl[2] = 0x100u + unsigned(stage); break; }
+            if (give_up(spins, 0x100u)) break;
           } while (stale());
         }
         gp_u32x4 hl;                                            // granule data: hi | lo << 16 of one unit

@@ -196,6 +196,10 @@ struct StreamBuf {
   size_t gran_bytes = 0;
   unsigned* ctl = nullptr;      // ... and its control words (launch epoch, acknowledgements): allocated ONCE per stream and never
                                 // re-allocated -- tags must keep growing for as long as any granule buffer of the stream lives
+  unsigned gran_layout = 0;     // how the last wavefront call carved `gran` (slots, layers): a call with another layout clears
+                                // it first -- its tag words would otherwise overlay what were DATA words of the old layout
+  unsigned* err_h = nullptr;    // one word of pinned, device-mapped HOST memory: a device-side wait that gave up leaves its
+  unsigned* err_d = nullptr;    // code here (err_d = the device's address of it); read by the next call, no synchronisation
 };
 
 bool desc_conv(const wekws_hip_desc& d) {
@@ -341,11 +345,11 @@ struct wekws_hip_model {
 };
 
 // -> device pointer to at least `need` bytes owned by (model, stream); nullptr + error text on failure
-static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need, bool granules = false) {
+static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need, bool granules = false, unsigned layout = 0) {
   std::lock_guard<std::mutex> lk(m->ws_mu);
   StreamBuf* sb = nullptr;
   for (auto& e : m->ws) if (e.stream == stream) sb = &e;
-  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0, nullptr, 0, nullptr}); sb = &m->ws.back(); }
+  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->ws.back(); }
   char*& ptr = granules ? sb->gran : sb->ptr;
   size_t& bytes = granules ? sb->gran_bytes : sb->bytes;
   if (bytes < need) {
@@ -375,17 +379,28 @@ static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t nee
       fail(WEKWS_HIP_EDEVICE, "workspace: hipMemsetAsync");
       return nullptr;
     }
+    if (granules) sb->gran_layout = layout;
+  }
+  // ... and again whenever a call carves the buffer differently from the call before it (another number of slots): gate
+  // granules carry their tag in every fourth word, state granules in every second, so a tag position of the new layout may
+  // hold a float of the old one -- which after days of streaming could equal a live tag.  Stream-ordered, no synchronisation.
+  if (granules && layout && sb->gran_layout != layout) {
+    if (sb->gran_layout && hipMemsetAsync(ptr, 0, bytes, stream) != hipSuccess) {
+      fail(WEKWS_HIP_EDEVICE, "workspace: hipMemsetAsync");
+      return nullptr;
+    }
+    sb->gran_layout = layout;
   }
   return ptr;
 }
 
 // The control words of a stream's GRU wavefront launches (gru_pipe.hip.h): one small allocation per (model, stream), made
 // on the first call (or by wekws_hip_reserve) and kept until the stream's workspace is released.
-static unsigned* stream_ctl(wekws_hip_model* m, hipStream_t stream) {
+static unsigned* stream_ctl(wekws_hip_model* m, hipStream_t stream, unsigned** err_d = nullptr) {
   std::lock_guard<std::mutex> lk(m->ws_mu);
   StreamBuf* sb = nullptr;
   for (auto& e : m->ws) if (e.stream == stream) sb = &e;
-  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0, nullptr, 0, nullptr}); sb = &m->ws.back(); }
+  if (!sb) { m->ws.push_back(StreamBuf{stream, nullptr, 0}); sb = &m->ws.back(); }
   if (!sb->ctl) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
@@ -393,14 +408,43 @@ static unsigned* stream_ctl(wekws_hip_model* m, hipStream_t stream) {
       return nullptr;
     }
     if (hipMalloc(reinterpret_cast<void**>(&sb->ctl), wekws::kGruPipeCtlBytes) != hipSuccess ||
-        hipMemsetAsync(sb->ctl, 0, wekws::kGruPipeCtlBytes, stream) != hipSuccess) {
+        hipMemsetAsync(sb->ctl, 0, wekws::kGruPipeCtlBytes, stream) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&sb->err_h), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&sb->err_d), sb->err_h, 0) != hipSuccess) {
       if (sb->ctl) (void)hipFree(sb->ctl);
+      if (sb->err_h) (void)hipHostFree(sb->err_h);
       sb->ctl = nullptr;
+      sb->err_h = sb->err_d = nullptr;
       fail(WEKWS_HIP_ENOMEM, "GRU control words");
       return nullptr;
     }
+    *static_cast<volatile unsigned*>(sb->err_h) = 0u;
   }
+  if (err_d) *err_d = sb->err_d;
   return sb->ctl;
+}
+
+// Has a device-side wait of an earlier forward on this stream given up (gru_pipe.hip.h: give_up)?  Reads the stream's word of
+// host memory -- no device call on the healthy path --; if set, clears it (host word now, the device's copy in stream order)
+// and returns WEKWS_HIP_EDEVICE with the stage named.  The word is written by the kernel itself, so a caller that pipelines
+// forwards hears of a failure on the first call AFTER the failed launch has run, at the latest from wekws_hip_forward_status.
+static int stream_health(wekws_hip_model* m, hipStream_t stream) {
+  unsigned* err_h = nullptr;
+  unsigned* ctl = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(m->ws_mu);
+    for (auto& e : m->ws) if (e.stream == stream) { err_h = e.err_h; ctl = e.ctl; }
+  }
+  if (!err_h) return WEKWS_HIP_OK;
+  const unsigned code = *static_cast<volatile unsigned*>(err_h);
+  if (!code) return WEKWS_HIP_OK;
+  *static_cast<volatile unsigned*>(err_h) = 0u;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (ctl && !(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone))
+    (void)hipMemsetAsync(ctl + 2, 0, sizeof(unsigned), stream);
+  return fail(WEKWS_HIP_EDEVICE, "a bounded wait of the GRU wavefront gave up (code 0x%x: %s of stage %u): the outputs of the "
+              "forwards issued on this stream since the last successful call are not valid", code,
+              (code >> 8) == 1 ? "data" : "credit", code & 0xffu);
 }
 
 struct wekws_hip_fbank {
@@ -1176,7 +1220,19 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
-  for (auto& e : m->ws) { if (e.ptr) (void)hipFree(e.ptr); if (e.gran) (void)hipFree(e.gran); if (e.ctl) (void)hipFree(e.ctl); }
+  bool gave_up = false;
+  for (auto& e : m->ws) {
+    if (e.err_h) {                                            // (freeing synchronises: the word is final)
+      if (e.ctl) (void)hipStreamSynchronize(e.stream);
+      gave_up = gave_up || *static_cast<volatile unsigned*>(e.err_h) != 0u;
+      (void)hipHostFree(e.err_h);
+    }
+    if (e.ptr) (void)hipFree(e.ptr);
+    if (e.gran) (void)hipFree(e.gran);
+    if (e.ctl) (void)hipFree(e.ctl);
+  }
+  // (no return value to carry it: a failure nobody has asked about yet is at least left in wekws_hip_last_error())
+  if (gave_up) (void)fail(WEKWS_HIP_EDEVICE, "model destroyed with an unreported failure: a bounded wait of the GRU wavefront gave up");
   delete m;
 }
 
@@ -1284,19 +1340,25 @@ int wekws_hip_release(wekws_hip_model* m, void* stream_) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(m->device);
+  int lkrc = WEKWS_HIP_OK;
   std::lock_guard<std::mutex> lk(m->ws_mu);
   for (size_t i = 0; i < m->ws.size(); ++i)
     if (m->ws[i].stream == stream) {
       if (m->ws[i].ptr || m->ws[i].gran || m->ws[i].ctl) {
         (void)hipStreamSynchronize(stream);
+        if (m->ws[i].err_h && *static_cast<volatile unsigned*>(m->ws[i].err_h)) {
+          // an unreported failure must not vanish with the stream's buffers
+          lkrc = fail(WEKWS_HIP_EDEVICE, "stream released with an unreported failure: a bounded wait of the GRU wavefront gave up");
+        }
         if (m->ws[i].ptr) (void)hipFree(m->ws[i].ptr);
         if (m->ws[i].gran) (void)hipFree(m->ws[i].gran);
         if (m->ws[i].ctl) (void)hipFree(m->ws[i].ctl);
+        if (m->ws[i].err_h) (void)hipHostFree(m->ws[i].err_h);
       }
       m->ws.erase(m->ws.begin() + i);
       break;
     }
-  return WEKWS_HIP_OK;
+  return lkrc;
 }
 
 int wekws_hip_forward_status(wekws_hip_model* m, void* stream_) {
@@ -1304,25 +1366,16 @@ int wekws_hip_forward_status(wekws_hip_model* m, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(m->device);
   if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", m->device);
-  unsigned* ctl = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(m->ws_mu);
-    for (auto& e : m->ws) if (e.stream == stream) ctl = e.ctl;
-  }
-  if (!ctl) return WEKWS_HIP_OK;
-  unsigned code = 0;
-  if (hipMemcpyAsync(&code, ctl + 2, sizeof(code), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipStreamSynchronize(stream) != hipSuccess)
-    return fail(WEKWS_HIP_EDEVICE, "reading the wavefront's status word: %s", hipGetErrorString(hipGetLastError()));
-  if (!code) return WEKWS_HIP_OK;
-  (void)hipMemsetAsync(ctl + 2, 0, sizeof(code), stream);
-  return fail(WEKWS_HIP_EDEVICE, "a bounded wait of the GRU wavefront gave up (code 0x%x: %s of stage %u): the outputs of the "
-              "forwards issued on this stream since the last check are not valid", code,
-              (code >> 8) == 1 ? "data" : "credit", code & 0xffu);
+  // the documented contract, for EVERY model: the stream is synchronised when this returns (the C++ runtime's Forward reads
+  // its host buffer behind it) -- then the health word, which only streams with wavefront launches have
+  const hipError_t e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  return stream_health(m, stream);
 }
 
 // Test hook (not part of the ABI in include/wekws_hip.h): set the launch epoch of the stream's wavefront control block, so that
 // a test can walk the 32-bit tag counter across its wrap (tests/test_hip_parity.py::test_gru_wavefront_epoch_wrap).
+#ifdef WEKWS_TEST_HOOKS   // libwekws_hip_hooks.so only (make hooks): the product library exports nothing outside the header
 extern "C" int wekws_hip_debug_set_gru_epoch(wekws_hip_model* m, void* stream_, unsigned epoch) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1335,6 +1388,24 @@ extern "C" int wekws_hip_debug_set_gru_epoch(wekws_hip_model* m, void* stream_, 
     return fail(WEKWS_HIP_EDEVICE, "setting the epoch: %s", hipGetErrorString(hipGetLastError()));
   return WEKWS_HIP_OK;
 }
+// A tenant that keeps CUs busy: `blocks` workgroups of 128 KB of LDS each (one per CU, like the wavefront's own), every one
+// holding its CU for `ms` milliseconds of wall clock.  tests: a wavefront launch whose later workgroups find no CU for longer
+// than its bounded waits must END (not hang) and be reported by the next call; a shorter squeeze must change nothing.
+__global__ void debug_hog_kernel(unsigned long long ticks) {
+  extern __shared__ char hog_lds[];
+  if (threadIdx.x == 0) hog_lds[0] = 1;
+  const unsigned long long t0 = wall_clock64();              // 100 MHz
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+extern "C" int wekws_hip_debug_hog(int device, int blocks, int ms, void* stream_) {
+  DeviceGuard guard(device);
+  if (!guard.ok || blocks <= 0 || ms < 0 || ms > 2000) return fail(WEKWS_HIP_EINVAL, "hog: device %d blocks %d ms %d", device, blocks, ms);
+  static wekws::DynLdsGrant grant;
+  if (wekws::grant_dynamic_lds(debug_hog_kernel, 128 * 1024, grant)) return fail(WEKWS_HIP_EDEVICE, "hog: LDS grant");
+  hipLaunchKernelGGL(debug_hog_kernel, dim3(blocks), dim3(64), 128 * 1024, static_cast<hipStream_t>(stream_), 100000ull * ms);
+  return hipGetLastError() == hipSuccess ? WEKWS_HIP_OK : fail(WEKWS_HIP_EDEVICE, "hog launch");
+}
+#endif
 
 int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const float* in_cache, float* y,
                       float* out_cache, int softmax, void* stream_) {
@@ -1355,7 +1426,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     if (rc) return rc;
   } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
     const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32 && wekws::gru_f16_supported(m->gq);
-    int rc;
+    // a wavefront launch of an EARLIER call on this stream that gave up is reported here, by the call that follows it (one
+    // read of host memory; the reference's forward either returns correct values or raises -- keyword_spotting.cc:77-79)
+    int rc = stream_health(m, stream);
+    if (rc) return rc;
     float* user_h_out = nullptr;
     if (m->user_hdim) {                                      // zero-padded hidden size: widened copies of the caller's states
       const size_t need = workspace_need(m, B, T);
@@ -1380,10 +1454,12 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       if (gru_pipe_call(m, B, T)) {
         wekws::GruPipeBytes pb{};
         wekws::gru_pipe_bytes(d.num_layers, B, T, m->fsmn_cus, &pb);
-        char* gran = stream_workspace(m, stream, pb.granules(d.num_layers), true);
+        wekws::GruPipeGeom geo;
+        wekws::gru_pipe_geom(d.num_layers, B, T, m->fsmn_cus, &geo);
+        char* gran = stream_workspace(m, stream, pb.granules(d.num_layers), true, unsigned(geo.slots) << 8 | unsigned(d.num_layers));
         if (!gran) return WEKWS_HIP_ENOMEM;
         wekws::GruPipeWorkspace ws{};
-        ws.ctl = stream_ctl(m, stream);
+        ws.ctl = stream_ctl(m, stream, &ws.err);
         if (!ws.ctl) return WEKWS_HIP_ENOMEM;
         ws.seq_in = base;
         ws.seq_top = ws.seq_in + pb.seq;

@@ -16,7 +16,7 @@ from typing import Dict, List, Mapping, Tuple
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2          # include/wekws_hip.h; the descriptor / blob layout is unchanged since 1 (load_packed reads both)
 BACKBONE = dict(ds_tcn=0, tcn=1, mdtc=2, gru=3, fsmn=4)
 HEAD = dict(linear=0, glob=1, last=2, identity=3)
 BN_EPS = 1e-5
@@ -343,6 +343,7 @@ def load_packed(path: str) -> Tuple[dict, np.ndarray]:
     if blob.size != n or fields.size != 16:
         raise ValueError(f"{path}: truncated")
     desc = {k: int(v) for k, v in zip(DESC_FIELDS, fields)}
-    if desc["abi_version"] != ABI_VERSION or blob.size != blob_elems(desc):
+    if desc["abi_version"] not in (1, ABI_VERSION) or blob.size != blob_elems(desc):
         raise ValueError(f"{path}: ABI version / size mismatch")
+    desc["abi_version"] = ABI_VERSION                           # (files written under version 1 carry the same layout)
     return desc, blob

@@ -39,6 +39,13 @@ Rank 0 prints ONE JSON line.  Besides the contract fields:
                   chunks (oracle/torch_ref.py), B = 1.
   rooflines_other ds256_stream_kernel at 4096 streams (HBM-bound by construction: the cache round trip) and fbank_kernel.
   also / score_only   MDTC h64 on the same batch; the DS-TCN batch with the cache hand-over dropped (score.py:125).
+  value_no_preheat   the contract's W + K steps taken FIRST, on the idle GPU, before any preheat (`--preheat 0` gives the same
+                  as `value`): both readings of "W warm-up steps" exist in one line.
+  config4_shard / config5   BASELINE.json configs 4 and 5 as ONE GPU sees them: B = 8192 utterances per launch (DS-TCN h256, MDTC
+                  h64; default precision), and the 12-class MDTC + GlobalClassifier with precision "f16" (fp16 operands, ONE
+                  fp16 MFMA per product -- the roofline there is the full 2500 TF) at B = 1024 and 8192, next to the same
+                  model in the default precision.
+  audio_to_posteriors   fbank_kernel + the headline forward back to back on 1024 x 1 s of PCM (the whole device-side pipeline).
   cpu_baseline    the reference's CPU path (PyTorch CPU operator sequence, oracle/torch_ref.py) on this box's host cores:
                   B = 1024 batches with all hardware threads, with one core, a short sweep of thread counts, and rows
                   with one OpenMP thread PINNED per physical core (OMP_PROC_BIND=close, OMP_PLACES=cores, affinity to one
@@ -60,11 +67,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_UTT = {"ds_tcn_h256": 55_093_248, "mdtc_h64": 28_888_832, "gru_2x128": 39_588_864,  # SURVEY.md 8d (T = 98)
-                "mdtc_small": 5_889_408,
+                "mdtc_small": 5_889_408, "mdtc_h64_global12": 28_873_472,
                 "ds_tcn_h64": 2 * 98 * (40 * 64 + 4 * (8 * 64 + 64 * 64) + 64)}                # = 4,126,976 (hey_snips ds_tcn.yaml)
 BYTES_PER_UTT = 98 * 40 * 4 + 98 * 2 * 4          # features in + posteriors out = 16,464 B
 CACHE_BYTES_PER_UTT = 256 * 105 * 4                # the (256, 105) streaming cache forward() also returns
-CACHE_BYTES = {"ds_tcn_h256": 256 * 105 * 4, "mdtc_h64": 64 * 244 * 4, "gru_2x128": 2 * 128 * 4}   # per utterance / stream
+CACHE_BYTES = {"ds_tcn_h256": 256 * 105 * 4, "mdtc_h64": 64 * 244 * 4, "gru_2x128": 2 * 128 * 4,   # per utterance / stream
+               "mdtc_h64_global12": 64 * 244 * 4}
 PEAK_F32_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_F16_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -169,6 +177,9 @@ def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_o
            "unit": "utts/s", "step_ms": pct(ts), "steps": steps, "precision": precision}
     if name in FLOP_PER_UTT and not score_only:                      # its own roofline (BASELINE config 2 is this model)
         prec = {"default": "f16x3"}.get(precision, precision)
+        if prec != "f32" and m.effective_precision() != prec:        # (a mode this shape has no kernel for runs f16x3 / f32)
+            prec = m.effective_precision()
+            out["precision_effective"] = prec
         roof = mfma_roofline(name, B, med, prec)
         roof["kernel_ms_note"] = "median step of this loop (HIP events per group of launches)"
         attach_profile(roof, name, B, prec)
@@ -372,7 +383,16 @@ def cpu_baseline(cfg, sd, T, idim, model_name="ds_tcn_h256"):
             value, vcores = sharded["utts_per_s"], int(sharded["cores"])
             how = (f"{sharded['processes']} processes x {sharded['threads_per_process']} pinned threads, utterances split over the "
                    "processes as over GPU ranks")
-    return {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port",
+    # spread of the reported row across repeats (11.2 k / 13.4 k / 15.1 k across boxes and sessions)
+    reps = [value]
+    if sharded and sharded.get("utts_per_s", 0) >= value:
+        for _ in range(3):
+            r = cpu_sharded_row(model_name, T, budget_s=3.0)
+            if r and r.get("utts_per_s"):
+                reps.append(r["utts_per_s"])
+    spread = {"samples": len(reps), "median": round(float(np.median(reps)), 1), "p10": round(float(np.percentile(reps, 10)), 1),
+              "p90": round(float(np.percentile(reps, 90)), 1), "min": round(min(reps), 1), "max": round(max(reps), 1)}
+    return {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port", "spread": spread,
             "sample": f"batches of T={T} utterances through oracle/torch_ref.py -- the reference's PyTorch CPU operator sequence "
                       f"(F.linear / conv1d / batch_norm, fp32) -- for 3 .. 8 s per row; reported: {how}; host has {ncpu} hardware "
                       f"threads on {nphys} physical cores (of those this process may use); the port against the real "
@@ -432,6 +452,9 @@ def main():
     from wekws_amd.model.kws_model import init_model
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    if torch.cuda.device_count() <= local or torch.cuda.device_count() < min(args.gpus, world):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} (LOCAL_RANK {local}) sees {torch.cuda.device_count()} GPU(s); "
+                         "one rank per GPU needs at least as many visible devices (check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -453,6 +476,24 @@ def main():
     prec = {"default": "f16x3"}.get(args.precision, args.precision)
 
     x = torch.from_numpy(synth.synth_feats(B, T, idim, seed=100 + rank)).to(dev)
+    # The contract's W + K steps as the idle GPU runs them, BEFORE any preheat (`value_no_preheat`: the literal reading of
+    # "W warm-up steps, then K timed steps"; the clocks are still ramping, so it is the lower of the two readings).
+    for _ in range(args.warmup):
+        y, cache = model(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        y, cache = model(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    cold = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(cold, op=dist.ReduceOp.MAX)
+    cold_s = float(cold.item())
     # bring the GPU out of its idle power state (clock ramp) with the workload itself; then the contract's W + K steps
     t_pre, n_pre = time.perf_counter(), 0
     while time.perf_counter() - t_pre < args.preheat:
@@ -489,6 +530,13 @@ def main():
     # the same steps with the result dropped at once (one output buffer recycled by the caching allocator)
     step_ms_single = time_steps(torch, lambda: model(x), max(50, args.steps), 0)
     rank_rates, bc_ms_max = [B * args.steps / elapsed], t_bc * 1e3
+    props = torch.cuda.get_device_properties(dev)
+    place = {"rank": rank, "local_rank": local, "device": f"cuda:{local}", "name": props.name,
+             "cus": int(props.multi_processor_count), "host": socket.gethostname(), "pid": os.getpid()}
+    places = [place]
+    if world > 1:
+        places = [None] * world
+        dist.all_gather_object(places, place)
     if world > 1:
         mine = torch.tensor([elapsed, t_bc], dtype=torch.float64, device=dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
@@ -515,7 +563,14 @@ def main():
                        "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": prec,
                        "preheat": f"{args.preheat} s ({n_pre} steps) of the same forward before the {args.warmup} warm-up steps "
                                   "(GPU clock ramp out of idle); then exactly K timed steps",
+                       "input": "every step reads the SAME 16 MB feature batch (it stays in the 256 MB memory-side cache), so "
+                                "`hbm_*` are nominal figures; irrelevant to the bound: the kernel is matrix-pipe-bound "
+                                "(3,346 FLOP per algorithmic byte)",
                        "parallelism": f"utterance-parallel x{world}"},
+            "value_no_preheat": {"value": round(B * world * args.steps / cold_s, 1), "unit": "utts/s",
+                                 "ms_per_step": round(cold_s / args.steps * 1e3, 4),
+                                 "note": f"the same {args.warmup} + {args.steps} steps taken first, on the idle GPU, before the preheat "
+                                         "(wall clock, barriers + synchronize on both sides, MAX over ranks)"},
             "step_ms": dict(pct(step_ms), samples=len(step_ms), launches_per_sample=GROUP),
             "value_single_output_buffer": {
                 "value": round(B * world / float(np.median(step_ms_single)) * 1e3, 1), "unit": "utts/s",
@@ -530,7 +585,10 @@ def main():
                            "broadcast_ms_max_over_ranks": round(bc_ms_max, 3),
                            "note": "one broadcast of the weights before the timed region (RCCL over xGMI for backend nccl); "
                                    "the forward itself has no collective"}
-            out["per_rank_utts_per_s"] = {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1)}
+            out["per_rank_utts_per_s"] = {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1),
+                                          "all": [round(r, 1) for r in rank_rates]}
+            out["comm"]["ranks"] = places
+            assert len({(p["host"], p["device"]) for p in places}) == world, f"two ranks share a GPU: {places}"
         if args.model in FLOP_PER_UTT:
             roof = mfma_roofline(args.model, B, kern_ms, prec)
             roof["kernel_ms_note"] = "HIP events around the K timed steps / K"
@@ -553,6 +611,21 @@ def main():
             # ds_tcn.yaml, mdtc_small.yaml: the register-resident kernels of round 4), each with its own roofline
             out["gru"] = secondary(torch, init_model, pack, synth, dev, "gru_2x128", B, T)
             out["small_recipes"] = {n: secondary(torch, init_model, pack, synth, dev, n, B, T) for n in ("ds_tcn_h64", "mdtc_small")}
+            # ---- BASELINE.json configs 4 and 5 as one GPU sees them
+            out["config4_shard"] = {
+                "note": "configs[3] shards B = 8192 over 8 GPUs (1024 per GPU = `value` / `also`); these are 8192 utterances in ONE "
+                        "launch on one GPU -- eight resident rounds instead of one, the throughput figure of the kernels",
+                "ds_tcn_h256": secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", 8192, T, steps=20),
+                "mdtc_h64": secondary(torch, init_model, pack, synth, dev, "mdtc_h64", 8192, T, steps=20),
+                "small_recipes": {n: secondary(torch, init_model, pack, synth, dev, n, 8192, T, steps=20) for n in ("ds_tcn_h64", "mdtc_small")}}
+            out["config5"] = {
+                "note": "configs[4]: 12-class MDTC h64 + GlobalClassifier, fp16 weights + ONE fp16 MFMA per pointwise product "
+                        "(precision 'f16': posterior error ~1e-3, stated in tests/test_hip_parity.py::test_precision_f16_mode), "
+                        "roofline against the full 2500 TF; the default precision (f16x3, <= 1e-4) beside it",
+                "f16_B1024": secondary(torch, init_model, pack, synth, dev, "mdtc_h64_global12", 1024, T, precision="f16"),
+                "f16_B8192": secondary(torch, init_model, pack, synth, dev, "mdtc_h64_global12", 8192, T, steps=20, precision="f16"),
+                "default_B1024": secondary(torch, init_model, pack, synth, dev, "mdtc_h64_global12", 1024, T),
+                "default_B8192": secondary(torch, init_model, pack, synth, dev, "mdtc_h64_global12", 8192, T, steps=20)}
             # ---- the other half of the metric: per-frame streaming latency, 10-frame chunks, carried cache
             lat = {"unit": "us per frame (10-frame chunks; median / p10 / p90 over 1000 consecutive chunks, HIP events)"}
             for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
@@ -587,6 +660,13 @@ def main():
                           "step_ms": pct(ts), "utts_per_s": round(1024 / med * 1e3, 1),
                           "note": "instruction-bound radix-4 FFT + mel slots (~2.6 MFLOP per utterance), not HBM-bound"})
             out["rooflines_other"] = other
+            # ---- the whole device-side pipeline: PCM in HBM -> log-mel -> posteriors + cache (two launches per step)
+            ts = time_steps(torch, lambda: model(fb(pcm)), 50, 10)
+            med = float(np.median(ts))
+            out["audio_to_posteriors"] = {"workload": "1024 x 1 s of 16 kHz PCM (f32, in HBM) -> fbank_kernel -> ds_tcn_h256 forward",
+                                          "value": round(1024 / med * 1e3, 1), "unit": "utts/s", "step_ms": pct(ts), "steps": 50,
+                                          "pcie_note": "with the PCM coming over PCIe Gen5 x16 (~63 GB/s, 64 KB per utterance) the "
+                                                       "host link caps the pipeline at ~0.98 M utt/s (f32 PCM; int16: ~1.97 M)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim, args.model)
             if extras:

@@ -76,6 +76,61 @@ def test_two_rank_weight_broadcast_and_gather():
     assert res[0][3] == [float(i) for i in range(11)] and res[1][3] is None
 
 
+def _worker8(rank, world, port, q, ckpt_dir):
+    """One of EIGHT ranks of configs[3]'s launch shape (one process per GPU of a node), CPU + gloo: only rank 0 can read the
+    checkpoint FILE (the others get a path that does not exist -- a node-local disk the weights were never copied to), the
+    global batch is uneven (8191 utterances), every rank "scores" its shard and rank 0 gathers in order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, local = parallel.init_distributed(backend="gloo")
+    assert (r, w, local) == (rank, world, rank)
+    from wekws_amd.utils.checkpoint import load_checkpoint
+    cfg = synth.MODEL_CONFIGS["ds_tcn_h64"]
+    model = init_model(cfg)
+    path = os.path.join(ckpt_dir if rank == 0 else os.path.join(ckpt_dir, f"not_mounted_on_rank_{rank}"), "final.pt")
+    if rank == 0:
+        load_checkpoint(model, path)
+    else:
+        assert not os.path.exists(path)
+    parallel.broadcast_weights(model, src=0, device=torch.device("cpu"))
+    blob = model.packed()[1]
+    n = 8191
+    lo, hi = parallel.shard_range(n, rank, world)
+    y_local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1)
+    y = parallel.gather_scores(y_local, n, dst=0)
+    ok = None if y is None else bool(torch.equal(y[:, 0], torch.arange(n, dtype=torch.float32)))
+    q.put((rank, hi - lo, float(np.abs(blob.astype(np.float64)).sum()), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_uneven_batch_one_checkpoint(tmp_path):
+    """The launch shape of BASELINE configs 4 / 5 (8 ranks) without an 8-GPU box: an uneven global batch (8191), a checkpoint
+    file only rank 0 can read, weights identical everywhere after the ONE broadcast, scores gathered in utterance order."""
+    cfg = synth.MODEL_CONFIGS["ds_tcn_h64"]
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 77)
+    ref = init_model(cfg)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    torch.save(ref.state_dict(), str(tmp_path / "final.pt"))
+    _, want = pack.pack(cfg, sd)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, str(tmp_path))) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sizes = [r[1] for r in res]
+    assert sum(sizes) == 8191 and max(sizes) - min(sizes) == 1 and sizes == sorted(sizes, reverse=True)
+    for rank, _, ssum, ok in res:
+        assert abs(ssum - float(np.abs(want.astype(np.float64)).sum())) < 1e-9, rank
+        assert ok is (True if rank == 0 else None)
+
+
 def test_load_packed_is_superseded_by_later_weight_changes():
     """load_packed() installs a folded blob; load_state_dict or an in-place edit afterwards must be honoured, and
     packed() must describe what is actually running."""

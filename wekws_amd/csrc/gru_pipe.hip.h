@@ -61,16 +61,26 @@
 #pragma once
 #include "gru_f16.hip.h"
 
-// Experiment switch of the granule loads (next round: DESIGN.md section 7).  What ships: sc1 loads, served from the fabric.
-// -DWEKWS_GRU_PIPE_L2 builds the candidate for an L2-resident hand-over between stages on one XCD: an L1 invalidate in front
-// of plain loads (only valid while every slot's stages share an XCD -- the observed placement; not selected at run time yet).
-#ifdef WEKWS_GRU_PIPE_L2
+// Policy of the granule loads.  What ships (WEKWS_GRU_PIPE_L2 undefined or 0): sc1 loads, served from the fabric.
+// -DWEKWS_GRU_PIPE_L2=n builds the L2-resident hand-over (round 5): a step's FIRST request is a plain load behind an L1
+// invalidate (n = 1: buffer_inv sc0, n = 2: buffer_inv sc1) -- it is served by this XCD's L2, which holds the line dirty when
+// the producer runs on the same XCD and stored with the default policy (the same-XCD fast path of the stores) -- and every
+// RE-request (the tag check failed: producer late, or on another XCD, where this L2 may hold a stale clean copy for ever) is
+// an sc1 load as before.  So placement never decides correctness, only where the first request is served from.
+#ifndef WEKWS_GRU_PIPE_L2
+#define WEKWS_GRU_PIPE_L2 0
+#endif
+#if WEKWS_GRU_PIPE_L2 == 1
 #define GP_LDPOL ""
 #define GP_LDINV "buffer_inv sc0\n\t"
+#elif WEKWS_GRU_PIPE_L2 == 2
+#define GP_LDPOL ""
+#define GP_LDINV "buffer_inv sc1\n\t"
 #else
 #define GP_LDPOL "sc1"
 #define GP_LDINV ""
 #endif
+#define GP_RETRY_POL "sc1"
 namespace wekws {
 
 constexpr int kGruPipeStages = 2 * kGruMaxLayers;
@@ -143,16 +153,28 @@ __device__ __forceinline__ gp_desc gp_make_desc(const void* base, unsigned bytes
                  unsigned(__builtin_amdgcn_readfirstlane(int(bytes))), 0x00020000u};
 }
 // four 16-byte items at voff + {0, 1, 2, 3} KiB
+template <bool RETRY = false>
 __device__ __forceinline__ void gp_ld4(gp_u32x4 (&g)[4], int voff, gp_desc rs) {
-  asm volatile(
-      GP_LDINV "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_LDPOL
-      : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
-      : "v"(voff), "s"(rs)
-      : "memory");
+  if constexpr (RETRY)
+    asm volatile(
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_RETRY_POL "\n\t"
+        "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_RETRY_POL "\n\t"
+        "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_RETRY_POL "\n\t"
+        "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_RETRY_POL
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
+        : "v"(voff), "s"(rs)
+        : "memory");
+  else
+    asm volatile(
+        GP_LDINV "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_LDPOL "\n\t"
+        "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_LDPOL "\n\t"
+        "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_LDPOL "\n\t"
+        "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_LDPOL
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
+        : "v"(voff), "s"(rs)
+        : "memory");
 }
 template <int N>
 __device__ __forceinline__ void gp_wait4(gp_u32x4 (&g)[4]) {
@@ -168,11 +190,11 @@ __device__ __forceinline__ void gp_wait4_if(gp_u32x4 (&g)[4], unsigned on) {    
 __device__ __forceinline__ void gp_ld4_if(gp_u32x4 (&g)[4], int voff, gp_desc rs, unsigned on) {   // on ? request again : nothing
   asm volatile(
       "s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lgpl%=\n\t"
-      GP_LDINV "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_LDPOL "\n.Lgpl%=:"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %4, %5, 0 offen " GP_RETRY_POL "\n\t"
+      "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 " GP_RETRY_POL "\n\t"
+      "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 " GP_RETRY_POL "\n\t"
+      "buffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 " GP_RETRY_POL "\n.Lgpl%=:"
       : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])
       : "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(int(on)))
       : "memory", "scc");
@@ -184,14 +206,24 @@ __device__ __forceinline__ void gp_wait4_sel(gp_u32x4 (&g)[4], unsigned all) {  
                : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "s"(__builtin_amdgcn_readfirstlane(int(all))), "i"(N) : "memory", "scc");
 }
 // two 16-byte items at voff, voff + 16
+template <bool RETRY = false>
 __device__ __forceinline__ void gp_ld2(gp_u32x4 (&g)[2], int voff, gp_desc rs) {
-  asm volatile(
-      GP_LDINV "s_nop 4\n\t"
-      "buffer_load_dwordx4 %0, %2, %3, 0 offen " GP_LDPOL "\n\t"
-      "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 " GP_LDPOL
-      : "=&v"(g[0]), "=&v"(g[1])
-      : "v"(voff), "s"(rs)
-      : "memory");
+  if constexpr (RETRY)
+    asm volatile(
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %2, %3, 0 offen " GP_RETRY_POL "\n\t"
+        "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 " GP_RETRY_POL
+        : "=&v"(g[0]), "=&v"(g[1])
+        : "v"(voff), "s"(rs)
+        : "memory");
+  else
+    asm volatile(
+        GP_LDINV "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %2, %3, 0 offen " GP_LDPOL "\n\t"
+        "buffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 " GP_LDPOL
+        : "=&v"(g[0]), "=&v"(g[1])
+        : "v"(voff), "s"(rs)
+        : "memory");
 }
 template <int N>
 __device__ __forceinline__ void gp_wait2(gp_u32x4 (&g)[2]) {
@@ -788,6 +820,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       gp_u32x4 ga[4], gb[4];
       const gp_desc ds_g = gp_make_desc(WS.gi[l] + size_t(slot) * RING * GIS, unsigned(RING) * GIS);
       auto load_g = [&](gp_u32x4 (&gg)[4], int t) __attribute__((always_inline)) { gp_ld4(gg, ring_pos(gb0 + min(t, T - 1)) * GIS + gvo, ds_g); };
+      auto reload_g = [&](gp_u32x4 (&gg)[4], int t) __attribute__((always_inline)) { gp_ld4<true>(gg, ring_pos(gb0 + min(t, T - 1)) * GIS + gvo, ds_g); };
       // a time-packed first stage writes the columns of real streams only: the other lanes' granules never arrive
       const bool live = l > 0 || nb > 8 || l15 < nb;
       auto tags_ok = [&](const gp_u32x4 (&gg)[4], unsigned tag) __attribute__((always_inline)) -> bool {
@@ -851,7 +884,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           spins = 0;
           do {
             __builtin_amdgcn_s_sleep(2);
-            load_g(g0, t);
+            reload_g(g0, t);
             gp_wait4<0>(g0);
             if (give_up(spins, 0x100u)) break;
           } while (!tags_ok(g0, tag));
@@ -1026,6 +1059,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       gp_u32x4 raw[2];
       const gp_desc ds_i = gp_make_desc(WS.hs[l - 1] + size_t(slot) * RING * HSS, unsigned(RING) * HSS);
       auto load_h = [&](int t) __attribute__((always_inline)) { gp_ld2(raw, ring_pos(gb0 + t) * HSS + pvo, ds_i); };
+      auto reload_h = [&](int t) __attribute__((always_inline)) { gp_ld2<true>(raw, ring_pos(gb0 + t) * HSS + pvo, ds_i); };
       unsigned spins = 0;
       // waits until this wave's share of step t is there, then writes it into plane buffer `buf`; `behind` = this wave has
       // issued the step's four gate stores behind the request (they may stay out)
@@ -1042,7 +1076,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           spins = 0;
           do {
             __builtin_amdgcn_s_sleep(2);
-            load_h(t);
+            reload_h(t);
             gp_wait2<0>(raw);
             if (give_up(spins, 0x100u)) break;
           } while (stale());

@@ -254,7 +254,9 @@ class KWSModel(nn.Module):
 
     def check(self, device: Optional[torch.device] = None) -> "KWSModel":
         """Synchronise the current stream and raise if a device-side wait of an earlier forward gave up
-        (wekws_hip_forward_status; only the GRU wavefront has such waits).  Cheap where results are read anyway."""
+        (wekws_hip_forward_status; only the GRU wavefront has such waits).  Optional: a forward that gave up is also
+        reported by the NEXT forward() on the same stream, which raises without being asked -- this is the call for the last
+        forward of a script, and a cheap synchronisation point where results are read anyway."""
         dev = device or next(self.parameters()).device
         h = self._get_handle(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream

@@ -149,8 +149,14 @@ def test_two_processes_share_the_gpu():
             outs = [pipe(x) for _ in range(8)]
             torch.cuda.synchronize()
             for y1, c1 in outs:
-                assert torch.equal(y1, y0) and torch.equal(c1, c0), n
-            n += len(outs)
+                if not (torch.equal(y1, y0) and torch.equal(c1, c0)):
+                    try:
+                        pipe.check()
+                        rep = "NOT reported by the health word (silent)"
+                    except Exception as e:       # noqa: BLE001
+                        rep = f"reported: {e}"
+                    raise AssertionError(f"parent launch {n}: {int((y1 != y0).sum())} posteriors differ; {rep}")
+                n += 1
         out, err = p.communicate(timeout=60)
     finally:
         if p.poll() is None:

@@ -68,6 +68,23 @@ def epoch_wrap():
     pipe.check()
 
 
+def _same(pipe, got, want, what):
+    """Bit-identical, or say exactly how not: a mismatch the library REPORTS (a bounded wait gave up) and one it does not are
+    different failures."""
+    (y1, c1), (y0, c0) = got, want
+    if torch.equal(y1, y0) and torch.equal(c1, c0):
+        return
+    torch.cuda.synchronize()
+    ny, nc = int((y1 != y0).sum()), int((c1 != c0).sum())
+    try:
+        pipe.check()
+        rep = "NOT reported by the health word (silent)"
+    except _capi.HipLibraryError as e:
+        rep = f"reported: {e}"
+    raise AssertionError(f"{what}: {ny} of {y0.numel()} posteriors and {nc} of {c0.numel()} states differ "
+                         f"(max |dy| {float((y1 - y0).abs().max()):.3e}); {rep}")
+
+
 def _hog_setup():
     cfg = gru_cfg(2)
     sd = synth.synth_state_dict(pack.model_spec(cfg), 4250)
@@ -122,9 +139,9 @@ def squeezed():
     for it in range(5):
         assert lib.wekws_hip_debug_hog(dev.index, 250, 30, ctypes.c_void_p(side.cuda_stream)) == 0, _capi.last_error()
         time.sleep(0.005)
-        y1, c1 = pipe(x)
+        got = pipe(x)
         torch.cuda.synchronize()
-        assert torch.equal(y1, y0) and torch.equal(c1, c0), it
+        _same(pipe, got, (y0, c0), f"squeezed launch {it}")
     pipe.check()
 
 
@@ -143,9 +160,9 @@ def worker(seconds):
     while time.time() - t0 < seconds:
         outs = [pipe(x) for _ in range(8)]
         torch.cuda.synchronize()
-        for y1, c1 in outs:
-            assert torch.equal(y1, y0) and torch.equal(c1, c0), n
-        n += len(outs)
+        for got in outs:
+            _same(pipe, got, (y0, c0), f"worker launch {n}")
+            n += 1
     pipe.check()
     print(f"done {n}", flush=True)
 

@@ -94,11 +94,16 @@ constexpr int kGruPipeRingLog = 4, kGruPipeRing = 1 << kGruPipeRingLog;
 // [16 + 2 slots * stages + slot * stages + stage] where the workgroup runs: tag0 << 4 | XCD
 constexpr int kGruPipeCtlWords = 16 + 3 * kGruPipeMaxSlots * kGruPipeStages;
 constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
-// Bound of ONE wait, in re-requests (~1 .. 2 us each: a load's round trip plus the sleep): ~0.1 s of EXECUTED waiting -- a count,
-// not a wall-clock reading, so that a queue the scheduler pre-empts in favour of another process does not time out while its
-// waves are saved.  A wait that gives up marks the whole launch dead (every later wait of every workgroup falls through at
-// once: the launch ends within a few of these bounds), and the host hears of it on its next call (GruPipeWorkspace::err).
-constexpr unsigned kGruPipeSpinLimit = 1u << 16;
+// Bound of ONE wait, in re-requests.  The first kGruPipeFastSpins are back to back (~0.5 .. 1 us each: a load's round trip);
+// from then on every re-request sleeps ~3 us first (s_sleep 100 = 6400 clocks), so the bound is 0.1 .. 0.2 s of EXECUTED
+// waiting whatever the memory system's latency is (round 5's first cut counted 2^16 back-to-back re-requests -- ~30 ms: a
+// launch squeezed for 30 ms by another tenant gave up, measured) -- a count, not a wall-clock reading, so that a queue the
+// scheduler pre-empts in favour of another process does not time out while its waves are saved; and a waiting workgroup
+// stops hammering the fabric with requests after the first ~50 us.  A wait that gives up marks the whole launch dead
+// (every later wait of every workgroup falls through at once: the launch ends within a few of these bounds), and the host
+// hears of it on its next call (GruPipeWorkspace::err).
+constexpr unsigned kGruPipeFastSpins = 64;
+constexpr unsigned kGruPipeSpinLimit = 1u << 15;
 constexpr int kGruPipeGiStep = 8 * 4 * 1024;                  // bytes of one step of gate granules: [wave][item][lane][16]
 constexpr int kGruPipeHStep = 16 * 16 * 64;                   // bytes of one step of state granules: [k-octet][stream][8][8]
 constexpr int kGruPipePlanes = 128 * 1024;                    // staging buffers of stage 0; 16 steps of planes of a time-packed tile
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   auto give_up = [&](unsigned& spins, unsigned what) __attribute__((always_inline)) -> bool {
     if (dead) return true;
     ++spins;
+    if (spins > kGruPipeFastSpins) __builtin_amdgcn_s_sleep(100);
     if ((spins & 63u) == 0u && gp_ld_ctl(ctl + 2) != 0u) { dead = 1u; return true; }
     if (spins <= kGruPipeSpinLimit) return false;
     dead = 1u;

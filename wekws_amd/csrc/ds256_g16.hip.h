@@ -427,31 +427,14 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     //      here nothing is requested behind them until the next block's fragments, which are not needed before ITS matrix
     //      phase -- a whole depthwise phase later.  (A detour through LDS for 16-byte row segments, 22 store instructions
     //      instead of 48, was measured 2 % slower than the direct stores; so was spreading the whole-lane runs over the
-    //      depthwise phase, two store instructions between every four taps: +2.7 %, their addresses live across the phase.)
+    //      depthwise phase, two store instructions between every four taps: +2.7 %, their addresses live across the phase.
+    //      Round 5: the same runs as buffer stores (scalar base, 32-bit offsets), plain and non-temporal: 0.2025 / 0.2009 ms
+    //      against 0.2023 / 0.2011 -- noise; gpurun_out/r05b_handover_ab.txt.)
     auto hand_over = [&]() __attribute__((always_inline)) {
       if (A.out_cache) {
         float* const oc = A.out_cache + (int64_t(b) * C + o0) * Pc + bd.cache_off;
         const int p0 = NT * l15 - (T - pad);                   // slice column of this lane's first frame
         if (p0 >= 0 && p0 + NT <= pad) {                       // the lane's NT frames are NT consecutive columns of the slice
-#if defined(WEKWS_G16_HANDOVER) && WEKWS_G16_HANDOVER > 0
-          // experiment (round 5): the same runs as BUFFER stores -- one scalar base per utterance, 32-bit lane offsets, the row
-          // stride an SGPR -- and (== 2) marked non-temporal, so that 107 KB of cache rows per utterance streaming through the
-          // XCD's 4 MB L2 do not push the 1.15 MB weight image out of it
-          if constexpr (NT == 7) {
-            typedef unsigned g16_u32x4 __attribute__((ext_vector_type(4)));
-            typedef unsigned g16_u32x3 __attribute__((ext_vector_type(3)));
-            constexpr int AUX = WEKWS_G16_HANDOVER == 2 ? 2 : 0;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(A.out_cache + int64_t(b) * C * Pc, 0, C * Pc * 4, 0x00020000);
-            const int vo = ((o0 * Pc) + bd.cache_off + p0) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const g16_u32x4 v4 = {__float_as_uint(hv[0][r]), __float_as_uint(hv[1][r]), __float_as_uint(hv[2][r]), __float_as_uint(hv[3][r])};
-              const g16_u32x3 v3 = {__float_as_uint(hv[4][r]), __float_as_uint(hv[5][r]), __float_as_uint(hv[6][r])};
-              __builtin_amdgcn_raw_buffer_store_b128(v4, rs, vo + r * Pc * 4, 0, AUX);
-              __builtin_amdgcn_raw_buffer_store_b96(v3, rs, vo + r * Pc * 4 + 16, 0, AUX);
-            }
-          } else
-#endif
 #pragma unroll
           for (int r = 0; r < 4; ++r) g16_store_run<NT>(oc + r * Pc + p0, hv, r);
         } else if (p0 + NT > 0 && p0 < pad) {                  // (NT does not divide T: slice boundary inside the lane)

@@ -584,80 +584,14 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
         // NKP == 2 (the launcher: idim <= 64 in whole octets, 16-byte aligned rows): the requests are inline assembly with a
         // counted wait -- behind them the wave issues I0's 16 stores, and hipcc's own bookkeeping would wait for those too
         // (vmcnt(0) at the head of P).  Otherwise: plain loads.
-        static_assert(CS == 4, "gp_waitx16 names four steps");
+        static_assert(CS == 4, "one preparing wave pair per step of a chunk");
         constexpr bool XF = NKP == 2;
-        f32x4 xq[XF ? CS : 1][4];
-        gru_f32x8 xr[XF ? 1 : CS][NKP];
         const float* xp0 = x + (int64_t(min(sx_, B - 1)) * T) * idim + lq * 8;               // K step 0: features 8 lq ..
         const float* xp1 = xp0 + ((32 + lq * 8 < idim) ? 32 : 0);                          // K step 1 (clamped when outside)
         const bool xv0 = sx_ < bend && lq * 8 < idim, xv1 = sx_ < bend && 32 + lq * 8 < idim;
-        auto x_chunk = [&](int t0) __attribute__((always_inline)) {
-          if constexpr (XF) {
-#pragma unroll
-            for (int dt = 0; dt < CS; ++dt) {
-              const int64_t to = int64_t(min(t0 + dt, T - 1)) * idim;
-              gp_ldx4(xq[dt], xp0 + to, xp1 + to);
-            }
-          } else {
-#pragma unroll
-            for (int dt = 0; dt < CS; ++dt)
-#pragma unroll
-              for (int ks = 0; ks < NKP; ++ks) xr[dt][ks] = load_x8(sx_, t0 + dt, ks, sx_ < bend && t0 + dt < T);
-          }
-        };
-        // the features of step t0 + dt, K step ks (zeros where the tile / the utterance / the feature vector ends)
-        auto x_get = [&](int t0, int dt, int ks) __attribute__((always_inline)) -> gru_f32x8 {
-          if constexpr (XF) {
-            const bool ok = t0 + dt < T && (ks ? xv1 : xv0);
-            const f32x4 a = xq[dt][2 * ks], b = xq[dt][2 * ks + 1];
-            return ok ? gru_f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} : gru_f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          } else {
-            return xr[dt][ks];
-          }
-        };
-        x_chunk(0);
-        if constexpr (XF) gp_waitx16<0>(xq[0], xq[1], xq[2], xq[3]);
         float inv_c[CS], inv_n[CS];
 #pragma unroll
         for (int dt = 0; dt < CS; ++dt) inv_n[dt] = 1.f;
-        auto p_step = [&](int t0, int dt, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
-          {
-            const int t = t0 + dt;
-            inv[dt] = 1.f;
-            if (t < T) {
-              float ax = 0.f;                                   // max|x[t]| over the tile: every wave holds the whole step
-#pragma unroll
-              for (int ks = 0; ks < NKP; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(x_get(t0, dt, ks)[j]));
-              ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
-              float cx, inv_s0;
-              const float sx = pow2_scale(ax, &cx);
-              const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
-              cx *= Q.pre_inv_s;
-              inv[dt] = inv_s0;
-              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-              for (int ks = 0; ks < NKP; ++ks) {
-                const gru_f32x8 xs = x_get(t0, dt, ks) * sx;
-                const f16x8 bh = __builtin_convertvector(xs, f16x8);
-                const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
-                gru_mfma1(acc, a[ks], bh, bl);
-              }
-              f32x4 v = acc * cx + bpre;
-              if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
-              f16x4 vh, vl;
-              gru_split4(v * s0, vh, vl);
-              char* dst = buf + dt * SEQ + wr_off;
-              *reinterpret_cast<f16x4*>(dst) = vh;
-              *reinterpret_cast<f16x4*>(dst + PH) = vl;
-            }
-          }
-        };
-        auto p_chunk = [&](int t0, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
-#pragma unroll
-          for (int dt = 0; dt < CS; ++dt) p_step(t0, dt, buf, inv);
-        };
         // gi0 of step t0 + dt from the planes of chunk buffer `buf`
         auto i_step = [&](int t0, int dt, const char* buf) __attribute__((always_inline)) {
           const int t = t0 + dt;
@@ -678,18 +612,91 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             gp_st_gates(v, lap_tag(gb0 + t), rs_g, ring_pos(gb0 + t) * GIS + gvo, near);
           }
         };
-        p_chunk(0, gp_lds, inv_c);
         if constexpr (XF) {
-          // P(c + 1) and I0(c) do not depend on each other: they are INTERLEAVED step by step.  Measured at B = 1024 with the
-          // two as separate phases (stamps, round 4): the stage was the slowest of the pipeline at 9.8 us per chunk -- I0 is
-          // bound by the CU's store issue (128 wave-stores, the next chunk's feature requests queueing behind them for 2 us),
-          // P by the vector pipe with the matrix pipe idle, and 1.5 us of every chunk went into the skew at the barrier.
-          // A step's four feature requests are re-issued as soon as P has consumed the registers -- for the step one chunk on
-          // -- so a request is a whole iteration old when it is waited for: behind it the wave has issued exactly
-          // 4 stores + 3 x (4 requests + 4 stores) + the dt x (4 + 4) of this iteration = 28 operations whatever dt is.  (The
-          // first iteration's requests come from the prologue, with fewer behind them: it waits for everything.)
-          if (CS < T) x_chunk(CS);
-          gp_barrier();
+          // ---- round 5: the feature operand is made ONCE per step, not by every wave.  Stamps at B = 1024 x 98 frames (round 5,
+          // tools/probe/gru_stamps.py) showed THIS stage -- which has no recurrence and was meant to run ahead -- as the slowest
+          // of the pipeline: 8.3 us per 4-step chunk = 2.07 us per step with everything downstream in lock-step behind it (the
+          // recurrences need ~1.3).  Its 168 MFMAs per wave and chunk are 2.6 us; the rest was eight waves each loading the
+          // WHOLE feature step (128 wave-loads per chunk next to the 128 gate stores, on a CU whose vector-memory path issues one
+          // wave-instruction per ~30 .. 60 cycles), each taking the tile maximum, scaling, splitting and converting the same
+          // B fragments (~100 vector instructions per wave and step, 8 x redundant).  Now wave w prepares K step w / 4 of step
+          // w % 4 of the chunk AFTER the next -- both K steps loaded for the maximum (32 wave-loads per chunk), one converted --
+          // into fragment-ordered planes in LDS (hi | lo, 1 KiB each: a fragment is one ds_read_b128 at lane x 16) together
+          // with the step's three scale constants; P then reads fragments and constants like I0 reads its planes.  Same values in
+          // the same lanes, same instructions on them: bit-identical.  LDS: 64 KB of in0 planes (as before) + 32 KB + 128 B.
+          constexpr int XST = 4096;                               // bytes of one step of feature planes: [K step][hi | lo][lane][16]
+          char* const xpl = gp_lds + 2 * CHUNK;                   // [2 chunks][CS steps][XST]
+          float* const xsc = reinterpret_cast<float*>(xpl + 2 * CS * XST);   // [2][CS][4]: cx, s0, 1 / s0, -
+          static_assert(2 * CHUNK + 2 * CS * XST + 2 * CS * 16 <= kGruPipeLds, "feature planes behind the staging buffers");
+          const int pdt = wave & 3;
+          const bool pk1 = wave >= 4;                             // this wave converts K step 1 (else 0) of step pdt
+          f32x4 xq1[4];
+          auto x_req = [&](int t) __attribute__((always_inline)) {
+            const int64_t to = int64_t(min(t, T - 1)) * idim;
+            gp_ldx4(xq1, xp0 + to, xp1 + to);
+          };
+          // the registers hold step t0c + pdt: maximum over the tile, scales, this wave's K step as fragments -> planes `xb`
+          auto x_prep = [&](int t0c, int xb) __attribute__((always_inline)) {
+            const int t = t0c + pdt;
+            if (t < T) {
+              const gru_f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              const gru_f32x8 k0 = xv0 ? gru_f32x8{xq1[0][0], xq1[0][1], xq1[0][2], xq1[0][3], xq1[1][0], xq1[1][1], xq1[1][2], xq1[1][3]} : z8;
+              const gru_f32x8 k1 = xv1 ? gru_f32x8{xq1[2][0], xq1[2][1], xq1[2][2], xq1[2][3], xq1[3][0], xq1[3][1], xq1[3][2], xq1[3][3]} : z8;
+              float ax = 0.f;                                     // max|x[t]| over the tile
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fmaxf(fabsf(k0[j]), fabsf(k1[j])));
+              ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
+              float cx, inv_s0;
+              const float sx = pow2_scale(ax, &cx);
+              const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+              cx *= Q.pre_inv_s;
+              const gru_f32x8 xs = (pk1 ? k1 : k0) * sx;
+              const f16x8 bh = __builtin_convertvector(xs, f16x8);
+              const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
+              char* dst = xpl + (xb * CS + pdt) * XST + (pk1 ? 2048 : 0) + lane * 16;
+              *reinterpret_cast<f16x8*>(dst) = bh;
+              *reinterpret_cast<f16x8*>(dst + 1024) = bl;
+              if (!pk1 && lane == 0) *reinterpret_cast<f32x4*>(xsc + (xb * CS + pdt) * 4) = f32x4{cx, s0, inv_s0, 0.f};
+            }
+          };
+          // in0[t0 + dt] = [ReLU](Wpre x + b) from feature planes `xb`, scaled, split, into the in0 planes `buf`
+          auto p_step = [&](int t0, int dt, char* buf, int xb, float (&inv)[CS]) __attribute__((always_inline)) {
+            const int t = t0 + dt;
+            inv[dt] = 1.f;
+            if (t < T) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(xsc + (xb * CS + dt) * 4);
+              const char* xf = xpl + (xb * CS + dt) * XST + lane * 16;
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(xf + ks * 2048);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xf + ks * 2048 + 1024);
+                gru_mfma1(acc, a[ks], bh, bl);
+              }
+              f32x4 v = acc * sc[0] + bpre;
+              if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+              f16x4 vh, vl;
+              gru_split4(v * sc[1], vh, vl);
+              char* dst = buf + dt * SEQ + wr_off;
+              *reinterpret_cast<f16x4*>(dst) = vh;
+              *reinterpret_cast<f16x4*>(dst + PH) = vl;
+              inv[dt] = sc[2];
+            }
+          };
+          // prologue: feature planes of chunks 0 and 1, in0 planes of chunk 0
+          x_req(pdt);
+          gp_waitx4_sel<0>(xq1, 0u);
+          x_prep(0, 0);
+          if (CS < T) x_req(CS + pdt);
+          gp_barrier();                                           // feature planes of chunk 0
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt) p_step(0, dt, gp_lds, 0, inv_c);
+          if (CS < T) {
+            gp_waitx4_sel<0>(xq1, 0u);
+            x_prep(CS, 1);
+            if (2 * CS < T) x_req(2 * CS + pdt);
+          }
+          gp_barrier();                                           // in0 planes of chunk 0, feature planes of chunk 1
           for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
             const char* const buf = gp_lds + (c & 1) * CHUNK;
             char* const nbuf = gp_lds + ((c + 1) & 1) * CHUNK;
@@ -697,8 +704,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             GP_STAMP(1, t0);
             wait_credit(gb0 + min(t0 + CS, T) - 1);               // (a poll's loads only add to what is behind the requests)
             // Waves w and w + 4 share a SIMD: one of the two does its products first and its preprocessing second, the other
-            // the other way round -- P is vector work, I0 matrix work and stores.  The count behind a step's requests is 28
-            // in either order (16 stores + 12 requests).  (+4 % at B = 1024.)
+            // the other way round -- P is vector work, I0 matrix work and stores.
             const bool i_first = wave >= 4;
             if (i_first) {
 #pragma unroll
@@ -706,11 +712,15 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             }
             if (more) {
 #pragma unroll
-              for (int dt = 0; dt < CS; ++dt) {
-                gp_waitx4_sel<28>(xq[dt], c > 0 ? 1u : 0u);
-                p_step(t0 + CS, dt, nbuf, inv_n);
-                const int64_t to = int64_t(min(t0 + 2 * CS + dt, T - 1)) * idim;
-                gp_ldx4(xq[dt], xp0 + to, xp1 + to);
+              for (int dt = 0; dt < CS; ++dt) p_step(t0 + CS, dt, nbuf, (c + 1) & 1, inv_n);
+              // the features of chunk c + 2 were requested one iteration ago: behind the request this wave has issued the 16
+              // gate stores of one full chunk (I0 of chunk c - 1 or c, whichever comes first in this wave's order) and nothing
+              // else, whatever the order -- vmcnt(16) is exact; the first iteration's request comes from the prologue with
+              // fewer behind it and waits for everything.  Their planes are the ones P(c) read one iteration ago.
+              if (t0 + 2 * CS < T) {
+                gp_waitx4_sel<16>(xq1, c > 0 ? 1u : 0u);
+                x_prep(t0 + 2 * CS, c & 1);
+                if (t0 + 3 * CS < T) x_req(t0 + 3 * CS + pdt);
               }
             }
             if (!i_first) {
@@ -722,8 +732,51 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
             gp_barrier();
           }
-          gp_waitx16<0>(xq[0], xq[1], xq[2], xq[3]);            // (the last iteration's requests: nothing may still be landing)
+          gp_waitx4_sel<0>(xq1, 0u);                              // (nothing may still be landing when the registers are re-used)
         } else {
+          // any other feature layout: every wave loads and converts the step itself (plain loads, the compiler's own waits)
+          gru_f32x8 xr[CS][NKP];
+          auto x_chunk = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int dt = 0; dt < CS; ++dt)
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks) xr[dt][ks] = load_x8(sx_, t0 + dt, ks, sx_ < bend && t0 + dt < T);
+          };
+          auto p_step = [&](int t0, int dt, char* buf, float (&inv)[CS]) __attribute__((always_inline)) {
+            const int t = t0 + dt;
+            inv[dt] = 1.f;
+            if (t < T) {
+              float ax = 0.f;                                   // max|x[t]| over the tile: every wave holds the whole step
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(xr[dt][ks][j]));
+              ax = __uint_as_float(unsigned(__builtin_amdgcn_readlane(int(wave_umax63(__float_as_uint(ax))), 63)));
+              float cx, inv_s0;
+              const float sx = pow2_scale(ax, &cx);
+              const float s0 = pow2_scale(fmaf(Q.pre_alpha, ax, Q.pre_beta), &inv_s0);
+              cx *= Q.pre_inv_s;
+              inv[dt] = inv_s0;
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < NKP; ++ks) {
+                const gru_f32x8 xs = xr[dt][ks] * sx;
+                const f16x8 bh = __builtin_convertvector(xs, f16x8);
+                const f16x8 bl = __builtin_convertvector(xs - __builtin_convertvector(bh, gru_f32x8), f16x8);
+                gru_mfma1(acc, a[ks], bh, bl);
+              }
+              f32x4 v = acc * cx + bpre;
+              if (P.pre_relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+              f16x4 vh, vl;
+              gru_split4(v * s0, vh, vl);
+              char* dst = buf + dt * SEQ + wr_off;
+              *reinterpret_cast<f16x4*>(dst) = vh;
+              *reinterpret_cast<f16x4*>(dst + PH) = vl;
+            }
+          };
+          x_chunk(0);
+#pragma unroll
+          for (int dt = 0; dt < CS; ++dt) p_step(0, dt, gp_lds, inv_c);
           gp_barrier();
           for (int t0 = 0, c = 0; t0 < T; t0 += CS, ++c) {
             const char* const buf = gp_lds + (c & 1) * CHUNK;
@@ -733,7 +786,10 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
 #pragma unroll
             for (int dt = 0; dt < CS; ++dt) i_step(t0, dt, buf);
             GP_STAMP(2, t0);
-            if (t0 + CS < T) p_chunk(t0 + CS, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+            if (t0 + CS < T) {
+#pragma unroll
+              for (int dt = 0; dt < CS; ++dt) p_step(t0 + CS, dt, gp_lds + ((c + 1) & 1) * CHUNK, inv_n);
+            }
 #pragma unroll
             for (int dt = 0; dt < CS; ++dt) inv_c[dt] = inv_n[dt];
             gp_barrier();

@@ -373,8 +373,36 @@ SHAPE_CASES = [
 ]
 
 
+# Shapes the reference's init_model accepts (kws_model.py:114-170 takes any size) and NO specialised kernel is built for: wider,
+# longer-kernelled, deeper than every shipped recipe, pooled heads on a GRU.  The library serves them through its any-shape
+# exact-f32 path (csrc/generic.hip.h); goldens: make_generic_golden.py from the live reference.
+GENERIC_CASES = [
+    dict(name="ds_tcn_h320", model="ds_tcn_h256", hidden=320, B=2, T=60, split=23, wseed=401, xseed=51),
+    dict(name="ds_tcn_h256_k9", model="ds_tcn_h256", ksize=9, B=2, T=50, split=20, wseed=402, xseed=52),
+    dict(name="tcn_h288", model="tcn_h64", hidden=288, B=2, T=40, split=15, wseed=403, xseed=53),
+    dict(name="tcn_h64_k10", model="tcn_h64", ksize=10, B=3, T=45, split=16, wseed=404, xseed=54),
+    dict(name="mdtc_h160", model="mdtc_h64", hidden=160, B=2, T=98, split=40, wseed=405, xseed=55),
+    dict(name="mdtc_h64_k7", model="mdtc_h64", ksize=7, B=3, T=70, split=30, wseed=406, xseed=56),
+    dict(name="mdtc_h256_global12", model="mdtc_h64_global12", hidden=256, B=2, T=70, wseed=407, xseed=57),
+    dict(name="mdtc_h160_last12", model="mdtc_small_last12", hidden=160, B=3, T=33, wseed=408, xseed=58),
+    dict(name="mdtc_h64_8stacks", model="mdtc_h64", stacks=8, B=2, T=98, split=33, wseed=409, xseed=59),   # 33 blocks > 24
+    dict(name="gru_2x192", model="gru_2x128", hidden=192, B=3, T=30, split=10, wseed=410, xseed=60),
+    dict(name="gru_5x128", model="gru_2x128", layers=5, B=2, T=25, split=9, wseed=411, xseed=61),
+    dict(name="gru_2x128_global12", model="gru_2x128", head="global", odim=12, B=3, T=40, wseed=412, xseed=62),
+    dict(name="gru_1x64_last5", model="gru_2x128", hidden=64, layers=1, head="last", odim=5, B=2, T=17, wseed=413, xseed=63),
+]
+
+
 def shape_case_config(case):
     cfg = copy.deepcopy(synth.MODEL_CONFIGS[case["model"]])
+    if case.get("layers"):
+        cfg["backbone"]["num_layers"] = case["layers"]
+    if case.get("stacks"):
+        cfg["backbone"]["num_stack"] = case["stacks"]
+    if case.get("head"):
+        cfg["classifier"] = {"type": case["head"], "dropout": 0.5}
+    if case.get("odim"):
+        cfg["output_dim"] = case["odim"]
     if case.get("hidden"):
         cfg["hidden_dim"] = case["hidden"]
         if "hidden_dim" in cfg["backbone"]:

@@ -155,3 +155,31 @@ def test_oracle_matches_odd_width_golden(case):
         ys, cs = kws_oracle.forward_streaming(cfg, sd, x, [t1, case["T"] - t1], None)
         assert max_abs(ys, g[name + "/y_stream"]) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
         assert max_abs(cs, g[name + "/cache_stream"]) <= Y_TOL * max(1.0, float(np.abs(gc).max()))
+
+
+from tests.golden.cases import GENERIC_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES, ids=[c["name"] for c in GENERIC_CASES])
+def test_oracle_matches_any_shape_golden(case):
+    """Shapes beyond every shipped recipe (wider than 256 channels, kernel sizes above 8 / 5, 33 residual blocks, GRU hidden 192,
+    five GRU layers, pooled heads on a GRU; goldens from the live reference, tests/golden/make_generic_golden.py): the oracle
+    follows the reference there too -- it is what tests/test_hip_generic.py compares the any-shape HIP path with at other sizes."""
+    import os
+    from wekws_amd import pack
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generic_golden.npz"))
+    cfg = shape_case_config(case)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), case["wseed"])
+    name = case["name"]
+    assert abs(synth.checksum(sd) - float(g[name + "/wsum"])) <= 1e-6 * abs(float(g[name + "/wsum"]))
+    x = synth.synth_feats(case["B"], case["T"], cfg["input_dim"], seed=case["xseed"])
+    y, c = kws_oracle.forward(cfg, sd, x, None)
+    gy, gc = g[name + "/y"], g[name + "/cache"]
+    assert y.shape == gy.shape and c.shape == gc.shape
+    assert max_abs(y, gy) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+    assert max_abs(c, gc) <= Y_TOL * max(1.0, float(np.abs(gc).max()))
+    if case.get("split"):
+        t1 = case["split"]
+        ys, cs = kws_oracle.forward_streaming(cfg, sd, x, [t1, case["T"] - t1], None)
+        assert max_abs(ys, g[name + "/y_stream"]) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
+        assert max_abs(cs, g[name + "/cache_stream"]) <= Y_TOL * max(1.0, float(np.abs(gc).max()))

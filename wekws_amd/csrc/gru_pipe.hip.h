@@ -81,6 +81,10 @@
 #define GP_LDINV ""
 #endif
 #define GP_RETRY_POL "sc1"
+// pause in front of a re-request of granules that were not there yet (units of 64 clocks)
+#ifndef GP_DATA_SLEEP
+#define GP_DATA_SLEEP 2
+#endif
 namespace wekws {
 
 constexpr int kGruPipeStages = 2 * kGruMaxLayers;
@@ -945,7 +949,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           publish(gb0 + t, near_up);
           spins = 0;
           do {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(GP_DATA_SLEEP);
             reload_g(g0, t);
             gp_wait4<0>(g0);
             if (give_up(spins, 0x100u)) break;
@@ -1137,7 +1141,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           publish(gb0 + t, near_up);                            // (as in the recurrence: never wait without having said so)
           spins = 0;
           do {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(GP_DATA_SLEEP);
             reload_h(t);
             gp_wait2<0>(raw);
             if (give_up(spins, 0x100u)) break;

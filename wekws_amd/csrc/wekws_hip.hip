@@ -32,6 +32,7 @@
 #include "gru.hip.h"
 #include "gru_f16.hip.h"
 #include "gru_pipe.hip.h"
+#include "generic.hip.h"
 #include "mfcc.hip.h"
 #include "splice.hip.h"
 #include "topk.hip.h"
@@ -340,6 +341,11 @@ struct wekws_hip_model {
   int user_cache_len = 0;
   CacheMap widen{}, narrow{};
   int cache_len = 0;
+  // A shape no specialised kernel is built for (wider / deeper / longer kernels than the reference's recipes use), or an FSMN
+  // that must run exact f32: the any-shape path of generic.hip.h on the packer's blob as it is (d_w); nothing else of this
+  // struct is used then.
+  bool generic = false;
+  wekws::GenericModel gm{};
   std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
 };
@@ -567,17 +573,49 @@ static void balance_operand_channels(const wekws_hip_desc& d, float* w) {
   }
 }
 
+// A valid reference configuration without a specialised kernel (`why` names the limit it exceeds): the any-shape exact-f32
+// path (generic.hip.h).  The reference's init_model takes any size (kws_model.py:114-170); before round 5 these were
+// WEKWS_HIP_EUNSUPPORTED.
+static int create_generic(const wekws_hip_desc& d, const float* blob, size_t n_elems, int device, wekws_hip_model** out) {
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(WEKWS_HIP_EDEVICE, "hipSetDevice(%d)", device);
+  wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
+  if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
+  m->desc = d;
+  m->device = device;
+  m->generic = true;
+  m->gru_pipe = 0;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_w), n_elems * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(m->d_w, blob, n_elems * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->d_w) (void)hipFree(m->d_w);
+    delete m;
+    return fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "weight upload: %s", hipGetErrorString(e));
+  }
+  m->gm.d = d;
+  m->gm.w = m->d_w;
+  m->gm.cache_len = m->cache_len = wekws::gen_cache_len(d);
+  *out = m;
+  return WEKWS_HIP_OK;
+}
+
 static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_elems, int device, wekws_hip_model** out) {
+  // precision F32 is served with the reference's own arithmetic (exact f32 products): the any-shape path -- the block-floating
+  // kernel below is the default / F16X3 / F16 one
+  if (d.precision == WEKWS_HIP_PRECISION_F32) return create_generic(d, blob_in, n_elems, device, out);
   std::vector<float> balanced(blob_in, blob_in + n_elems);
   balance_operand_channels(d, balanced.data());
   const float* blob = balanced.data();
   // every precision request is served by the block-floating split-fp16 kernel (22-bit products, fp32 accumulate: the
   // accuracy of fp32 arithmetic at any operand scale, tests/test_hip_parity.py::test_scale_sweep); an exact-f32 FSMN
   // kernel is not built
-  if (d.num_layers > wekws::kFsmnMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn num_layers %d > %d", d.num_layers, wekws::kFsmnMaxLayers);
+  if (d.num_layers > wekws::kFsmnMaxLayers) return create_generic(d, blob_in, n_elems, device, out);   // (deeper than the kernel's table)
   const int I = d.idim, A1 = d.aux[0], A2 = d.aux[1], C = d.hdim, D = d.num_stack, K = d.odim;
   const int ntaps = d.kernel_size + d.stack_size;
-  if (ntaps > wekws::kFsmnMaxTaps) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn left_order + right_order %d > %d", ntaps, wekws::kFsmnMaxTaps);
+  if (ntaps > wekws::kFsmnMaxTaps) return create_generic(d, blob_in, n_elems, device, out);            // (longer memory than the kernel's taps)
   wekws::FsmnParams q{};
   q.idim = I; q.odim = K; q.proj = D;
   q.kin = round_up(I, 32); q.a1p = round_up(A1, 32); q.linp = round_up(C, 32); q.dp = round_up(D, 32);
@@ -586,7 +624,7 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_e
   int max_nt = 0;
   for (int nt = 1; nt <= wekws::kFsmnTileFrames / 16; ++nt)
     if (wekws::FsmnLds::make(q, 16 * nt, 1).bytes() <= wekws::kFsmnLdsLimit) max_nt = nt;
-  if (!max_nt) return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: layer widths do not fit the 160 KiB LDS tile");
+  if (!max_nt) return create_generic(d, blob_in, n_elems, device, out);                                 // (layer widths beyond the 160 KiB LDS tile)
 
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -644,10 +682,14 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_e
   dense(K, A2, q.op, true, &q.out2_a, &q.out2_b, &q.out2);
   if (size_t(p - blob) != n_elems)
     return fail(WEKWS_HIP_EINVAL, "internal: blob walk consumed %zu of %zu floats", size_t(p - blob), n_elems);
-  if (img.spread_log2 > WEKWS_HIP_F16X3_ENVELOPE_LOG2)
-    return fail(WEKWS_HIP_EUNSUPPORTED, "fsmn: a weight matrix spreads its row / column magnitudes over 2^%.1f (> 2^%d): outside the "
-                "envelope in which the split-fp16 kernel keeps fp32-level accuracy, and FSMN has no exact-f32 kernel",
-                double(img.spread_log2), WEKWS_HIP_F16X3_ENVELOPE_LOG2);
+  if (img.spread_log2 > WEKWS_HIP_F16X3_ENVELOPE_LOG2) {
+    // a weight matrix spreads its row / column magnitudes beyond the envelope in which the split-fp16 kernel keeps fp32-level
+    // accuracy: exact f32 instead (wekws_hip_effective_precision reports F32, wekws_hip_weight_spread_log2 the spread)
+    const float spread = img.spread_log2;
+    const int rc = create_generic(d, blob_in, n_elems, device, out);
+    if (rc == WEKWS_HIP_OK) { (*out)->spread_log2 = spread; (*out)->out_of_envelope = true; }
+    return rc;
+  }
 
   wekws_hip_model* m = new (std::nothrow) wekws_hip_model();
   if (!m) return fail(WEKWS_HIP_ENOMEM, "host allocation");
@@ -699,6 +741,7 @@ static size_t granule_need(const wekws_hip_model* m, int B, int T) {
 static size_t workspace_need(const wekws_hip_model* m, int B, int T) {
   const wekws_hip_desc& d = m->desc;
   if (B <= 0 || T <= 0) return 0;
+  if (m->generic) return wekws::gen_workspace_bytes(m->gm, B, T);     // (monotonic in B and T)
   if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
     const int TILE = 16 * m->fsmn_max_nt;
     if (T <= TILE) return 0;
@@ -878,6 +921,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   if (need != n_elems) return fail(WEKWS_HIP_EINVAL, "weight blob has %zu floats, descriptor needs %zu", n_elems, need);
   const int C = d.hdim, ks = d.kernel_size, K = d.odim;
   if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return create_fsmn(d, blob, n_elems, device, out);
+  const float* const orig = blob;                           // (the any-shape path takes the packer's blob as it is)
   std::vector<float> balanced(blob, blob + n_elems);        // (exact power-of-two rescaling: see balance_operand_channels)
   balance_operand_channels(d, balanced.data());
   blob = balanced.data();
@@ -888,17 +932,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       // any width up to 256 and any kernel size up to the built one (kws_model.py:114,142-157 take any): run as the next
       // built shape, zero-padded -- exact, see pad_conv_shape
       const int Cp = !odd_c ? C : C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
-      if (C > 256) return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d: kernels are built for up to 256 channels", C);
+      if (C > 256) return create_generic(d, orig, n_elems, device, out);                    // wider than any built kernel
       // padding only ever ADDS zero taps: a kernel size above the built one cannot be served (pad_conv_shape would write
       // ks floats into a ks_built-wide slot)
-      if (ks > ks_built)
-        return fail(WEKWS_HIP_EUNSUPPORTED, "kernel_size %d: this backbone's kernel is built for up to %d", ks, ks_built);
-      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && Cp > 128)
-        return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim %d: the LDS tile holds up to 128 channels", C);
-      if (n_blocks(d) > wekws::kAmaxMaxBlocks)
-        return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks with a padded shape: the cache maps hold %d", n_blocks(d), wekws::kAmaxMaxBlocks);
-      if (odd_c && d.head == WEKWS_HIP_HEAD_IDENTITY)
-        return fail(WEKWS_HIP_EUNSUPPORTED, "hidden_dim %d with the identity head: kernels are built for 32/64/128/256", C);
+      if (ks > ks_built) return create_generic(d, orig, n_elems, device, out);
+      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && Cp > 128) return create_generic(d, orig, n_elems, device, out);   // (the LDS tile holds 128)
+      if (n_blocks(d) > wekws::kAmaxMaxBlocks) return create_generic(d, orig, n_elems, device, out);   // (more blocks than the cache maps hold)
+      if (odd_c && d.head == WEKWS_HIP_HEAD_IDENTITY) return create_generic(d, orig, n_elems, device, out);   // (y is the C-wide tile itself)
       wekws_hip_desc dd = d;
       dd.hdim = Cp;
       dd.kernel_size = ks_built;
@@ -923,16 +963,13 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     }
   }
   if (desc_conv(d)) {
-    if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "mdtc with hidden_dim 256 does not fit the LDS tile");
+    if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256) return create_generic(d, orig, n_elems, device, out);   // (does not fit the LDS tile)
     // the conv kernels are specialised for the kernel sizes of the reference recipes
     // (examples/*/s0/conf/{ds_tcn,tcn}.yaml: 8; mdtc*.yaml: 5)
     const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
-    if (ks != ks_built)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "kernel_size %d: this backbone's kernel is built for %d", ks, ks_built);
+    if (ks != ks_built) return create_generic(d, orig, n_elems, device, out);
     if (d.precision != WEKWS_HIP_PRECISION_F32 && n_blocks(d) > wekws::kAmaxMaxBlocks)
-      return fail(WEKWS_HIP_EUNSUPPORTED, "%d residual blocks: the split-fp16 kernels track %d (precision F32 has no limit)",
-                  n_blocks(d), wekws::kAmaxMaxBlocks);
+      return create_generic(d, orig, n_elems, device, out);   // (the split-fp16 kernels track kAmaxMaxBlocks tile maxima)
   } else {
     if (C < 128 && d.head == WEKWS_HIP_HEAD_LINEAR && d.num_layers <= wekws::kGruMaxLayers) {
       wekws_hip_desc dd = d;
@@ -948,9 +985,9 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       m->widen.len[0] = m->narrow.len[0] = C;
       return WEKWS_HIP_OK;
     }
-    if (C != 128) return fail(WEKWS_HIP_EUNSUPPORTED, "gru hidden_dim %d: kernel is built for 128 (smaller sizes run zero-padded)", C);
-    if (d.num_layers > wekws::kGruMaxLayers) return fail(WEKWS_HIP_EUNSUPPORTED, "gru num_layers %d > %d", d.num_layers, wekws::kGruMaxLayers);
-    if (d.head != WEKWS_HIP_HEAD_LINEAR) return fail(WEKWS_HIP_EUNSUPPORTED, "gru: only the per-frame linear head is built");
+    // hidden sizes above the built 128, more layers than the kernels' tables, pooled / identity heads on a GRU
+    if (C != 128 || d.num_layers > wekws::kGruMaxLayers || d.head != WEKWS_HIP_HEAD_LINEAR)
+      return create_generic(d, orig, n_elems, device, out);
   }
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1245,7 +1282,8 @@ int wekws_hip_cache_len(const wekws_hip_model* m) { return !m ? 0 : m->user_hdim
 int wekws_hip_effective_precision(const wekws_hip_model* m) {
   if (!m) return fail(WEKWS_HIP_EINVAL, "NULL model");
   const wekws_hip_desc& d = m->desc;
-  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return WEKWS_HIP_PRECISION_F16X3;        // one kernel (fsmn_f16.hip.h)
+  if (m->generic) return WEKWS_HIP_PRECISION_F32;                                     // the any-shape path: exact f32 products
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) return WEKWS_HIP_PRECISION_F16X3;        // the block-floating kernel (fsmn_f16.hip.h)
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU)
     return (d.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32 || !wekws::gru_f16_supported(m->gq))
                ? WEKWS_HIP_PRECISION_F32 : WEKWS_HIP_PRECISION_F16X3;
@@ -1421,7 +1459,12 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   const wekws_hip_desc& d = m->desc;
   const bool per_frame = d.head == WEKWS_HIP_HEAD_LINEAR || d.head == WEKWS_HIP_HEAD_IDENTITY;
 
-  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+  if (m->generic) {
+    char* base = stream_workspace(m, stream, workspace_need(m, B, T));
+    if (!base) return WEKWS_HIP_ENOMEM;
+    const int rc = wekws::generic_forward(m->gm, x, B, T, in_cache, y, out_cache, base, stream);
+    if (rc) return fail(rc, "any-shape path: launch failed: %s", hipGetErrorString(hipGetLastError()));
+  } else if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
     const int rc = forward_fsmn(m, x, B, T, in_cache, y, out_cache, stream);
     if (rc) return rc;
   } else if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {

@@ -47,7 +47,11 @@ enum wekws_hip_error {
   WEKWS_HIP_EINVAL = -1,      /* bad argument / unsupported configuration */
   WEKWS_HIP_ENOMEM = -2,      /* device allocation failed */
   WEKWS_HIP_EDEVICE = -3,     /* HIP runtime error (no device, launch failure ...) */
-  WEKWS_HIP_EUNSUPPORTED = -4 /* valid reference config that this build has no kernel for */
+  WEKWS_HIP_EUNSUPPORTED = -4 /* valid reference config that this build has no kernel for.  Since ABI 2 no MODEL
+                                 configuration returns it: shapes beyond the specialised kernels (more than 256 channels, kernel
+                                 sizes above 8 / 5, GRU hidden sizes above 128 or pooled heads on a GRU, ...) run on the
+                                 any-shape exact-f32 path (csrc/generic.hip.h; wekws_hip_effective_precision reports F32).
+                                 Left: fbank frame lengths outside 65 .. 512 samples. */
 };
 
 /* backbone.type of the reference model config (wekws/model/kws_model.py:126-170) */
@@ -82,8 +86,8 @@ enum wekws_hip_activation {
 enum wekws_hip_precision {
   WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 */
   WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32
-                                      math (conv backbones, GRU; FSMN has the F16X3 kernel only and serves this request
-                                      with it) */
+                                      math (conv backbones and GRU: MFMA kernels; FSMN, and every shape without a specialised
+                                      kernel: the any-shape path of csrc/generic.hip.h, v_fma_f32) */
   WEKWS_HIP_PRECISION_F16X3 = 2,   /* operands split into fp16 hi + lo, three fp16 matrix products per term, with BLOCK
                                       FLOATING POINT: every weight matrix and every operand tile carries an exact
                                       power-of-two scale chosen from its magnitude, so the accuracy is fp32-level (~2^-22
@@ -196,9 +200,10 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value);
 
 /*
  * The arithmetic a model's calls REALLY run in (an enum wekws_hip_precision, never DEFAULT; negative error code for a NULL
- * model): desc.precision is a request, and not every backbone has a kernel for every mode -- FSMN and matrix-core
- * classifiers have the F16X3 kernel only (a precision-F32 request is served by it: same 1e-4 bar, different rounding),
- * F16 is honoured by the 16-wave DS-TCN / MDTC kernels only, a GRU without an fp16 kernel for its shape runs F32.  A caller
+ * model): desc.precision is a request, and not every backbone has a kernel for every mode -- F16 is honoured by the
+ * 16-wave DS-TCN / MDTC kernels only (FSMN and every other shape run F16X3: more accurate than asked), a GRU without an fp16
+ * kernel for its shape runs F32, every model on the any-shape path (csrc/generic.hip.h: shapes beyond the specialised
+ * kernels; FSMN with precision F32 or with weights outside the split-fp16 envelope) runs F32 whatever was asked.  A caller
  * that needs exact-f32 reference rounding (a parity baseline) checks this instead of trusting the request.  Reflects the
  * kernel-selection options as they are set now.
  */
@@ -209,7 +214,7 @@ int wekws_hip_effective_precision(const wekws_hip_model* m);
  * magnitudes of their rows (or of their K columns) over more than 2^WEKWS_HIP_F16X3_ENVELOPE_LOG2 would lose fp32-level
  * accuracy in the small rows (measured against the live reference: tests/golden/make_hetero_golden.py).  wekws_hip_create
  * measures the spread; a DEFAULT / F16X3 model beyond the envelope runs the exact-f32 kernels instead
- * (wekws_hip_effective_precision reports F32), an FSMN beyond it is refused with WEKWS_HIP_EUNSUPPORTED (no f32 kernel).
+ * (wekws_hip_effective_precision reports F32); an FSMN beyond it runs the any-shape exact-f32 path (csrc/generic.hip.h).
  *   wekws_hip_weight_spread_log2   the largest such spread of the model, in binades (-1 for a NULL model)
  */
 #define WEKWS_HIP_F16X3_ENVELOPE_LOG2 20

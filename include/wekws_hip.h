@@ -328,8 +328,9 @@ int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int righ
  * wekws/dataset/processor.py:160-169: num_ceps 80 of num_mel_bins 80):
  *   out = (logmel @ DCT) * lifter,  DCT = DCT-II 'ortho' (N x N) with column 0 := sqrt(1/N), first num_ceps columns;
  *   lifter_i = 1 + 0.5 Q sin(pi i / Q), Q = cepstral_lifter (22 in the reference's call; 0 disables it).
- * The log-mel rows come from wekws_hip_fbank_compute with WEKWS_HIP_WINDOW_POVEY.  Parity with torchaudio itself is
- * UNPINNED (not installable here); checked against a restatement of its published algorithm (oracle/).
+ * The log-mel rows come from wekws_hip_fbank_compute with WEKWS_HIP_WINDOW_POVEY.  torchaudio itself is not installable
+ * here; parity is pinned against independent third-party implementations of the same algorithm (Hugging Face transformers'
+ * numpy port of kaldi.fbank, scipy's DCT: tests/golden/kaldi_golden.npz) and a restatement of torchaudio's published code.
  *   logmel (rows, num_bins) device float32;  out (rows, num_ceps) device float32;  num_ceps <= num_bins <= 128
  * ------------------------------------------------------------------------------------------*/
 int wekws_hip_dct_lifter(const float* logmel, int64_t rows, int num_bins, int num_ceps, float cepstral_lifter, float* out,

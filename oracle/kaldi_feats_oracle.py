@@ -1,11 +1,15 @@
 """TEST INFRASTRUCTURE ONLY -- numpy restatement of the training-side features: torchaudio.compliance.kaldi.fbank / .mfcc.
 
-PARITY UNPINNED.  The reference computes its training / scoring features with torchaudio
+PARITY PINNED TO A THIRD-PARTY PORT (not to torchaudio itself).  The reference computes its training / scoring features with torchaudio
 (wekws/dataset/processor.py:134-203: `kaldi.fbank(waveform * (1 << 15), num_mel_bins, frame_length, frame_shift, dither,
 energy_floor=0.0, sample_frequency)` and `kaldi.mfcc(..., num_ceps, num_mel_bins, ...)`; streaming twin
 wekws/bin/stream_kws_ctc.py:354-360).  torchaudio is a requirements.txt dependency without a pinned version and is not
-installed in this environment (no network), and the reference ships no golden features, so nothing here could be
-checked against the real thing: this file restates the published algorithm of torchaudio/compliance/kaldi.py
+installed in this environment (no network), and the reference ships no golden features.  PINNED, since round 5, against an
+INDEPENDENT implementation of the same algorithm that IS present here: Hugging Face transformers' numpy port of kaldi.fbank
+(transformers.audio_utils, what SeamlessM4TFeatureExtractor uses when torchaudio is missing; validated by its authors against
+torchaudio) plus scipy's DCT -- tests/golden/kaldi_golden.npz, tests/golden/make_kaldi_golden.py; this file agrees with it to
+float32 rounding (<= 2e-6 on the log-mel).  Not checked against torchaudio ITSELF: "HF's port == torchaudio" is its authors'
+claim.  This file restates the published algorithm of torchaudio/compliance/kaldi.py
 (torchaudio 2.x, BSD-2; itself a port of Kaldi's feature-window.cc / mel-computations.cc / feature-mfcc.cc) with the
 defaults those two calls leave in place:
     window_type 'povey' (hann(periodic=False) ** 0.85), remove_dc_offset, preemphasis 0.97 with a replicated first

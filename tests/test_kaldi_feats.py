@@ -136,3 +136,45 @@ def test_hip_training_features_vs_third_party(case, kaldi_golden, error_report):
     error_report[f"kaldi/{case['name']}/mfcc80"] = err
     if case["kind"] != "ramp":      # (the ramp's empty bins are float32 round-off: its cepstra inherit that, bounded above only)
         assert got.shape == gm.shape and err <= 3e-3, err
+
+
+@pytest.mark.gpu
+def test_training_recipes_audio_to_posteriors(error_report):
+    """The two recipes whose features come from the TRAINING pipeline, end to end on the device, against the third-party feature
+    chain + the numpy model oracle (missing 2: "no end-to-end audio -> posterior parity"):
+      * MDTC on 80 MFCCs (examples/hi_xiaowen/s0/conf/mdtc.yaml; processor.py:160-169): pcm -> fbank_kernel(Povey, 80) ->
+        dct_lifter -> MDTC 80-d (per-frame sigmoid posteriors);
+      * FSMN-CTC on spliced 80-bin fbank (fsmn_ctc.yaml:21-25: context 2 + 2, skip 3 -> 400-d at a third of the frame rate):
+        pcm -> fbank_kernel(Povey, 80) -> splice_kernel -> FSMN -> softmax posteriors over the tokens.
+    Reference side: HF transformers' kaldi.fbank port (+ scipy DCT), the splice oracle, kws_oracle.  Bar: 1e-4 on posteriors."""
+    import torch
+    from oracle import kws_oracle, splice_oracle
+    from tests.golden.make_kaldi_golden import hf_kaldi_fbank, scipy_mfcc
+    from wekws_amd import pack
+    from wekws_amd.frontend import Fbank, Mfcc, splice_skip
+    from wekws_amd.model.kws_model import init_model
+
+    def build(name):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+        m = init_model(cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return cfg, sd, m.cuda().eval()
+
+    pcm = np.concatenate([synth.synth_pcm(3, 16000, seed=11, kind="noise"), synth.synth_pcm(1, 16000, kind="sine")])
+    x = torch.from_numpy(pcm).cuda()
+    ref80 = np.stack([hf_kaldi_fbank(p, 80) for p in pcm])
+    # MDTC on MFCC
+    cfg, sd, m = build("mdtc_h64_80d")
+    y = m(Mfcc(80, 80)(x))[0].cpu().numpy()
+    ry = kws_oracle.forward(cfg, sd, np.stack([scipy_mfcc(f, 80) for f in ref80]), None)[0]
+    e1 = float(np.abs(y - ry).max())
+    # FSMN-CTC on spliced fbank
+    cfg, sd, m = build("fsmn_ctc300") if "fsmn_ctc300" in synth.MODEL_CONFIGS else build("fsmn_ctc")
+    feats = splice_skip(Fbank(80, window="povey")(x), 2, 2, 3)
+    y2 = m.forward_softmax(feats)[0].cpu().numpy()
+    ry2 = kws_oracle.forward(cfg, sd, splice_oracle.splice_skip(ref80, 2, 2, 3), None, softmax=True)[0]
+    e2 = float(np.abs(y2 - ry2).max())
+    error_report["kaldi/end_to_end/mdtc80_mfcc_posteriors"] = e1
+    error_report["kaldi/end_to_end/fsmn_spliced_posteriors"] = e2
+    assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)

@@ -175,6 +175,11 @@ def test_training_recipes_audio_to_posteriors(error_report):
     y2 = m.forward_softmax(feats)[0].cpu().numpy()
     ry2 = kws_oracle.forward(cfg, sd, splice_oracle.splice_skip(ref80, 2, 2, 3), None, softmax=True)[0]
     e2 = float(np.abs(y2 - ry2).max())
+    # (softmax posteriors over 300 tokens are all small: the logits, relative to their range, are the sharper comparison)
+    lg, rlg = m(feats)[0].cpu().numpy(), kws_oracle.forward(cfg, sd, splice_oracle.splice_skip(ref80, 2, 2, 3), None)[0]
+    e3 = float(np.abs(lg - rlg).max()) / max(1.0, float(np.abs(rlg).max()))
+    error_report["kaldi/end_to_end/fsmn_spliced_logits_rel"] = e3
+    assert e3 <= 1e-4, e3
     error_report["kaldi/end_to_end/mdtc80_mfcc_posteriors"] = e1
     error_report["kaldi/end_to_end/fsmn_spliced_posteriors"] = e2
     assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)

@@ -674,10 +674,11 @@ def test_ds256_matrix_core_depthwise_variant(golden):
         assert max_abs(cache[:1], gc) <= tol_for(gc), case["name"]
 
 
-def test_fsmn_f32_request_is_served_by_the_block_floating_kernel():
-    """FSMN has one kernel: split-fp16 products with block floating point (fsmn_f16.hip.h), fp32-level accuracy at any
-    operand scale (test_scale_sweep runs FSMN in both precision settings).  A precision-F32 descriptor is accepted and
-    gives the same numbers as the default."""
+def test_fsmn_f32_request_runs_exact_f32():
+    """FSMN's specialised kernel multiplies split-fp16 products with block floating point (fsmn_f16.hip.h: fp32-level accuracy
+    at any operand scale, test_scale_sweep).  Until round 4 it also served a precision-F32 request (same numbers as the
+    default, effective precision 'f16x3'); since round 5 that request runs the reference's own arithmetic on the any-shape
+    path (csrc/generic.hip.h) and the library says so.  The two agree to fp32 rounding; both meet the oracle at 1e-4."""
     from wekws_amd import pack
     cfg = dict(synth.MODEL_CONFIGS["fsmn_small"])
     sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
@@ -685,9 +686,10 @@ def test_fsmn_f32_request_is_served_by_the_block_floating_kernel():
     y0, c0 = run(build(cfg, sd), x)
     m32 = build(cfg, sd).set_precision("f32")
     y1, c1 = run(m32, x)
-    assert np.array_equal(y0, y1) and np.array_equal(c0, c1)
-    # ... and the library says so: the request is 'f32', what runs is 'f16x3' (wekws_hip_effective_precision)
-    assert m32.effective_precision() == "f16x3" and build(cfg, sd).effective_precision() == "f16x3"
+    ry, rc = kws_oracle.forward(cfg, sd, x, None)
+    assert max_abs(y0, ry) <= tol_for(ry) and max_abs(y1, ry) <= tol_for(ry)
+    assert max_abs(y0, y1) <= 2e-5 * max(1.0, float(np.abs(ry).max())) and max_abs(c0, c1) <= 2e-5 * max(1.0, float(np.abs(rc).max()))
+    assert m32.effective_precision() == "f32" and build(cfg, sd).effective_precision() == "f16x3"
 
 
 def test_effective_precision_reports_what_runs():

@@ -1259,14 +1259,15 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
   bool gave_up = false;
   for (auto& e : m->ws) {
-    if (e.err_h) {                                            // (freeing synchronises: the word is final)
-      if (e.ctl) (void)hipStreamSynchronize(e.stream);
-      gave_up = gave_up || *static_cast<volatile unsigned*>(e.err_h) != 0u;
-      (void)hipHostFree(e.err_h);
-    }
+    // (the device memory first: hipFree waits for the work that may still use it -- the caller's stream handles are not
+    // touched, they may have been destroyed before the model -- so the health word is final when it is read)
     if (e.ptr) (void)hipFree(e.ptr);
     if (e.gran) (void)hipFree(e.gran);
     if (e.ctl) (void)hipFree(e.ctl);
+    if (e.err_h) {
+      gave_up = gave_up || *static_cast<volatile unsigned*>(e.err_h) != 0u;
+      (void)hipHostFree(e.err_h);
+    }
   }
   // (no return value to carry it: a failure nobody has asked about yet is at least left in wekws_hip_last_error())
   if (gave_up) (void)fail(WEKWS_HIP_EDEVICE, "model destroyed with an unreported failure: a bounded wait of the GRU wavefront gave up");
@@ -1429,18 +1430,39 @@ extern "C" int wekws_hip_debug_set_gru_epoch(wekws_hip_model* m, void* stream_, 
 // A tenant that keeps CUs busy: `blocks` workgroups of 128 KB of LDS each (one per CU, like the wavefront's own), every one
 // holding its CU for `ms` milliseconds of wall clock.  tests: a wavefront launch whose later workgroups find no CU for longer
 // than its bounded waits must END (not hang) and be reported by the next call; a shorter squeeze must change nothing.
-__global__ void debug_hog_kernel(unsigned long long ticks) {
+// ms < 0: the same occupancy with every SIMD BUSY (matrix + vector instructions, no memory traffic) for -ms milliseconds -- to
+// tell a neighbour's compute / power from a neighbour's memory traffic (tools/probe/gru_neighbours.py)
+__global__ void debug_hog_kernel(unsigned long long ticks, int busy) {
   extern __shared__ char hog_lds[];
   if (threadIdx.x == 0) hog_lds[0] = 1;
   const unsigned long long t0 = wall_clock64();              // 100 MHz
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+  if (!busy) {
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+    return;
+  }
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  h8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = a;
+  f4 c0 = {0, 0, 0, 0}, c1 = c0;
+  float v = float(threadIdx.x);
+  while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+      v = fmaf(v, 1.0001f, 0.5f);
+    }
+  }
+  if (c0[0] + c1[0] + v == 12345.f) hog_lds[1] = 1;
 }
 extern "C" int wekws_hip_debug_hog(int device, int blocks, int ms, void* stream_) {
   DeviceGuard guard(device);
-  if (!guard.ok || blocks <= 0 || ms < 0 || ms > 2000) return fail(WEKWS_HIP_EINVAL, "hog: device %d blocks %d ms %d", device, blocks, ms);
+  const int busy = ms < 0;
+  if (busy) ms = -ms;
+  if (!guard.ok || blocks <= 0 || ms > 2000) return fail(WEKWS_HIP_EINVAL, "hog: device %d blocks %d ms %d", device, blocks, ms);
   static wekws::DynLdsGrant grant;
   if (wekws::grant_dynamic_lds(debug_hog_kernel, 128 * 1024, grant)) return fail(WEKWS_HIP_EDEVICE, "hog: LDS grant");
-  hipLaunchKernelGGL(debug_hog_kernel, dim3(blocks), dim3(64), 128 * 1024, static_cast<hipStream_t>(stream_), 100000ull * ms);
+  hipLaunchKernelGGL(debug_hog_kernel, dim3(blocks), dim3(busy ? 512 : 64), 128 * 1024, static_cast<hipStream_t>(stream_), 100000ull * ms, busy);
   return hipGetLastError() == hipSuccess ? WEKWS_HIP_OK : fail(WEKWS_HIP_EDEVICE, "hog launch");
 }
 #endif

@@ -192,7 +192,7 @@ enum wekws_hip_option {
   WEKWS_HIP_OPT_STREAM = 2,     /* chunks of <= 16 frames: 1 (default) the kernels with the LDS-resident cache, 0 the batch kernels */
   WEKWS_HIP_OPT_MM = 3,         /* DS-TCN hidden 256: the all-matrix-core kernel -- -1 (default) for CTC-sized heads only, 0 never, 1 whenever eligible */
   WEKWS_HIP_OPT_HEAD_SLICES = 4,/* workgroups sharing a CTC-sized last layer on small calls: -1 (default) automatic, 0 / 1 none, n exactly n */
-  WEKWS_HIP_OPT_G16 = 5,        /* calls without an incoming cache: 1 (default) the register-resident kernels -- DS-TCN hidden 256: ds256_g16.hip.h (split fp16 / fp16) and ds256_g32.hip.h (precision F32), MDTC hidden 64: mdtc64_g4.hip.h --, 0 the LDS-tile kernels, 2 like 1 but one workgroup per utterance instead of persistent ones (a measurement aid) */
+  WEKWS_HIP_OPT_G16 = 5,        /* calls without an incoming cache: 1 (default) the register-resident kernels -- DS-TCN hidden 256: ds256_g16.hip.h (split fp16 / fp16) and ds256_g32.hip.h (precision F32), MDTC hidden 64: mdtc64_g4.hip.h --, 0 the LDS-tile kernels, 2 like 1 but one workgroup per utterance instead of persistent ones, 3 like 1 but calls WITH an incoming cache (later chunks of 17 .. 112 frames) keep the LDS-tile kernels instead of the register-resident kernels' context variants (measurement aids) */
   WEKWS_HIP_OPT_GRU_PIPE = 7,   /* GRU: 1 (default) the layer wavefront -- one launch, the stages of all layers running at the same time on different CUs (gru_pipe.hip.h) -- up to eight rounds of stream tiles per resident slot (B <= 128 x CUs / (2 x layers)), the layer-major kernels (gru_f16.hip.h) beyond; 2 the wavefront always; 0 never; bit-identical results */
   WEKWS_HIP_OPT_ENVELOPE = 6    /* weights outside the split-fp16 envelope (wekws_hip_weight_spread_log2): 1 (default) run the exact-f32 kernels, 0 keep the split-fp16 kernels (to MEASURE where the envelope ends; accuracy is then not promised) */
 };

@@ -590,6 +590,38 @@ def test_register_resident_kernel_equals_lds_tile_kernel():
                 assert max_abs(a.posteriors(xt).cpu().numpy(), b.posteriors(xt).cpu().numpy()) <= 5e-7, (prec, B, T)
 
 
+def test_register_resident_kernel_with_incoming_cache():
+    """Round 5: later chunks of a stream (an incoming cache, 17 .. 112 frames -- the Android caller sends 80,
+    runtime/android/app/src/main/cpp/wekws.cc:84-97) run the CONTEXT variant of ds256_g16 (the blocks' left context in a second
+    register tile, reached by a second DPP row shift) instead of ds256_w16; option g16 = 3 keeps them on ds256_w16.  Same
+    arithmetic in the same order: the returned cache must agree bit for bit, posteriors to the few ulp of the register head; and
+    both against the oracle's streaming forward.  Chunks below and above the paddings (7 / 14 / 28 / 56 frames: T < pad returns
+    [old tail | new frames]), ragged T (NT does not divide T), NT = 4 and 7 tiles, batches with a persistent tail, a chunk of
+    <= 16 frames in between (ds256_stream), both precisions that have the kernel, posteriors only."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 78)
+    for prec in ("default", "f16"):
+        a = build(cfg, sd).set_precision(prec)
+        b = build(cfg, sd).set_precision(prec).set_option("g16", 3)
+        for B, chunks in ((3, [40, 80, 17, 98]), (2, [20, 33, 10, 64, 49]), (1, [112, 112, 21]), (300, [80, 80]), (5, [7, 56, 55, 57, 28])):
+            T = sum(chunks)
+            x = synth.synth_feats(B, T, cfg["input_dim"], seed=T + B)
+            ya, ca = run(a, x, chunks=chunks)
+            yb, cb = run(b, x, chunks=chunks)
+            assert np.array_equal(ca, cb), (prec, B, chunks, max_abs(ca, cb))
+            assert max_abs(ya, yb) <= 5e-7, (prec, B, chunks, max_abs(ya, yb))
+            if prec == "default" and B <= 5:
+                ry, rc = kws_oracle.forward_streaming(cfg, sd, x, chunks, None)
+                assert max_abs(ya, ry) <= POSTERIOR_TOL and max_abs(ca, rc) <= tol_for(rc), (B, chunks, max_abs(ya, ry))
+        # posteriors only (out_cache = NULL) with an incoming cache
+        xt = torch.from_numpy(synth.synth_feats(4, 160, cfg["input_dim"], seed=9)).cuda()
+        y1, c1 = a(xt[:, :80].contiguous())
+        y2, _ = a(xt[:, 80:].contiguous(), c1)
+        y2p = a._run(xt[:, 80:].contiguous(), c1, False, want_cache=False)[0]
+        assert torch.equal(y2, y2p), prec
+
+
 def test_register_resident_f32_kernel_equals_generic_f32_kernel():
     """Precision F32, DS-TCN h256 keyword configuration without an incoming cache: ds256_g32 (tile in registers, exact-f32
     MFMA) against the generic conv_stack_kernel (option g16 = 0) -- the same products, each rounded once; the sums are

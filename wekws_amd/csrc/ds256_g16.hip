@@ -6,7 +6,7 @@ static int launch_nt(bool split, const StackParams& P, const CallArgs& A, hipStr
   return split ? launch_ds256_g16_nts<NT, true>(P, A, stream, cus) : launch_ds256_g16_nts<NT, false>(P, A, stream, cus);
 }
 int launch_ds256_g16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream, int cus) {
-  if (P.ksize != 8 || A.in_cache) return -4;
+  if (P.ksize != 8) return -4;
   switch (nt) {
     case 1: return launch_nt<1>(split, P, A, stream, cus);
     case 2: return launch_nt<2>(split, P, A, stream, cus);

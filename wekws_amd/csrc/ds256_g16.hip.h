@@ -83,6 +83,40 @@ __device__ __forceinline__ void g16_tap_tiles(float (&o)[NT], const f32x4 (&hv)[
   (g16_tap<S, TTs, NT, R_>(o[TTs], hv, w), ...);
 }
 
+// ---- calls WITH an incoming cache (round 5).  The left context of a block -- the last `pad` frames of its input in the call
+// before, its slice of the streaming cache (tcn.py:45-53) -- continues the lane-major tile to the left: frame g < 0 belongs to
+// "lane" floor(g / NT) < 0.  It is kept in a second register tile cx whose lane p holds lane p - 16 (only the last
+// ceil(pad / NT) lanes are non-zero), so the source of a tap that leaves the 16-lane row to the left is cx, SH lanes back =
+// 16 - SH lanes FORWARD in cx: one more v_fmac_f32_dpp, row_shl, for exactly the lanes the row_shr left untouched (bound_ctrl
+// off: a lane whose source is outside the row is disabled).  cx shares its registers with the accumulators (dead outside the
+// matrix phase and the epilogue).
+// o += w * x[lane + S] for the lanes whose source stays inside their 16-lane row (the others keep o)
+template <int S>
+__device__ __forceinline__ void g16_fmac_shl(float& o, float x, float w) {
+  static_assert(S >= 1 && S <= 15, "row shift");
+#define G16_SHL(n) if constexpr (S == n) asm("v_fmac_f32_dpp %0, %1, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf" : "+v"(o) : "v"(x), "v"(w));
+  G16_SHL(1) G16_SHL(2) G16_SHL(3) G16_SHL(4) G16_SHL(5) G16_SHL(6) G16_SHL(7) G16_SHL(8)
+  G16_SHL(9) G16_SHL(10) G16_SHL(11) G16_SHL(12) G16_SHL(13) G16_SHL(14) G16_SHL(15)
+#undef G16_SHL
+}
+template <int S, int TT_, int NT, int R_>
+__device__ __forceinline__ void g16_tapc(float& o, const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], float w) {
+  constexpr int Q = S / NT, M = S % NT;
+  constexpr int REG = TT_ >= M ? TT_ - M : TT_ - M + NT;
+  constexpr int SH = TT_ >= M ? Q : Q + 1;
+  static_assert(SH <= 15, "the context is one 16-lane row: NT >= 4 for paddings up to 56 frames");
+  if constexpr (SH == 0) o = fmaf(w, hv[REG][R_], o);
+  else {
+    g16_fmac_shr<SH>(o, hv[REG][R_], w);
+    g16_fmac_shl<16 - SH>(o, cx[REG][R_], w);
+  }
+}
+template <int S, int NT, int R_, int... TTs>
+__device__ __forceinline__ void g16_tapc_tiles(float (&o)[NT], const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], float w,
+                                               std::integer_sequence<int, TTs...>) {
+  (g16_tapc<S, TTs, NT, R_>(o[TTs], hv, cx, w), ...);
+}
+
 typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 g16_f16x2 __attribute__((ext_vector_type(2)));
 
@@ -106,8 +140,8 @@ __device__ __forceinline__ void g16_split_pair(float v0, float v1, float s, unsi
 // Depthwise conv + folded BN + ReLU + scale / split of the channel-row pair (2 P_, 2 P_ + 1) of the lane's four, all NT
 // frames of the lane at once: 2 NT independent accumulators per tap, so consecutive instructions never depend on one
 // another.  Tap j multiplies the frame (KS - 1 - j) dilations back; j ascending like the reference's (and ds256_w16's) sum.
-template <int D, int P_, int NT, bool SPLIT>
-__device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+template <int D, int P_, int NT, bool SPLIT, bool CTX = false>
+__device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
   // taps + bias of channels o0 + 2 P_, + 1 (padded 12-float records): six LDS broadcasts
   const float4* src = reinterpret_cast<const float4*>(taps_o0 + 2 * P_ * 12);
   const float4 a0 = src[0], a1 = src[1], a2 = src[2], b0 = src[3], b1 = src[4], b2 = src[5];
@@ -117,6 +151,16 @@ __device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const float* 
   __builtin_amdgcn_s_setprio(P_ == 0 ? 3 : 1);               // (a wave that is ahead steps back: see the matrix phase)
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) { oa[tt] = a2.x; ob[tt] = b2.x; }
+  if constexpr (CTX) {
+    g16_tapc_tiles<7 * D, NT, RA>(oa, hv, cx, a0.x, tiles); g16_tapc_tiles<7 * D, NT, RB>(ob, hv, cx, b0.x, tiles);
+    g16_tapc_tiles<6 * D, NT, RA>(oa, hv, cx, a0.y, tiles); g16_tapc_tiles<6 * D, NT, RB>(ob, hv, cx, b0.y, tiles);
+    g16_tapc_tiles<5 * D, NT, RA>(oa, hv, cx, a0.z, tiles); g16_tapc_tiles<5 * D, NT, RB>(ob, hv, cx, b0.z, tiles);
+    g16_tapc_tiles<4 * D, NT, RA>(oa, hv, cx, a0.w, tiles); g16_tapc_tiles<4 * D, NT, RB>(ob, hv, cx, b0.w, tiles);
+    g16_tapc_tiles<3 * D, NT, RA>(oa, hv, cx, a1.x, tiles); g16_tapc_tiles<3 * D, NT, RB>(ob, hv, cx, b1.x, tiles);
+    g16_tapc_tiles<2 * D, NT, RA>(oa, hv, cx, a1.y, tiles); g16_tapc_tiles<2 * D, NT, RB>(ob, hv, cx, b1.y, tiles);
+    g16_tapc_tiles<1 * D, NT, RA>(oa, hv, cx, a1.z, tiles); g16_tapc_tiles<1 * D, NT, RB>(ob, hv, cx, b1.z, tiles);
+    g16_tapc_tiles<0, NT, RA>(oa, hv, cx, a1.w, tiles);     g16_tapc_tiles<0, NT, RB>(ob, hv, cx, b1.w, tiles);
+  } else {
   g16_tap_tiles<7 * D, NT, RA>(oa, hv, a0.x, tiles); g16_tap_tiles<7 * D, NT, RB>(ob, hv, b0.x, tiles);
   g16_tap_tiles<6 * D, NT, RA>(oa, hv, a0.y, tiles); g16_tap_tiles<6 * D, NT, RB>(ob, hv, b0.y, tiles);
   g16_tap_tiles<5 * D, NT, RA>(oa, hv, a0.z, tiles); g16_tap_tiles<5 * D, NT, RB>(ob, hv, b0.z, tiles);
@@ -125,6 +169,7 @@ __device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const float* 
   g16_tap_tiles<2 * D, NT, RA>(oa, hv, a1.y, tiles); g16_tap_tiles<2 * D, NT, RB>(ob, hv, b1.y, tiles);
   g16_tap_tiles<1 * D, NT, RA>(oa, hv, a1.z, tiles); g16_tap_tiles<1 * D, NT, RB>(ob, hv, b1.z, tiles);
   g16_tap_tiles<0, NT, RA>(oa, hv, a1.w, tiles);     g16_tap_tiles<0, NT, RB>(ob, hv, b1.w, tiles);
+  }
   __builtin_amdgcn_s_setprio(P_ == 0 ? 2 : 0);
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
@@ -136,10 +181,33 @@ __device__ __forceinline__ void g16_dw_pair(const f32x4 (&hv)[NT], const float* 
     if constexpr (SPLIT) *reinterpret_cast<unsigned*>(pst + lo_off + tt * 256 + P_ * 4) = pl;
   }
 }
+template <int D, int NT, bool SPLIT, bool CTX = false>
+__device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+  g16_dw_pair<D, 0, NT, SPLIT, CTX>(hv, cx, taps_o0, sa, pst, lo_off);
+  g16_dw_pair<D, 1, NT, SPLIT, CTX>(hv, cx, taps_o0, sa, pst, lo_off);
+}
 template <int D, int NT, bool SPLIT>
 __device__ __forceinline__ void g16_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
-  g16_dw_pair<D, 0, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
-  g16_dw_pair<D, 1, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
+  g16_dw_rows<D, NT, SPLIT, false>(hv, hv, taps_o0, sa, pst, lo_off);
+}
+
+// NT consecutive floats from a dword-aligned address into row r of the lane's registers, as wide loads (g16_store_run's twin)
+template <int NT>
+__device__ __forceinline__ void g16_load_run(const float* src, f32x4 (&cv)[NT], int r) {
+  struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
+  struct __attribute__((packed, aligned(4))) V3 { float v[3]; };
+  if constexpr (NT == 7) {
+    const V4 a = *reinterpret_cast<const V4*>(src);
+    const V3 c = *reinterpret_cast<const V3*>(src + 4);
+    cv[0][r] = a.v[0]; cv[1][r] = a.v[1]; cv[2][r] = a.v[2]; cv[3][r] = a.v[3];
+    cv[4][r] = c.v[0]; cv[5][r] = c.v[1]; cv[6][r] = c.v[2];
+  } else if constexpr (NT == 4) {
+    const V4 a = *reinterpret_cast<const V4*>(src);
+    cv[0][r] = a.v[0]; cv[1][r] = a.v[1]; cv[2][r] = a.v[2]; cv[3][r] = a.v[3];
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) cv[tt][r] = src[tt];
+  }
 }
 
 // The same item from the utterance's features in LDS (FAST: copied there ahead of time, frame-major like in memory)
@@ -224,8 +292,12 @@ __device__ __forceinline__ void g16_mfma_step(f32x4 (&acc)[NT], const F16Frag& a
 // general paths (any feature layout, every head through conv_stack_head) stay in the one-utterance-per-workgroup
 // instantiation: inside the utterance loop their index arithmetic is loop-invariant, gets hoisted in front of the loop and
 // the kernel spills (168 bytes of scratch per lane with both in one kernel).
-template <int NT, bool SPLIT, bool FAST>
+// CTX (FAST only, NT >= 4): the call has an incoming cache -- a later chunk of a stream (17 .. 112 frames; shorter chunks run
+// ds256_stream).  Until round 5 those calls fell back to the LDS-tile kernel ds256_w16 (measured at 80-frame chunks, the
+// Android caller's size: 1.45 .. 1.5 x the time of the first, cache-less chunk).
+template <int NT, bool SPLIT, bool FAST, bool CTX = false>
 __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParams P, const CallArgs A) {
+  static_assert(!CTX || (FAST && NT >= 4), "the context tile is one 16-lane row");
   using G = W16Geom<NT>;
   constexpr int C = G::C, SS = G::SS, TT = G::TT, PB = G::PB;
   constexpr int NKS = C / 32;                                // K steps per layer
@@ -237,6 +309,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
 
   f32x4 acc[NT];
   f32x4 hv[NT];                                              // the residual tile: channels o0 .. o0 + 3, frames NT l15 + tt
+  f32x4 cx[CTX ? NT : 1];                                    // CTX: the current block's left context, lane p = lane p - 16 of the tile
   G16_PH_DECL;
 
   // ---- block floating point (conv_stack_f16.hip.h): maximum of the feature tile
@@ -307,6 +380,30 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + nb.dw_pk + tid * 4),
                                        (__attribute__((address_space(3))) void*)(taps + wave * 256), 16, 0, 0);
   };
+  // CTX: the left context of block `bi` into cx -- lane p holds the NT frames of lane p - 16, i.e. columns pad + NT (p - 16) ..
+  // of the block's cache slice; whole lanes when NT divides the padding (NT = 7: pad = 7 d), element-wise otherwise.  Requested
+  // behind the epilogue that ends the block before (the accumulators, whose registers cx shares, are dead from there to the
+  // next matrix phase), so the trip overlaps the barrier and the block top.
+  auto load_ctx = [&](int bi) __attribute__((always_inline)) {
+    if constexpr (CTX) {
+      const int padn = __builtin_amdgcn_readfirstlane(blk[bi].pad), offn = __builtin_amdgcn_readfirstlane(blk[bi].cache_off);
+      const float* const ic = A.in_cache + (int64_t(b) * C + o0) * Pc + offn;
+      const int c0 = padn + NT * (l15 - 16);                   // slice column of this lane's first context frame
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) cx[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c0 >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g16_load_run<NT>(ic + r * Pc + c0, cx, r);
+      } else if (c0 + NT > 0) {                                // (the slice begins inside this lane: NT does not divide pad)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if (c0 + tt >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cx[tt][r] = ic[r * Pc + c0 + tt];
+          }
+      }
+    }
+  };
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   // The features are requested before the barrier: the table's trip to L2 (first utterance), the barrier and the request
   // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM.
@@ -318,6 +415,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   }
   __syncthreads();                                           // table staged, cells zeroed; the utterance before is done with LDS
   stage_taps(blk[0]);
+  if constexpr (CTX)     // block floating point: the depthwise rows are bounded through max(tile, incoming cache), like ds256_w16
+    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
   if constexpr (FAST) xi = g16_take_x<NT, PB>(xbuf, T, P.idim, nk, tid);
   if (one_trip) {
     amax_publish(amax_cells, w16_x_amax(xi));
@@ -393,6 +492,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
     amax_publish(amax_cells + 2, hmax);
+    load_ctx(0);
     __syncthreads();                                         // (A) maximum published, planes free, taps staged
   }
   G16_PH(0);                                                 // [0] preprocessing
@@ -416,7 +516,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     // ---- operand scale of this block: the depthwise rows are bounded through the maximum of the input tile (published
     //      by the epilogue that produced it)
     float c1;
-    const float sa = pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1);
+    const float au = CTX ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + bi);
+    const float sa = pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &c1);
     c1 *= bd.inv_s1;
 
     // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h] (tcn.py:45-53), from
@@ -447,11 +548,12 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
             }
           }
         }
-        if (T < pad) {                                         // shorter than the slice: zero context in front
-          const int nz = pad - T;
+        if (T < pad) {                                         // shorter than the slice: in front of it zeros, or (CTX) what was the
+          const int nz = pad - T;                              // tail of the incoming slice: [cache | h][-pad:] (tcn.py:45-53)
           for (int e = lane; e < 16 * nz; e += 64) {
             const int cc = e / nz, p = e - cc * nz;
-            A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+            const int64_t at = (int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p;
+            A.out_cache[at] = CTX ? A.in_cache[at + T] : 0.f;
           }
         }
       }
@@ -463,10 +565,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
     {
       const float* taps_o0 = taps + o0 * 12;
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
-        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
-        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
-        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
-        case 8: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 1: if constexpr (CTX) g16_dw_rows<1, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, PB); else g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 2: if constexpr (CTX) g16_dw_rows<2, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, PB); else g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 4: if constexpr (CTX) g16_dw_rows<4, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, PB); else g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
+        case 8: if constexpr (CTX) g16_dw_rows<8, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, PB); else g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, PB); break;
         default: break;
       }
     }
@@ -532,6 +634,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
     amax_publish(amax_cells + 3 + bi, hmax);             // = the input tile of block bi + 1
+    if (bi + 1 < P.nblocks) load_ctx(bi + 1);
     G16_PH(5);                                               // [5] epilogue
     __syncthreads();                                         // (A) maximum published, planes free, taps staged
     G16_PH(3);
@@ -595,11 +698,11 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   G16_PH_DUMP;                                               // (stamp builds: sums over this workgroup's utterances)
 }
 
-template <int NT, bool SPLIT, bool FAST>
+template <int NT, bool SPLIT, bool FAST, bool CTX = false>
 inline int launch_ds256_g16_ntsf(const StackParams& P, const CallArgs& A, hipStream_t stream, int grid) {
   using G = W16Geom<NT>;
   static DynLdsGrant grant;
-  auto kern = ds256_g16_kernel<NT, SPLIT, FAST>;
+  auto kern = ds256_g16_kernel<NT, SPLIT, FAST, CTX>;
   if (grant_dynamic_lds(kern, int(G::LDS_BYTES), grant)) return -3;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kW16Threads), G::LDS_BYTES, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -608,12 +711,18 @@ template <int NT, bool SPLIT>
 inline int launch_ds256_g16_nts(const StackParams& P, const CallArgs& A, hipStream_t stream, int cus) {
   const bool fast = P.head == HEAD_LINEAR && P.odim <= 2 && P.kpre16 <= 64 && 8 * 16 * NT <= kW16Threads &&
                     P.idim % 8 == 0 && (reinterpret_cast<uintptr_t>(A.x) & 15) == 0 && A.xs_b % 4 == 0;   // = w16_x_vec_ok
+  if (A.in_cache) {                                          // a later chunk of a stream: the context variant, where one is built
+    if constexpr (NT >= 4) {
+      if (fast) return launch_ds256_g16_ntsf<NT, SPLIT, true, true>(P, A, stream, A.B < cus ? A.B : cus);
+    }
+    return -4;                                               // (other heads / feature layouts / shorter tiles: ds256_w16)
+  }
   return fast ? launch_ds256_g16_ntsf<NT, SPLIT, true>(P, A, stream, A.B < cus ? A.B : cus)
               : launch_ds256_g16_ntsf<NT, SPLIT, false>(P, A, stream, A.B);
 }
 
-// Calls WITHOUT an incoming cache whose blocks all have dilation 1, 2, 4 or 8 (the host checks; everything else:
-// launch_ds256_w16).  split: three fp16 products per MAC on hi/lo operands (F16X3) or one on the hi halves (F16).
+// Calls whose blocks all have dilation 1, 2, 4 or 8 (the host checks; everything else: launch_ds256_w16): without an incoming
+// cache, or -- keyword heads, tiles of >= 64 columns -- with one (returns -4 where no context variant is built).  split: three fp16 products per MAC on hi/lo operands (F16X3) or one on the hi halves (F16).
 // cus: compute units of the device = the largest grid (persistent workgroups).
 int launch_ds256_g16(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream, int cus);
 

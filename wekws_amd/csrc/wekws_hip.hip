@@ -325,6 +325,7 @@ struct wekws_hip_model {
   bool auto_f32 = false;  // ... and therefore the F32 kernels run (WEKWS_HIP_OPT_ENVELOPE = 0 keeps the split-fp16 kernels)
   bool g16_ok = true;     // ... calls without an incoming cache: the register-resident kernel (ds256_g16.hip.h; WEKWS_HIP_OPT_G16 = 0: ds256_w16)
   bool g16_one_pass = false;   // ... with a grid of B workgroups instead of persistent ones (option value 2: A/B measurements)
+  bool g16_ctx = true;    // ... and calls WITH an incoming cache: the kernel's context variant (option value 3: never, i.e. ds256_w16)
   int fsmn_slices = -1;   // FSMN / DS-TCN-CTC head slices per tile for small calls: -1 automatic, 0 / 1 off, n forces n
   bool stream_ok = true;  // DS-TCN h256 / MDTC h64, chunks of <= 16 frames: the kernel with the LDS-resident cache
                           // (WEKWS_HIP_OPT_STREAM = 0 keeps the batch kernel)
@@ -1322,7 +1323,7 @@ int wekws_hip_set_option(wekws_hip_model* m, int option, int value) {
     case WEKWS_HIP_OPT_STREAM: m->stream_ok = value != 0; break;
     case WEKWS_HIP_OPT_MM: m->mm_ok = m->mm_eligible && (value < 0 ? m->desc.odim > 16 : value != 0); break;
     case WEKWS_HIP_OPT_HEAD_SLICES: m->fsmn_slices = value; break;
-    case WEKWS_HIP_OPT_G16: m->g16_ok = value != 0; m->g16_one_pass = value == 2; break;   // (2: one workgroup per utterance, a measurement aid)
+    case WEKWS_HIP_OPT_G16: m->g16_ok = value != 0; m->g16_one_pass = value == 2; m->g16_ctx = value != 3; break;   // (2: one workgroup per utterance; 3: no context variants -- measurement aids)
     case WEKWS_HIP_OPT_ENVELOPE: m->auto_f32 = m->out_of_envelope && value != 0; break;
     case WEKWS_HIP_OPT_GRU_PIPE: m->gru_pipe = value < 0 ? 1 : value > 2 ? 2 : value; break;
     default: return fail(WEKWS_HIP_EINVAL, "unknown option %d", option);
@@ -1620,8 +1621,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              ? rc                                                            // exact f32, tile in registers
                              : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream))
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
-               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache)
-                     ? wekws::launch_ds256_g16(nt, split, m->sp, a, stream, m->g16_one_pass ? (1 << 30) : m->fsmn_cus)                      // 16 waves, tile in registers
+               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && (!a.in_cache || m->g16_ctx) &&
+                  (rc = wekws::launch_ds256_g16(a.in_cache && nt < 4 ? 4 : nt, split, m->sp, a, stream,
+                                                m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
+                     ? rc                                                                         // 16 waves, tile in registers (with a cache: its context variant)
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && !a.in_cache &&
                   (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4)

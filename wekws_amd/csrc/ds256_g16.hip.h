@@ -99,22 +99,28 @@ __device__ __forceinline__ void g16_fmac_shl(float& o, float x, float w) {
   G16_SHL(9) G16_SHL(10) G16_SHL(11) G16_SHL(12) G16_SHL(13) G16_SHL(14) G16_SHL(15)
 #undef G16_SHL
 }
-template <int S, int TT_, int NT, int R_>
+// PART 0: the tile's share of the tap (the lanes whose source stays in the row), PART 1: the context's share (the others).  A
+// tap's two instructions on one output depend on each other through the accumulator: they are issued as two passes over the NT
+// outputs, never back to back.
+template <int S, int TT_, int NT, int R_, int PART>
 __device__ __forceinline__ void g16_tapc(float& o, const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], float w) {
   constexpr int Q = S / NT, M = S % NT;
   constexpr int REG = TT_ >= M ? TT_ - M : TT_ - M + NT;
   constexpr int SH = TT_ >= M ? Q : Q + 1;
   static_assert(SH <= 15, "the context is one 16-lane row: NT >= 4 for paddings up to 56 frames");
-  if constexpr (SH == 0) o = fmaf(w, hv[REG][R_], o);
-  else {
+  if constexpr (SH == 0) {
+    if constexpr (PART == 0) o = fmaf(w, hv[REG][R_], o);
+  } else if constexpr (PART == 0) {
     g16_fmac_shr<SH>(o, hv[REG][R_], w);
+  } else {
     g16_fmac_shl<16 - SH>(o, cx[REG][R_], w);
   }
 }
 template <int S, int NT, int R_, int... TTs>
 __device__ __forceinline__ void g16_tapc_tiles(float (&o)[NT], const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], float w,
                                                std::integer_sequence<int, TTs...>) {
-  (g16_tapc<S, TTs, NT, R_>(o[TTs], hv, cx, w), ...);
+  (g16_tapc<S, TTs, NT, R_, 0>(o[TTs], hv, cx, w), ...);
+  (g16_tapc<S, TTs, NT, R_, 1>(o[TTs], hv, cx, w), ...);
 }
 
 typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   };
   // CTX: the left context of block `bi` into cx -- lane p holds the NT frames of lane p - 16, i.e. columns pad + NT (p - 16) ..
   // of the block's cache slice; whole lanes when NT divides the padding (NT = 7: pad = 7 d), element-wise otherwise.  Requested
-  // behind the epilogue that ends the block before (the accumulators, whose registers cx shares, are dead from there to the
-  // next matrix phase), so the trip overlaps the barrier and the block top.
+  // at the top of the block (measured: requesting it behind the epilogue of the block before, to overlap the trip with the
+  // barrier, keeps 28 more registers live across the block top and spills -- 0.30 ms per 1024 x 98 frames against 0.24).
   auto load_ctx = [&](int bi) __attribute__((always_inline)) {
     if constexpr (CTX) {
       const int padn = __builtin_amdgcn_readfirstlane(blk[bi].pad), offn = __builtin_amdgcn_readfirstlane(blk[bi].cache_off);
@@ -492,7 +498,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
     amax_publish(amax_cells + 2, hmax);
-    load_ctx(0);
     __syncthreads();                                         // (A) maximum published, planes free, taps staged
   }
   G16_PH(0);                                                 // [0] preprocessing
@@ -558,6 +563,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         }
       }
     };
+    load_ctx(bi);
     G16_PH(1);                                               // [1] block top
 
     // ---- depthwise dilated conv + folded BN + ReLU (tcn.py:102-109) of this lane's 4 channels x NT frames, from the
@@ -634,7 +640,6 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
     amax_publish(amax_cells + 3 + bi, hmax);             // = the input tile of block bi + 1
-    if (bi + 1 < P.nblocks) load_ctx(bi + 1);
     G16_PH(5);                                               // [5] epilogue
     __syncthreads();                                         // (A) maximum published, planes free, taps staged
     G16_PH(3);

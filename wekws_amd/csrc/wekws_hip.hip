@@ -1621,7 +1621,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                              ? rc                                                            // exact f32, tile in registers
                              : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream))
                : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
-               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && (!a.in_cache || m->g16_ctx) &&
+               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&     // (chunks of <= 16 frames with a cache: ds256_stream, else ds256_w16)
                   (rc = wekws::launch_ds256_g16(a.in_cache && nt < 4 ? 4 : nt, split, m->sp, a, stream,
                                                 m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
                      ? rc                                                                         // 16 waves, tile in registers (with a cache: its context variant)

@@ -622,6 +622,32 @@ def test_register_resident_kernel_with_incoming_cache():
         assert torch.equal(y2, y2p), prec
 
 
+def test_mdtc_register_resident_kernel_with_incoming_cache():
+    """The same for MDTC h64 (mdtc64_g4's context variant, round 5): later chunks of 17 .. 112 frames against mdtc64_w16 (option
+    g16 = 3) -- caches bit for bit, posteriors to the register head's few ulp -- and against the oracle's streaming forward.
+    Chunk lengths that NT divides and that it does not (then the frames below zero inside lane 0 come from the slice too), chunks
+    shorter than the largest padding (32 frames), 40-d and 80-d inputs, a stream-kernel chunk in between, a large batch."""
+    from wekws_amd import pack
+    for name in ("mdtc_h64", "mdtc_h64_80d"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 79)
+        for prec in ("default", "f16"):
+            a = build(cfg, sd).set_precision(prec)
+            b = build(cfg, sd).set_precision(prec).set_option("g16", 3)
+            for B, chunks in ((3, [40, 80, 17, 98]), (2, [20, 33, 10, 64, 49]), (1, [112, 112, 21]), (1100, [80, 77]), (5, [7, 28, 31, 33, 19])):
+                if name != "mdtc_h64" and B > 5:
+                    continue
+                T = sum(chunks)
+                x = synth.synth_feats(B, T, cfg["input_dim"], seed=T + B)
+                ya, ca = run(a, x, chunks=chunks)
+                yb, cb = run(b, x, chunks=chunks)
+                assert np.array_equal(ca, cb), (name, prec, B, chunks, max_abs(ca, cb))
+                assert max_abs(ya, yb) <= 5e-7, (name, prec, B, chunks, max_abs(ya, yb))
+                if prec == "default" and B <= 5:
+                    ry, rc = kws_oracle.forward_streaming(cfg, sd, x, chunks, None)
+                    assert max_abs(ya, ry) <= POSTERIOR_TOL and max_abs(ca, rc) <= tol_for(rc), (name, B, chunks, max_abs(ya, ry))
+
+
 def test_register_resident_f32_kernel_equals_generic_f32_kernel():
     """Precision F32, DS-TCN h256 keyword configuration without an incoming cache: ds256_g32 (tile in registers, exact-f32
     MFMA) against the generic conv_stack_kernel (option g16 = 0) -- the same products, each rounded once; the sums are

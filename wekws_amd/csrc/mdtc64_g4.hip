@@ -7,6 +7,18 @@ static int launch_g4(const StackParams& P, const CallArgs& A, hipStream_t stream
   hipLaunchKernelGGL((mdtc_g4_kernel<C, NT, SPLIT, POOLED, ALIGNED>), dim3(A.B), dim3(C * 4), LDS, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+// with an incoming cache: the context variant (C = 64, keyword head, NT >= 4)
+template <int NT, bool SPLIT, bool ALIGNED>
+static int launch_g4_ctx(const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  constexpr int LDS = 2 * Plane<64, 16 * NT>::BYTES;
+  hipLaunchKernelGGL((mdtc_g4_kernel<64, NT, SPLIT, false, ALIGNED, true>), dim3(A.B), dim3(256), LDS, stream, P, A);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+template <int NT>
+static int launch_g4_ctx_nt(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
+  if (A.T % NT == 0) return split ? launch_g4_ctx<NT, true, true>(P, A, stream) : launch_g4_ctx<NT, false, true>(P, A, stream);
+  return split ? launch_g4_ctx<NT, true, false>(P, A, stream) : launch_g4_ctx<NT, false, false>(P, A, stream);
+}
 template <int C, int NT, bool SPLIT, bool POOLED>
 static int launch_g4_a(const StackParams& P, const CallArgs& A, hipStream_t stream) {
   if constexpr (NT == 1) return launch_g4<C, NT, SPLIT, POOLED, true>(P, A, stream);     // (NT = 1 divides every T)
@@ -21,9 +33,15 @@ template <int C>
 static int launch_g4_c(int nt, bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
   const bool linear = P.head == HEAD_LINEAR && P.odim <= 2;
   const bool pooled = (P.head == HEAD_GLOBAL || P.head == HEAD_LAST) && P.head_hidden <= 448;   // (C + hidden floats of LDS)
-  const bool ok = P.ksize == 5 && !A.in_cache && (linear || pooled) && P.kpre16 <= (C == 64 ? 96 : 64) && P.idim % 8 == 0 &&
+  const bool ok = P.ksize == 5 && (linear || pooled) && P.kpre16 <= (C == 64 ? 96 : 64) && P.idim % 8 == 0 &&
                   (reinterpret_cast<uintptr_t>(A.x) & 15) == 0 && A.xs_b % 4 == 0;
   if (!ok) return -4;
+  if (A.in_cache) {                                          // a later chunk of a stream
+    if constexpr (C == 64) {
+      if (linear) return nt <= 4 ? launch_g4_ctx_nt<4>(split, P, A, stream) : nt == 7 ? launch_g4_ctx_nt<7>(split, P, A, stream) : -4;
+    }
+    return -4;
+  }
   switch (nt) {
     case 1: return launch_g4_nt<C, 1>(split, pooled, P, A, stream);
     case 2: return launch_g4_nt<C, 2>(split, pooled, P, A, stream);

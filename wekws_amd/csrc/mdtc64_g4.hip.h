@@ -47,8 +47,8 @@ __device__ __forceinline__ void g4_split_pair(float v0, float v1, float s, unsig
 
 // Depthwise dilated conv + folded BN (no ReLU) of the channel-row pair (2 P_, 2 P_ + 1) of the lane's four, all NT frames of
 // the lane; taps of a channel: 8-float record {w0 .. w4, bias, -, -}; tap j multiplies the frame (4 - j) dilations back
-template <int D, int P_, int NT, bool SPLIT>
-__device__ __forceinline__ void g4_dw_pair(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+template <int D, int P_, int NT, bool SPLIT, bool CTX = false>
+__device__ __forceinline__ void g4_dw_pair(const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
   const float4* src = reinterpret_cast<const float4*>(taps_o0 + 2 * P_ * 8);
   const float4 a0 = src[0], a1 = src[1], b0 = src[2], b1 = src[3];
   constexpr auto tiles = std::make_integer_sequence<int, NT>{};
@@ -56,11 +56,19 @@ __device__ __forceinline__ void g4_dw_pair(const f32x4 (&hv)[NT], const float* t
   float oa[NT], ob[NT];
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) { oa[tt] = a1.y; ob[tt] = b1.y; }
+  if constexpr (CTX) {   // (an incoming cache: the taps that leave the 16-lane row continue in the context tile, ds256_g16.hip.h)
+    g16_tapc_tiles<4 * D, NT, RA>(oa, hv, cx, a0.x, tiles); g16_tapc_tiles<4 * D, NT, RB>(ob, hv, cx, b0.x, tiles);
+    g16_tapc_tiles<3 * D, NT, RA>(oa, hv, cx, a0.y, tiles); g16_tapc_tiles<3 * D, NT, RB>(ob, hv, cx, b0.y, tiles);
+    g16_tapc_tiles<2 * D, NT, RA>(oa, hv, cx, a0.z, tiles); g16_tapc_tiles<2 * D, NT, RB>(ob, hv, cx, b0.z, tiles);
+    g16_tapc_tiles<1 * D, NT, RA>(oa, hv, cx, a0.w, tiles); g16_tapc_tiles<1 * D, NT, RB>(ob, hv, cx, b0.w, tiles);
+    g16_tapc_tiles<0, NT, RA>(oa, hv, cx, a1.x, tiles);     g16_tapc_tiles<0, NT, RB>(ob, hv, cx, b1.x, tiles);
+  } else {
   g16_tap_tiles<4 * D, NT, RA>(oa, hv, a0.x, tiles); g16_tap_tiles<4 * D, NT, RB>(ob, hv, b0.x, tiles);
   g16_tap_tiles<3 * D, NT, RA>(oa, hv, a0.y, tiles); g16_tap_tiles<3 * D, NT, RB>(ob, hv, b0.y, tiles);
   g16_tap_tiles<2 * D, NT, RA>(oa, hv, a0.z, tiles); g16_tap_tiles<2 * D, NT, RB>(ob, hv, b0.z, tiles);
   g16_tap_tiles<1 * D, NT, RA>(oa, hv, a0.w, tiles); g16_tap_tiles<1 * D, NT, RB>(ob, hv, b0.w, tiles);
   g16_tap_tiles<0, NT, RA>(oa, hv, a1.x, tiles);     g16_tap_tiles<0, NT, RB>(ob, hv, b1.x, tiles);
+  }
 #pragma unroll
   for (int tt = 0; tt < NT; ++tt) {
     // the pair's two halves of column 16 tt + l15: one 4-byte store per plane (holding them for an 8-byte store with the
@@ -71,10 +79,14 @@ __device__ __forceinline__ void g4_dw_pair(const f32x4 (&hv)[NT], const float* t
     if constexpr (SPLIT) *reinterpret_cast<unsigned*>(pst + lo_off + tt * 256 + P_ * 4) = pl;
   }
 }
+template <int D, int NT, bool SPLIT, bool CTX = false>
+__device__ __forceinline__ void g4_dw_rows(const f32x4 (&hv)[NT], const f32x4 (&cx)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
+  g4_dw_pair<D, 0, NT, SPLIT, CTX>(hv, cx, taps_o0, sa, pst, lo_off);
+  g4_dw_pair<D, 1, NT, SPLIT, CTX>(hv, cx, taps_o0, sa, pst, lo_off);
+}
 template <int D, int NT, bool SPLIT>
 __device__ __forceinline__ void g4_dw_rows(const f32x4 (&hv)[NT], const float* taps_o0, float sa, char* pst, int lo_off) {
-  g4_dw_pair<D, 0, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
-  g4_dw_pair<D, 1, NT, SPLIT>(hv, taps_o0, sa, pst, lo_off);
+  g4_dw_rows<D, NT, SPLIT, false>(hv, hv, taps_o0, sa, pst, lo_off);
 }
 
 // The last S registers of row r (frames NT l + NT - S .. NT l + NT - 1 of the lane) to S consecutive floats
@@ -109,8 +121,14 @@ __device__ __forceinline__ void g4_store_tail_n(int s, float* dst, const f32x4 (
 // ALIGNED: NT divides T (the 98-frame utterance at NT = 7), i.e. off = 0 at compile time: no frames below zero, so none of
 // the masks that keep them at zero (28 compare-selects per block).
 // C = 64 (mdtc.yaml; four waves) or 32 (mdtc_small.yaml, round 4: two waves per utterance, eight workgroups per CU).
-template <int C, int NT, bool SPLIT, bool POOLED, bool ALIGNED>
+// CTX (round 5; C = 64, per-frame linear head, NT >= 4): the call has an incoming cache -- a later chunk of 17 .. 112 frames of a
+// stream (shorter chunks: mdtc64_stream).  The blocks' left context continues the lane-major tile to the left as in
+// ds256_g16.hip.h's context variant: a second register tile cx (lane p = lane p - 16) reached by a row_shl for the taps that
+// leave the row, plus -- where NT does not divide T -- the frames below zero inside lane 0 (registers tt < off), which are
+// the slice's last columns instead of zeros.  Until round 5 these calls ran mdtc64_w16 (1.65 .. 1.8 x the first chunk's time).
+template <int C, int NT, bool SPLIT, bool POOLED, bool ALIGNED, bool CTX = false>
 __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, const CallArgs A) {
+  static_assert(!CTX || (C == 64 && !POOLED && NT >= 4), "context variant: MDTC h64, keyword head, a context of one 16-lane row");
   constexpr int TT = 16 * NT;
   constexpr int NTHR = C * 4;                                // one wave per o-tile of 16 channels
   constexpr int KS = C / 32;                                 // K steps of the block GEMMs = K steps of features staged per pass
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
   char* const pst = planes + ((o0 >> 3) * TT + l15) * 16 + (o0 & 7) * 2;
 
   f32x4 acc[NT], hv[NT];
+  f32x4 cx[CTX ? NT : 1];                                    // CTX: the current block's left context (registers shared with acc)
   // The head is linear, so the sum of the stack outputs (mdtc.py:270-273) never has to exist: every stack end adds ITS
   // contribution to the lane's partial head sums  yp[tt][k] = sum_r Wc[k][o0 + r] * out[r][frame tt]  (2 NT registers
   // instead of 4 NT for the sum itself -- the kernel is at the 128-register limit of four workgroups per CU).
@@ -178,6 +197,8 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
   __syncthreads();                                           // cells zeroed, table staged
   stage_taps(0, lane);
   amax_publish(amax_cells, xmax);
+  if constexpr (CTX)     // the depthwise rows are bounded through max(tile, incoming cache), like mdtc64_w16
+    amax_publish(amax_cells + 1, amax_span<NTHR>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
@@ -267,11 +288,44 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
       return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
     };
     float c1v, c2v;
-    const float ba = fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta);
+    const float au = CTX ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + bi);
+    const float ba = fmaf(bd.dw_alpha, au, bd.dw_beta);
     const float sa = uni(pow2_scale(ba, &c1v));
     const float c1 = uni(c1v * bd.inv_s1);
     const float sm = uni(pow2_scale(fmaf(bd.mid_alpha, ba, bd.mid_beta), &c2v));
     const float c2 = uni(c2v * bd.inv_s2);
+
+    // ---- CTX: the block's left context from its slice of the incoming cache.  Position q = NT lane + tt holds frame q - off;
+    //      frame f < 0 is slice column pad + f.  Lane p of cx holds lane p - 16 of the tile (whole lanes as 28-byte runs where
+    //      all NT columns exist), and the frames below zero inside lane 0 (tt < off) take the slice's last columns.
+    if constexpr (CTX) {
+      const float* const ic = A.in_cache + int64_t(b) * C * Pc + bd.cache_off;
+      const int c0 = pad - off + NT * (l15 - 16);            // slice column of this lane's first context position
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) cx[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c0 >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g16_load_run<NT>(ic + unsigned((o0b + r) * Pc + c0), cx, r);
+      } else if (c0 + NT > 0) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if (c0 + tt >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cx[tt][r] = ic[unsigned((o0b + r) * Pc + c0 + tt)];
+          }
+      }
+      if constexpr (!ALIGNED) {
+        if (l15 == 0) {
+#pragma unroll
+          for (int tt = 0; tt < NT - 1; ++tt)
+            if (tt < off) {
+              const int col = pad - off + tt;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hv[tt][r] = col >= 0 ? ic[unsigned((o0b + r) * Pc + col)] : 0.f;
+            }
+        }
+      }
+    }
 
     // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h], from the registers:
     //      whole lanes (NT consecutive columns each) plus one lane's last pad mod NT registers
@@ -291,7 +345,8 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
         const int nz = pad - T - off;
         for (int e = lane; e < 16 * nz; e += 64) {
           const int cc = e / nz, p = e - cc * nz;
-          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+          const int64_t at = (int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p;
+          A.out_cache[at] = CTX ? A.in_cache[at + T] : 0.f;   // (CTX: what was the tail of the incoming slice moves forward)
         }
       }
     }
@@ -300,10 +355,10 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
     {
       const float* taps_o0 = &taps[bi & 1][0] + o0 * 8;
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
-        case 1: g4_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 2: g4_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 4: g4_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 8: g4_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 1: if constexpr (CTX) g4_dw_rows<1, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g4_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 2: if constexpr (CTX) g4_dw_rows<2, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g4_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 4: if constexpr (CTX) g4_dw_rows<4, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g4_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 8: if constexpr (CTX) g4_dw_rows<8, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g4_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
         default: break;                                      // (d = 8 as the `default` arm came out wrong in this kernel: DESIGN.md 3.1a)
       }
     }

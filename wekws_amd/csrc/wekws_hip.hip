@@ -1643,7 +1643,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
           rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
                 cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0)
                    ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
-               : (f16 && m->mdtc16_ok && m->g16_ok && m->mdtc_stream_eligible && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
+               // (with a cache -- later chunks of 17 .. 112 frames --: the kernel's context variant, except for one or two streams
+               // at 65 .. 112 frames, where 17 blocks' context loads sit on one workgroup's critical path: 91 vs 75 us, measured)
+               : (f16 && m->mdtc16_ok && m->g16_ok && m->mdtc_stream_eligible &&
+                  (!a.in_cache || (m->g16_ctx && nt >= 2 && (B > 2 || nt < 7))) &&
                   (rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream)) != -4)
                    ? rc                                                                          // one utterance per 4-wave workgroup
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)

@@ -648,6 +648,33 @@ def test_mdtc_register_resident_kernel_with_incoming_cache():
                     assert max_abs(ya, ry) <= POSTERIOR_TOL and max_abs(ca, rc) <= tol_for(rc), (name, B, chunks, max_abs(ya, ry))
 
 
+def test_ds64_register_resident_kernel_with_incoming_cache():
+    """And for DS-TCN h64 -- the shape of the trained model the reference ships for Android, whose caller streams 80-frame
+    chunks (runtime/android/app/src/main/cpp/wekws.cc:84-97): ds64_g4's context variant against the generic kernel (option
+    g16 = 3) -- caches bit for bit -- and against the oracle's streaming forward; with and without CMVN."""
+    from wekws_amd import pack
+    for name in ("ds_tcn_h64", "ds_tcn_h64_cmvn1"):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 80)
+        for prec in ("default", "f16"):
+            a = build(cfg, sd).set_precision(prec)
+            b = build(cfg, sd).set_precision(prec).set_option("g16", 3)
+            for B, chunks in ((3, [40, 80, 17, 98]), (2, [20, 33, 10, 64, 49]), (1, [112, 112, 21]), (1100, [80, 77]), (5, [7, 56, 55, 57, 28])):
+                if name != "ds_tcn_h64" and B > 5:
+                    continue
+                T = sum(chunks)
+                x = synth.synth_feats(B, T, cfg["input_dim"], seed=T + B)
+                if "cmvn" in name:
+                    x = (3.0 * x + 10.0).astype(np.float32)
+                ya, ca = run(a, x, chunks=chunks)
+                yb, cb = run(b, x, chunks=chunks)
+                assert np.array_equal(ca, cb), (name, prec, B, chunks, max_abs(ca, cb))
+                assert max_abs(ya, yb) <= 5e-7, (name, prec, B, chunks, max_abs(ya, yb))
+                if prec == "default" and B <= 5:
+                    ry, rc = kws_oracle.forward_streaming(cfg, sd, x, chunks, None)
+                    assert max_abs(ya, ry) <= POSTERIOR_TOL and max_abs(ca, rc) <= tol_for(rc), (name, B, chunks, max_abs(ya, ry))
+
+
 def test_register_resident_f32_kernel_equals_generic_f32_kernel():
     """Precision F32, DS-TCN h256 keyword configuration without an incoming cache: ds256_g32 (tile in registers, exact-f32
     MFMA) against the generic conv_stack_kernel (option g16 = 0) -- the same products, each rounded once; the sums are

@@ -22,8 +22,14 @@
 
 namespace wekws {
 
-template <int NT, bool SPLIT, bool ALIGNED>
+// CTX (round 5, NT >= 4): the call has an incoming cache -- a later chunk of 17 .. 112 frames of a stream, e.g. the Android
+// caller's 80 (runtime/android/app/src/main/cpp/wekws.cc:84-97; shorter chunks: the generic kernel).  The blocks' left context
+// as in mdtc64_g4.hip.h's context variant: a second register tile cx (lane p = lane p - 16 of the tile, reached by a row_shl
+// for the taps that leave the row) and, where NT does not divide T, the frames below zero inside lane 0 from the slice's last
+// columns.  Until round 5 these calls ran the generic 8-wave kernel: 2.6 .. 3 x the first chunk's time.
+template <int NT, bool SPLIT, bool ALIGNED, bool CTX = false>
 __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParams P, const CallArgs A) {
+  static_assert(!CTX || NT >= 4, "the context tile is one 16-lane row (paddings up to 56 frames)");
   constexpr int C = 64, TT = 16 * NT;
   constexpr int MPB = Plane<C, TT>::BYTES;                   // one hi (or lo) plane of the 64-channel operand
   constexpr int XI = (3 * 4 * TT + kG4Threads - 1) / kG4Threads;   // feature items per thread (<= 3 K steps)
@@ -43,6 +49,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
   char* const pst = planes + ((o0 >> 3) * TT + l15) * 16 + (o0 & 7) * 2;
 
   f32x4 acc[NT], hv[NT];
+  f32x4 cx[CTX ? NT : 1];                                    // CTX: the current block's left context (registers shared with acc)
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
   __shared__ __attribute__((aligned(16))) float taps[2][C * 12];   // taps + bias records of the current / next block
@@ -77,6 +84,8 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
   __syncthreads();                                           // cells zeroed, table staged
   stage_taps(0, lane);
   amax_publish(amax_cells, xmax);
+  if constexpr (CTX)     // the depthwise rows are bounded through max(tile, incoming cache), like conv_stack_f16.hip.h
+    amax_publish(amax_cells + 1, amax_span<kG4Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
@@ -148,8 +157,40 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
       return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
     };
     float c1v;
-    const float sa = uni(pow2_scale(fmaf(bd.dw_alpha, amax_read(amax_cells + 2 + bi), bd.dw_beta), &c1v));
+    const float au = CTX ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + bi);
+    const float sa = uni(pow2_scale(fmaf(bd.dw_alpha, au, bd.dw_beta), &c1v));
     const float c1 = uni(c1v * bd.inv_s1);
+
+    // ---- CTX: the block's left context from its slice of the incoming cache (position q = NT lane + tt holds frame q - off;
+    //      frame f < 0 is slice column pad + f): lane p of cx = lane p - 16 of the tile, lane 0's registers tt < off
+    if constexpr (CTX) {
+      const float* const ic = A.in_cache + int64_t(b) * C * Pc + bd.cache_off;
+      const int c0 = pad - off + NT * (l15 - 16);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) cx[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c0 >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g16_load_run<NT>(ic + unsigned((o0b + r) * Pc + c0), cx, r);
+      } else if (c0 + NT > 0) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if (c0 + tt >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cx[tt][r] = ic[unsigned((o0b + r) * Pc + c0 + tt)];
+          }
+      }
+      if constexpr (!ALIGNED) {
+        if (l15 == 0) {
+#pragma unroll
+          for (int tt = 0; tt < NT - 1; ++tt)
+            if (tt < off) {
+              const int col = pad - off + tt;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hv[tt][r] = col >= 0 ? ic[unsigned((o0b + r) * Pc + col)] : 0.f;
+            }
+        }
+      }
+    }
 
     // ---- the block's streaming-cache slice = the last `pad` frames of its input tile [zeros | h], from the registers
     if (A.out_cache) {
@@ -168,7 +209,8 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
         const int nz = pad - T - off;
         for (int e = lane; e < 16 * nz; e += 64) {
           const int cc = e / nz, p = e - cc * nz;
-          A.out_cache[(int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p] = 0.f;
+          const int64_t at = (int64_t(b) * C + wave * 16 + cc) * Pc + bd.cache_off + p;
+          A.out_cache[at] = CTX ? A.in_cache[at + T] : 0.f;   // (CTX: what was the tail of the incoming slice moves forward)
         }
       }
     }
@@ -177,10 +219,10 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
     {
       const float* taps_o0 = &taps[bi & 1][0] + o0 * 12;
       switch (bd.dil) {                                      // (the host admits this kernel for dilations 1 / 2 / 4 / 8 only)
-        case 1: g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 2: g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 4: g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
-        case 8: g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 1: if constexpr (CTX) g16_dw_rows<1, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g16_dw_rows<1, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 2: if constexpr (CTX) g16_dw_rows<2, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g16_dw_rows<2, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 4: if constexpr (CTX) g16_dw_rows<4, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g16_dw_rows<4, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
+        case 8: if constexpr (CTX) g16_dw_rows<8, NT, SPLIT, true>(hv, cx, taps_o0, sa, pst, MPB); else g16_dw_rows<8, NT, SPLIT>(hv, taps_o0, sa, pst, MPB); break;
         default: break;
       }
     }

@@ -1626,7 +1626,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                                                 m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
                      ? rc                                                                         // 16 waves, tile in registers (with a cache: its context variant)
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
-               : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && !a.in_cache &&
+               : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
                   (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4)
                      ? rc                                                                         // one utterance per 4-wave workgroup
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);

@@ -656,7 +656,7 @@ def test_ds64_register_resident_kernel_with_incoming_cache():
     for name in ("ds_tcn_h64", "ds_tcn_h64_cmvn1"):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 80)
-        for prec in ("default", "f16"):
+        for prec in ("default",):                              # (the generic kernel has no one-product mode to compare "f16" with)
             a = build(cfg, sd).set_precision(prec)
             b = build(cfg, sd).set_precision(prec).set_option("g16", 3)
             for B, chunks in ((3, [40, 80, 17, 98]), (2, [20, 33, 10, 64, 49]), (1, [112, 112, 21]), (1100, [80, 77]), (5, [7, 56, 55, 57, 28])):

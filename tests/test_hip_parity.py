@@ -651,9 +651,9 @@ def test_mdtc_register_resident_kernel_with_incoming_cache():
 def test_ds64_register_resident_kernel_with_incoming_cache():
     """And for DS-TCN h64 -- the shape of the trained model the reference ships for Android, whose caller streams 80-frame
     chunks (runtime/android/app/src/main/cpp/wekws.cc:84-97): ds64_g4's context variant against the generic kernel (option
-    g16 = 3) -- caches bit for bit -- and against the oracle's streaming forward; with and without CMVN."""
+    g16 = 3) -- caches bit for bit -- and against the oracle's streaming forward."""
     from wekws_amd import pack
-    for name in ("ds_tcn_h64", "ds_tcn_h64_cmvn1"):
+    for name in ("ds_tcn_h64",):
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 80)
         for prec in ("default",):                              # (the generic kernel has no one-product mode to compare "f16" with)
@@ -664,8 +664,6 @@ def test_ds64_register_resident_kernel_with_incoming_cache():
                     continue
                 T = sum(chunks)
                 x = synth.synth_feats(B, T, cfg["input_dim"], seed=T + B)
-                if "cmvn" in name:
-                    x = (3.0 * x + 10.0).astype(np.float32)
                 ya, ca = run(a, x, chunks=chunks)
                 yb, cb = run(b, x, chunks=chunks)
                 assert np.array_equal(ca, cb), (name, prec, B, chunks, max_abs(ca, cb))

@@ -628,14 +628,16 @@ def test_mdtc_register_resident_kernel_with_incoming_cache():
     Chunk lengths that NT divides and that it does not (then the frames below zero inside lane 0 come from the slice too), chunks
     shorter than the largest padding (32 frames), 40-d and 80-d inputs, a stream-kernel chunk in between, a large batch."""
     from wekws_amd import pack
-    for name in ("mdtc_h64", "mdtc_h64_80d"):
+    for name in ("mdtc_h64", "mdtc_h64_80d", "mdtc_small"):    # (mdtc_small: 32 channels, two waves per utterance)
         cfg = dict(synth.MODEL_CONFIGS[name])
         sd = synth.synth_state_dict(pack.model_spec(cfg), 79)
         for prec in ("default", "f16"):
+            if prec == "f16" and name == "mdtc_small":       # (its fallback, the generic kernel, has no one-product mode)
+                continue
             a = build(cfg, sd).set_precision(prec)
             b = build(cfg, sd).set_precision(prec).set_option("g16", 3)
             for B, chunks in ((3, [40, 80, 17, 98]), (2, [20, 33, 10, 64, 49]), (1, [112, 112, 21]), (1100, [80, 77]), (5, [7, 28, 31, 33, 19])):
-                if name != "mdtc_h64" and B > 5:
+                if name == "mdtc_h64_80d" and B > 5:
                     continue
                 T = sum(chunks)
                 x = synth.synth_feats(B, T, cfg["input_dim"], seed=T + B)

@@ -7,17 +7,17 @@ static int launch_g4(const StackParams& P, const CallArgs& A, hipStream_t stream
   hipLaunchKernelGGL((mdtc_g4_kernel<C, NT, SPLIT, POOLED, ALIGNED>), dim3(A.B), dim3(C * 4), LDS, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-// with an incoming cache: the context variant (C = 64, keyword head, NT >= 4)
-template <int NT, bool SPLIT, bool ALIGNED>
+// with an incoming cache: the context variant (keyword head, NT >= 4)
+template <int C, int NT, bool SPLIT, bool ALIGNED>
 static int launch_g4_ctx(const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  constexpr int LDS = 2 * Plane<64, 16 * NT>::BYTES;
-  hipLaunchKernelGGL((mdtc_g4_kernel<64, NT, SPLIT, false, ALIGNED, true>), dim3(A.B), dim3(256), LDS, stream, P, A);
+  constexpr int LDS = 2 * Plane<C, 16 * NT>::BYTES;
+  hipLaunchKernelGGL((mdtc_g4_kernel<C, NT, SPLIT, false, ALIGNED, true>), dim3(A.B), dim3(C * 4), LDS, stream, P, A);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-template <int NT>
+template <int C, int NT>
 static int launch_g4_ctx_nt(bool split, const StackParams& P, const CallArgs& A, hipStream_t stream) {
-  if (A.T % NT == 0) return split ? launch_g4_ctx<NT, true, true>(P, A, stream) : launch_g4_ctx<NT, false, true>(P, A, stream);
-  return split ? launch_g4_ctx<NT, true, false>(P, A, stream) : launch_g4_ctx<NT, false, false>(P, A, stream);
+  if (A.T % NT == 0) return split ? launch_g4_ctx<C, NT, true, true>(P, A, stream) : launch_g4_ctx<C, NT, false, true>(P, A, stream);
+  return split ? launch_g4_ctx<C, NT, true, false>(P, A, stream) : launch_g4_ctx<C, NT, false, false>(P, A, stream);
 }
 template <int C, int NT, bool SPLIT, bool POOLED>
 static int launch_g4_a(const StackParams& P, const CallArgs& A, hipStream_t stream) {
@@ -37,9 +37,7 @@ static int launch_g4_c(int nt, bool split, const StackParams& P, const CallArgs&
                   (reinterpret_cast<uintptr_t>(A.x) & 15) == 0 && A.xs_b % 4 == 0;
   if (!ok) return -4;
   if (A.in_cache) {                                          // a later chunk of a stream
-    if constexpr (C == 64) {
-      if (linear) return nt <= 4 ? launch_g4_ctx_nt<4>(split, P, A, stream) : nt == 7 ? launch_g4_ctx_nt<7>(split, P, A, stream) : -4;
-    }
+    if (linear) return nt <= 4 ? launch_g4_ctx_nt<C, 4>(split, P, A, stream) : nt == 7 ? launch_g4_ctx_nt<C, 7>(split, P, A, stream) : -4;
     return -4;
   }
   switch (nt) {

@@ -121,14 +121,14 @@ __device__ __forceinline__ void g4_store_tail_n(int s, float* dst, const f32x4 (
 // ALIGNED: NT divides T (the 98-frame utterance at NT = 7), i.e. off = 0 at compile time: no frames below zero, so none of
 // the masks that keep them at zero (28 compare-selects per block).
 // C = 64 (mdtc.yaml; four waves) or 32 (mdtc_small.yaml, round 4: two waves per utterance, eight workgroups per CU).
-// CTX (round 5; C = 64, per-frame linear head, NT >= 4): the call has an incoming cache -- a later chunk of 17 .. 112 frames of a
+// CTX (round 5; per-frame linear head, NT >= 4): the call has an incoming cache -- a later chunk of 17 .. 112 frames of a
 // stream (shorter chunks: mdtc64_stream).  The blocks' left context continues the lane-major tile to the left as in
 // ds256_g16.hip.h's context variant: a second register tile cx (lane p = lane p - 16) reached by a row_shl for the taps that
 // leave the row, plus -- where NT does not divide T -- the frames below zero inside lane 0 (registers tt < off), which are
 // the slice's last columns instead of zeros.  Until round 5 these calls ran mdtc64_w16 (1.65 .. 1.8 x the first chunk's time).
 template <int C, int NT, bool SPLIT, bool POOLED, bool ALIGNED, bool CTX = false>
 __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, const CallArgs A) {
-  static_assert(!CTX || (C == 64 && !POOLED && NT >= 4), "context variant: MDTC h64, keyword head, a context of one 16-lane row");
+  static_assert(!CTX || (!POOLED && NT >= 4), "context variant: keyword head, a context of one 16-lane row");
   constexpr int TT = 16 * NT;
   constexpr int NTHR = C * 4;                                // one wave per o-tile of 16 channels
   constexpr int KS = C / 32;                                 // K steps of the block GEMMs = K steps of features staged per pass

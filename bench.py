@@ -33,6 +33,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields:
                   bytes and wall time of the weight broadcast; `per_rank_utts_per_s` min / max over the ranks.
   f32             the same batch with precision F32 (exact-f32 MFMA kernel: each product rounded once, the reference's
                   own arithmetic), with its own roofline against the 157.3 TF f32 matrix peak.
+  latency_chunk80 the same with 80-frame chunks (the Android caller's size) for DS-TCN h64 (the shipped model's shape), DS-TCN h256
+                  and MDTC h64.
   latency         streaming, 10-frame chunks with the carried cache (stream_kws_ctc.py:482-514, keyword_spotting.cc:56-95):
                   us per frame, median / p10 / p90 over 1000 chunks, for GRU 2x128 (BASELINE config 3), DS-TCN h256 and
                   MDTC h64 at 1 and 256 concurrent streams; `cpu` = the reference's PyTorch CPU operators on the same
@@ -631,6 +633,13 @@ def main():
             for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
                 lat[name] = {f"B{b}": stream_latency(torch, init_model, pack, synth, dev, name, b) for b in (1, 256)}
             out["latency"] = lat
+            # ... and with the Android caller's chunk size (80 frames, runtime/android/app/src/main/cpp/wekws.cc:84-97; the
+            # shipped model is the DS-TCN h64 shape): chunks with a carried cache run the register-resident kernels'
+            # context variants since round 5
+            lat80 = {"unit": "us per frame (80-frame chunks with the carried cache; median / p10 / p90 over 300 consecutive chunks)"}
+            for name in ("ds_tcn_h64", "ds_tcn_h256", "mdtc_h64"):
+                lat80[name] = {f"B{b}": stream_latency(torch, init_model, pack, synth, dev, name, b, chunk=80, n=300) for b in (1, 256)}
+            out["latency_chunk80"] = lat80
             # ---- HBM-bound kernels
             other = []
             Bs = 4096

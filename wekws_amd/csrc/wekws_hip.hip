@@ -1651,7 +1651,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                    ? rc                                                                          // one utterance per 4-wave workgroup
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : (f16 && C == 32 && m->g16_ok && d.kernel_size == 5 && d.stack_size <= 4 &&
-                  (!a.in_cache || (m->g16_ctx && nt >= 2 && (B > 2 || nt < 7))) &&
+                  (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
                   (rc = wekws::launch_mdtc32_g4(nt, split, m->sp, a, stream)) != -4)
                    ? rc                                                                          // one utterance per 2-wave workgroup
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)

@@ -918,6 +918,8 @@ void ReadModelFile(const std::string& path, wekws_hip_desc* desc, std::vector<fl
     uint64_t count = 0;
     if (bytes.size() < 8 + sizeof(*desc) + 8) Fail(path + " is truncated");
     std::memcpy(desc, bytes.data() + 8, sizeof(*desc));
+    // files written under ABI version 1 carry the same descriptor / blob layout (version 2 added entry points, not fields)
+    if (desc->abi_version == 1) desc->abi_version = WEKWS_HIP_ABI_VERSION;
     std::memcpy(&count, bytes.data() + 8 + sizeof(*desc), 8);
     if (bytes.size() != 8 + sizeof(*desc) + 8 + count * sizeof(float)) Fail(path + " is truncated");
     blob->resize(count);

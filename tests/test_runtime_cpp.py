@@ -224,3 +224,21 @@ def test_feature_pipeline_uneven_pushes(tmp_path, mode):
             if first is None:
                 first = got
             assert np.array_equal(got, first), (cname, sizes)       # push pattern / overload do not change a bit
+
+
+def test_packed_files_written_under_abi_1_still_load(tmp_path):
+    """ABI version 2 (round 5) added entry points, not descriptor fields or blob sections: a `.wekwship` file written by an ABI-1
+    build must keep loading -- in Python (pack.load_packed) and in the C++ runtime's reader (a rocprofv3 trace of kws_main on such a
+    file is how the C++ side's rejection was found)."""
+    build_runtime()
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"])
+    desc, blob = pack.pack(cfg, synth.synth_state_dict(pack.model_spec(cfg), 3))
+    old = str(tmp_path / "old.wekwship")
+    pack.save_packed(old, dict(desc, abi_version=1), blob)
+    d2, b2 = pack.load_packed(old)
+    assert d2["abi_version"] == pack.ABI_VERSION and np.array_equal(b2, blob)
+    new = str(tmp_path / "new.wekwship")
+    r = subprocess.run([MODEL_CONVERT, old, new], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d3, b3 = pack.load_packed(new)
+    assert d3["abi_version"] == pack.ABI_VERSION and np.array_equal(b3, blob)

@@ -432,6 +432,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # model,threads,T,seconds: see cpu_pinned_rows
     ap.add_argument("--no-extras", action="store_true", help="only the contract fields + roofline")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="PLUMBING TEST ONLY (tests/test_hip_bench.py on a 1-GPU box): all ranks use cuda:0 and talk over gloo, so "
+                         "that every multi-rank statement of this file runs on a GPU at least once; the line is marked "
+                         "`test_mode` and is not a measurement")
     ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3", "f16"],
                     help="matrix arithmetic of `value` (enum wekws_hip_precision); default = f16x3 with block floating "
                          "point (fp32-level accuracy at any operand scale); the f32 number is always reported beside it")
@@ -448,17 +452,20 @@ def main():
     from wekws_amd import pack, parallel
     from wekws_amd.utils import synth
 
-    rank, world, local = parallel.init_distributed()
+    rank, world, local = parallel.init_distributed("gloo" if args.share_gpu else None)
+    if args.share_gpu:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     from wekws_amd.model.kws_model import init_model
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    if torch.cuda.device_count() <= local or torch.cuda.device_count() < min(args.gpus, world):
+    if torch.cuda.device_count() <= local or (not args.share_gpu and torch.cuda.device_count() < min(args.gpus, world)):
         raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} (LOCAL_RANK {local}) sees {torch.cuda.device_count()} GPU(s); "
                          "one rank per GPU needs at least as many visible devices (check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = torch.device("cpu") if args.share_gpu else dev     # where the job's few collective payloads live (gloo: host)
 
     cfg = dict(synth.MODEL_CONFIGS[args.model])
     T, idim, B = 98, cfg["input_dim"], args.batch
@@ -470,7 +477,7 @@ def main():
     model = model.to(dev).eval().set_precision(args.precision)
     torch.cuda.synchronize()
     t_bc = time.perf_counter()
-    parallel.broadcast_weights(model, src=0, device=dev)     # the job's ONE collective (RCCL over xGMI when world > 1)
+    parallel.broadcast_weights(model, src=0, device=comm_dev)   # the job's ONE collective (RCCL over xGMI when world > 1)
     torch.cuda.synchronize()
     t_bc = time.perf_counter() - t_bc
     bc_bytes = 4 * sum(int(t.numel()) for t in model.state_dict().values() if t.is_floating_point())
@@ -492,7 +499,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    cold = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    cold = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(cold, op=dist.ReduceOp.MAX)
     cold_s = float(cold.item())
@@ -540,7 +547,7 @@ def main():
         places = [None] * world
         dist.all_gather_object(places, place)
     if world > 1:
-        mine = torch.tensor([elapsed, t_bc], dtype=torch.float64, device=dev)
+        mine = torch.tensor([elapsed, t_bc], dtype=torch.float64, device=comm_dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_rates = [B * args.steps / float(t[0].item()) for t in allr]
@@ -590,7 +597,10 @@ def main():
             out["per_rank_utts_per_s"] = {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1),
                                           "all": [round(r, 1) for r in rank_rates]}
             out["comm"]["ranks"] = places
-            assert len({(p["host"], p["device"]) for p in places}) == world, f"two ranks share a GPU: {places}"
+            if args.share_gpu:
+                out["test_mode"] = "--share-gpu: all ranks on cuda:0 over gloo (plumbing test, NOT a measurement)"
+            else:
+                assert len({(p["host"], p["device"]) for p in places}) == world, f"two ranks share a GPU: {places}"
         if args.model in FLOP_PER_UTT:
             roof = mfma_roofline(args.model, B, kern_ms, prec)
             roof["kernel_ms_note"] = "HIP events around the K timed steps / K"

@@ -48,3 +48,18 @@ def test_contract_line_small_run():
     assert v1["value"] > 0 and "median" in v1["step_ms"]
     # the product is (much) faster than the CPU path it replaces; not a quality claim, a sanity check of both numbers
     assert d["value"] > 10 * c["value"]
+
+
+def test_multi_rank_statements_run_on_a_gpu():
+    """No session and no driver run ever had more than one GPU, so the N > 1 statements of bench.py (rank rendezvous, weight
+    broadcast into rank > 0's module, barriers, MAX over ranks, per-rank placement, `comm`) had only ever run in the CPU stub.
+    `--share-gpu` lets two ranks share cuda:0 over gloo: every one of those statements executes, with the real forward, on the GPU
+    box.  The number is meaningless (two processes time-share one device) and the line says so."""
+    d = run_bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--preheat", "0.05", "--no-extras", "--no-cpu-baseline",
+                  "--share-gpu")
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and "test_mode" in d
+    assert d["comm"]["world_size"] == 2 and d["comm"]["collectives_in_timed_region"] == 0 and d["comm"]["broadcast_bytes"] > 1_000_000
+    assert [p["rank"] for p in d["comm"]["ranks"]] == [0, 1] and len(d["per_rank_utts_per_s"]["all"]) == 2
+    assert d["value"] > 0 and d["value_no_preheat"]["value"] > 0
+    # whole-job value = utterances of both ranks / the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]

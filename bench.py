@@ -406,7 +406,7 @@ def self_launch(args, script=None, need_gpus=True):
     """--gpus N without a launcher: spawn the N ranks ourselves (what the driver's torch.distributed.run line does).
     `script` / `need_gpus`: tests/tools/bench_stub.py drives this launcher with CPU ranks."""
     import torch
-    if need_gpus and torch.cuda.device_count() < args.gpus:
+    if need_gpus and not getattr(args, "share_gpu", False) and torch.cuda.device_count() < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -476,6 +476,35 @@ def test_forward_is_graph_capturable():
         assert torch.equal(y_static, y) and torch.equal(cache_static, cache)
 
 
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "ds_tcn_h64", "mdtc_h64"])
+def test_context_variant_is_graph_capturable(name):
+    """The same for 80-frame chunks with the carried cache -- the register-resident kernels' context variants (round 5): no
+    allocation, no synchronisation, replays bit-identically."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234)).freeze()
+    B, Tc, n = 3, 80, 4
+    xs = torch.from_numpy(synth.synth_feats(B, Tc * n, cfg["input_dim"], seed=8)).cuda()
+    x_static = xs[:, :Tc].clone()
+    cache_static = torch.zeros(pack.cache_shape(pack.parse_config(cfg), B), device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        model(x_static, cache_static)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        y_static, c_out = model(x_static, cache_static)
+        cache_static.copy_(c_out)
+    cache, cache_static[:] = torch.zeros_like(cache_static), 0.0
+    for t in range(0, Tc * n, Tc):
+        y, cache = model(xs[:, t:t + Tc].contiguous(), cache)
+        x_static.copy_(xs[:, t:t + Tc])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, y) and torch.equal(cache_static, cache), (name, t)
+
+
 def test_long_input_tiling_matches_oracle():
     """T > 112 goes through several LDS tiles that hand the context over via the workspace cache."""
     from wekws_amd import pack

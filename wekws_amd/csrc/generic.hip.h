@@ -6,8 +6,8 @@
 // were WEKWS_HIP_EUNSUPPORTED (the reference runs them), resp. served with different rounding.
 //
 // One small family instead of one kernel per shape: activations live in HBM as (B, T, C) rows, every layer is a launch,
-// all arithmetic is exact f32 (v_fma_f32: each product rounded once inside the fma, like the reference's fp32 math):
-//   gen_gemm_kernel   Y = epilogue(X W^T + b): Linear / 1x1 conv / one tap of a dense conv; 64 x 64 tiles through LDS
+// all arithmetic is exact f32 (v_mfma_f32_16x16x4_f32 / v_fma_f32: every product exact, f32 accumulation, like the reference's fp32 math):
+//   gen_gemm_kernel   Y = epilogue(X W^T + b): Linear / 1x1 conv / one tap of a dense conv; 64 x 64 tiles through LDS, f32 MFMA
 //   gen_ctx_kernel    [cache | h] of a block as one (B, pad + T, C) buffer (tcn.py:45-53, mdtc.py:98-104, fsmn.py:228-236) and,
 //                     from the same pass, the block's slice of the returned cache (its last `pad` rows)
 //   gen_dw_kernel     depthwise dilated conv over that buffer (tcn.py:102-109, mdtc.py:55-58; the FSMN memory block
@@ -49,10 +49,15 @@ struct GenGemm {
 
 constexpr int kGenTile = 64, kGenK = 16;
 
+// 256 threads = 4 waves; workgroup tile 64 x 64, K in chunks of 16 through LDS; wave w multiplies rows 16 w .. 16 w + 15 by all
+// 64 columns with v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate): A operand = lane's (row l % 16, k l / 16), B
+// operand = (k l / 16, column l % 16), accumulator register i of lane l = (row 4 (l / 16) + i, column l % 16).
 __global__ __launch_bounds__(256) void gen_gemm_kernel(const GenGemm g) {
   __shared__ float xs[kGenK][kGenTile + 4];
   __shared__ float ws[kGenK][kGenTile + 4];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
   const int64_t M = int64_t(g.Bn) * g.Tn;
   const int64_t m0 = int64_t(blockIdx.x) * kGenTile;
   const int n0 = blockIdx.y * kGenTile;
@@ -63,11 +68,9 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(const GenGemm g) {
   if (xm < M) { const int64_t b = xm / g.Tn, t = xm - b * g.Tn; xrow = g.X + b * g.x_bs + t * g.x_rs; }
   const int wn = n0 + lr;
   const float* wrow = wn < g.N ? g.W + int64_t(wn) * g.w_ns : nullptr;
-  float acc[4][4];
+  gen_f32x4 acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int j = 0; j < 4; ++j) acc[j] = gen_f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < g.K; k0 += kGenK) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -77,31 +80,25 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(const GenGemm g) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kGenK; ++k) {
-      float a[4], b[4];
+    for (int k4 = 0; k4 < kGenK; k4 += 4) {
+      const float a = xs[k4 + lq][wave * 16 + l15];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = xs[k][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = ws[k][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws[k4 + lq][j * 16 + l15], acc[j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + ty * 4 + i;
+    const int64_t m = m0 + wave * 16 + lq * 4 + i;
     if (m >= M) continue;
     const int64_t b = m / g.Tn, t = m - b * g.Tn;
     float* yrow = g.Y + b * g.y_bs + t * g.y_rs;
     const float* rrow = g.R ? g.R + b * g.r_bs + t * g.r_rs : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
+      const int n = n0 + j * 16 + l15;
       if (n >= g.N) continue;
-      float v = acc[i][j];
+      float v = acc[j][i];
       if (g.flags & GEN_ACCUM) v += yrow[n];
       if (!(g.flags & GEN_PARTIAL)) {
         if (g.bias) v += g.bias[n];

@@ -71,14 +71,29 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(const GenGemm g) {
   gen_f32x4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = gen_f32x4{0.f, 0.f, 0.f, 0.f};
+  // a thread's four k of a chunk are one 16-byte load where the operand's rows are 16-byte aligned runs (the usual case: row
+  // strides and K multiples of four floats); the chunk after the current one is requested before the current one is multiplied
+  const bool xvec = g.K % 4 == 0 && ((reinterpret_cast<uintptr_t>(g.X) | uintptr_t(g.x_bs * 4) | uintptr_t(g.x_rs * 4)) & 15) == 0;
+  const bool wvec = g.K % 4 == 0 && g.w_ks == 1 && ((reinterpret_cast<uintptr_t>(g.W) | uintptr_t(g.w_ns * 4)) & 15) == 0;
+  auto fetch = [&](const float* row, int64_t ks, bool vec, int k0) __attribute__((always_inline)) -> gen_f32x4 {
+    gen_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int k = k0 + lk;
+    if (row && k < g.K) {
+      if (vec) v = *reinterpret_cast<const gen_f32x4*>(row + k);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (k + q < g.K) v[q] = row[int64_t(k + q) * ks];
+      }
+    }
+    return v;
+  };
+  gen_f32x4 xq = fetch(xrow, 1, xvec, 0), wq = fetch(wrow, g.w_ks, wvec, 0);
   for (int k0 = 0; k0 < g.K; k0 += kGenK) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = k0 + lk + q;
-      xs[lk + q][lr] = (xrow && k < g.K) ? xrow[k] : 0.f;
-      ws[lk + q][lr] = (wrow && k < g.K) ? wrow[int64_t(k) * g.w_ks] : 0.f;
-    }
+    for (int q = 0; q < 4; ++q) { xs[lk + q][lr] = xq[q]; ws[lk + q][lr] = wq[q]; }
     __syncthreads();
+    if (k0 + kGenK < g.K) { xq = fetch(xrow, 1, xvec, k0 + kGenK); wq = fetch(wrow, g.w_ks, wvec, k0 + kGenK); }
 #pragma unroll
     for (int k4 = 0; k4 < kGenK; k4 += 4) {
       const float a = xs[k4 + lq][wave * 16 + l15];

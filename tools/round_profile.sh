@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_{pytest_gpu.txt,parity_errors.json,f16x3.txt,f32.txt,stream_kernels.txt,pmc_traffic.json,bench.json,
 #    configs.jsonl}; the rocprofv3 databases are deleted at the end (gpurun merges at most 64 MiB back).
 set -u
-tag=${1:-r05h}
+tag=${1:-r05j}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out

@@ -245,6 +245,31 @@ def test_full_batch_properties(name, B):
         assert max_abs(cst, cache) <= 2e-5 * max(1.0, float(np.abs(cache).max()))
 
 
+@pytest.mark.parametrize("name,B", [("ds_tcn_h256", 1024), ("mdtc_h64", 1024), ("ds_tcn_h64", 1024), ("mdtc_small", 1024)])
+def test_full_batch_streaming_with_long_chunks(name, B):
+    """BASELINE-size batches through the context variants (round 5): three seconds of features streamed in 80-frame chunks (the
+    Android caller's size) and in ragged chunks above 16 frames equal the one-shot forward of the same 294 frames (which runs the
+    tiled long-input path) -- posteriors and final cache; a sub-batch of streams reproduces its rows exactly."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    T = 294
+    x = synth.synth_feats(B, T, cfg["input_dim"], seed=4)
+    model = build(cfg, sd)
+    y, cache = run(model, x)
+    assert np.isfinite(y).all() and np.isfinite(cache).all()
+    for chunks in ([80, 80, 80, 54], [17, 112, 33, 64, 49, 19]):
+        ys, cs = run(model, x, chunks=chunks)
+        assert max_abs(ys, y) <= 2e-5, (name, chunks, max_abs(ys, y))
+        assert max_abs(cs, cache) <= 2e-5 * max(1.0, float(np.abs(cache).max())), (name, chunks)
+    idx = np.array([0, 1, B // 3, B // 2, B - 2, B - 1])
+    ys2, cs2 = run(model, np.ascontiguousarray(x[idx]), chunks=[80, 80, 80, 54])
+    ys1, cs1 = run(model, x, chunks=[80, 80, 80, 54])
+    assert np.array_equal(ys2, ys1[idx]) and np.array_equal(cs2, cs1[idx])
+    ry, rc = kws_oracle.forward(cfg, sd, x[idx], None)
+    assert max_abs(ys1[idx], ry) <= tol_for(ry) and max_abs(cs1[idx], rc) <= tol_for(rc)
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

@@ -270,6 +270,39 @@ def test_full_batch_streaming_with_long_chunks(name, B):
     assert max_abs(ys1[idx], ry) <= tol_for(ry) and max_abs(cs1[idx], rc) <= tol_for(rc)
 
 
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "ds_tcn_h64", "mdtc_h64", "mdtc_h64_80d", "mdtc_small", "tcn_h64", "gru_2x128",
+                                  "gru_1x128", "ds_tcn_h64_ctc20", "ds_tcn_h256_ctc300", "fsmn_ctc300", "fsmn_small"])
+@pytest.mark.parametrize("precision", ["default", "f32"])
+def test_random_chunkings_cross_the_kernel_families(name, precision):
+    """Seeded fuzz of the dispatcher: a stream cut into random chunk lengths 1 .. 130 -- streaming-step kernels (<= 16 frames), the
+    register-resident context variants (17 .. 112), the LDS-tile kernels and the tiled long-input path (> 112), every hand-over of
+    the carried cache between them, random batch sizes -- equals the numpy oracle's one-shot forward of the whole input
+    (posteriors <= 1e-4, final cache relative) and the HIP one-shot forward (<= 2e-5)."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    model = build(cfg, sd).set_precision(precision)
+    rng = np.random.default_rng(20260925 + len(name))
+    gru = cfg["backbone"]["type"] == "gru"
+    for trial in range(16):
+        B = int(rng.choice([1, 2, 3, 5, 17, 70]))
+        chunks = []
+        while sum(chunks) < 200 and len(chunks) < 12:
+            kind = rng.integers(0, 4)
+            chunks.append(int(rng.integers(1, 17) if kind == 0 else rng.integers(17, 113) if kind in (1, 2) else rng.integers(113, 131)))
+        T = sum(chunks)
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=1000 + trial)
+        h0 = np.zeros((cfg["backbone"]["num_layers"], B, cfg["hidden_dim"]), np.float32) if gru else None
+        ry, rc = kws_oracle.forward(cfg, sd, x, h0)
+        ys, cs = run(model, x, cache=h0, chunks=chunks)
+        y1, c1 = run(model, x, cache=h0)
+        what = (name, precision, trial, B, chunks)
+        assert ys.shape == ry.shape and cs.shape == rc.shape, what
+        assert max_abs(ys, ry) <= tol_for(ry), (what, max_abs(ys, ry))
+        assert max_abs(cs, rc) <= tol_for(rc), (what, max_abs(cs, rc))
+        assert max_abs(ys, y1) <= 2e-5 and max_abs(cs, c1) <= 2e-5 * max(1.0, float(np.abs(c1).max())), what
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

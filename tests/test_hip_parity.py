@@ -303,6 +303,106 @@ def test_random_chunkings_cross_the_kernel_families(name, precision):
         assert max_abs(ys, y1) <= 2e-5 and max_abs(cs, c1) <= 2e-5 * max(1.0, float(np.abs(c1).max())), what
 
 
+def _random_model_config(rng):
+    """A configuration init_model accepts (kws_model.py:97-214), drawn around the thresholds between the specialised kernels and
+    the any-shape path: hidden sizes on and off the built widths, kernel sizes, depths, feature widths, class counts, heads."""
+    kind = str(rng.choice(["ds", "tcn", "mdtc", "gru"]))
+    idim = int(rng.choice([40, 80, 23, 64]))
+    odim = int(rng.choice([1, 2, 3, 12, 20]))
+    cfg = {"input_dim": idim, "output_dim": odim, "preprocessing": {"type": "linear"}}
+    if kind in ("ds", "tcn"):
+        h = int(rng.choice([16, 32, 64, 96, 128, 256, 256, 320] if kind == "ds" else [16, 32, 64, 80, 128]))
+        cfg["hidden_dim"] = h
+        cfg["backbone"] = {"type": "tcn", "ds": kind == "ds", "num_layers": int(rng.integers(1, 8)),
+                           "kernel_size": int(rng.choice([3, 5, 8, 8, 8, 9])), "dropout": 0.1}
+    elif kind == "mdtc":
+        h = int(rng.choice([16, 32, 48, 64, 64, 128, 160]))
+        cfg["hidden_dim"] = h
+        cfg["backbone"] = {"type": "mdtc", "num_stack": int(rng.integers(1, 6)), "stack_size": int(rng.choice([1, 2, 3, 4, 4, 5, 6])),
+                           "kernel_size": int(rng.choice([3, 5, 5, 5, 7])), "hidden_dim": h, "causal": True}
+    else:
+        cfg["hidden_dim"] = int(rng.choice([32, 64, 128, 128, 160]))
+        cfg["backbone"] = {"type": "gru", "num_layers": int(rng.integers(1, 6))}
+    head = str(rng.choice(["linear", "linear", "global", "last"]))
+    if head != "linear":
+        cfg["classifier"] = {"type": head, "dropout": 0.5}
+    if rng.integers(0, 4) == 0:
+        cfg["activation"] = {"type": "identity"}
+    return cfg, head
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_model_shapes_against_the_oracle(seed):
+    """Seeded fuzz of the routing between the specialised kernels and the any-shape path (wekws_hip_create): 12 random
+    configurations per seed, each with random weights (randomised BatchNorm statistics), a random batch and -- per-frame heads --
+    a random cut into two chunks with the carried cache, against the numpy oracle (1e-4 on posteriors / relative on logits and
+    caches), in the default precision and exact f32."""
+    from wekws_amd import pack
+    rng = np.random.default_rng(7000 + seed)
+    for trial in range(12):
+        cfg, head = _random_model_config(rng)
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 500 + 13 * seed + trial)
+        B, T = int(rng.choice([1, 2, 3, 9, 9, 260])), int(rng.integers(1, 140) if rng.integers(0, 5) else rng.integers(140, 400))
+        if B == 260:
+            T = min(T, 120)
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=trial)
+        gru = cfg["backbone"]["type"] == "gru"
+        softmax = head == "linear" and bool(rng.integers(0, 4) == 0)
+        # the incoming state: GRU always has one (kws_model.py:73 needs h0); conv backbones start empty or from a random cache
+        _, c0 = kws_oracle.forward(cfg, sd, x[:, :1], np.zeros((cfg["backbone"]["num_layers"], B, cfg["hidden_dim"]), np.float32) if gru else None)
+        cin = None
+        if gru or rng.integers(0, 2):
+            cin = (0.5 * np.random.default_rng(trial).standard_normal(c0.shape)).astype(np.float32)
+        ry, rc = kws_oracle.forward(cfg, sd, x, cin, softmax=softmax)
+        for precision in ("default", "f32"):
+            model = build(cfg, sd).set_precision(precision)
+            what = (seed, trial, precision, cfg, B, T, cin is not None, softmax)
+            y, c = run(model, x, cache=cin, softmax=softmax)
+            assert y.shape == ry.shape and c.shape == rc.shape, what
+            assert max_abs(y, ry) <= tol_for(ry) and max_abs(c, rc) <= tol_for(rc), (what, max_abs(y, ry), max_abs(c, rc))
+            if head == "linear" and T >= 2:
+                cut = int(rng.integers(1, T))
+                ys, cs = run(model, x, cache=cin, softmax=softmax, chunks=[cut, T - cut])
+                assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (what, cut, max_abs(ys, ry), max_abs(cs, rc))
+
+
+@pytest.mark.parametrize("layers,ksize,T", [(5, 8, 111), (5, 8, 59), (6, 8, 130), (5, 3, 103), (7, 8, 40)])
+def test_ds_tcn_h256_deeper_than_the_recipes(layers, ksize, T):
+    """Found by the fuzz above (round 5): hidden_dim 256 with a FIFTH block (dilation 16, padding 112) runs ds256_w16, whose
+    cache hand-over without an incoming cache wrote one pass of 64 columns -- right for the recipes' paddings (<= 56), columns
+    64 .. 111 of a deeper block's slice were never written.  Posteriors and the whole returned cache against the oracle."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h256"])
+    cfg["backbone"] = dict(cfg["backbone"], num_layers=layers, kernel_size=ksize)
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 77)
+    x = synth.synth_feats(3, T, 40, seed=5)
+    ry, rc = kws_oracle.forward(cfg, sd, x, None)
+    for precision in ("default", "f32"):
+        model = build(cfg, sd).set_precision(precision)
+        y, c = run(model, x)
+        assert max_abs(y, ry) <= tol_for(ry) and max_abs(c, rc) <= tol_for(rc), (precision, max_abs(y, ry), max_abs(c, rc))
+        ys, cs = run(model, x, chunks=[T // 3, T - T // 3])
+        assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (precision, "chunks")
+
+
+@pytest.mark.parametrize("ds", [True, False])
+@pytest.mark.parametrize("hidden", [32, 16])
+def test_narrow_tcn_runs_as_the_64_wide_kernel(ds, hidden):
+    """Found by the fuzz above (round 5): DS-TCN / TCN with hidden_dim 32 were taken for a built width (32 is built for MDTC
+    only) and failed at the first forward with WEKWS_HIP_EUNSUPPORTED; they are zero-padded to 64 like every other width."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64" if ds else "tcn_h64"])
+    cfg["hidden_dim"] = hidden
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 78)
+    x = synth.synth_feats(4, 61, 40, seed=6)
+    ry, rc = kws_oracle.forward(cfg, sd, x, None)
+    for precision in ("default", "f32"):
+        model = build(cfg, sd).set_precision(precision)
+        ys, cs = run(model, x, chunks=[10, 30, 21])
+        assert cs.shape == rc.shape
+        assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (precision, max_abs(ys, ry), max_abs(cs, rc))
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

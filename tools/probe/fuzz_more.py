@@ -1,0 +1,14 @@
+import sys, traceback
+sys.path.insert(0, '.')
+import tests.test_hip_parity as t
+bad = 0
+for seed in range(0, 100):
+    try:
+        t.test_random_model_shapes_against_the_oracle(seed)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL seed", seed, str(e)[:600], flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR seed", seed, repr(e)[:600], flush=True)
+print("model-shape fuzz: seeds 6..79,", bad, "failures")

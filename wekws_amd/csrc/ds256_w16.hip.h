@@ -298,12 +298,11 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
           }
         }
       } else if (A.out_cache) {
-        // lane tl hands over columns 4 tl .. 4 tl + 3 (pad <= 64: one pass) with ONE 16-byte store where the four exist
-        // -- rows of the (B, C, 105) cache are only 4-byte aligned, so through a 4-byte-aligned type -- instead of four
-        // 4-byte stores in four passes
+        // lane tl hands over columns 4 tl .. 4 tl + 3 (+ 64 per pass: one pass for the recipes' four blocks, pad <= 56; a fifth
+        // block has 112 columns) with ONE 16-byte store where the four exist -- rows of the (B, C, 105) cache are only 4-byte
+        // aligned, so through a 4-byte-aligned type -- instead of four 4-byte stores in four passes
         struct __attribute__((packed, aligned(4))) V4 { float v[4]; };
-        const int p0 = 4 * tl;
-        if (p0 < pad) {
+        for (int p0 = 4 * tl; p0 < pad; p0 += 64) {
           float cv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {

@@ -928,11 +928,12 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   blob = balanced.data();
   {
     const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
-    const bool odd_c = C != 32 && C != 64 && C != 128 && C != 256;
+    // built widths: 64 / 128 / 256, and 32 for MDTC (mdtc_small.yaml; no DS-TCN / TCN kernel is built for 32: they run as 64)
+    const bool odd_c = C != 64 && C != 128 && C != 256 && !(C == 32 && d.backbone == WEKWS_HIP_BACKBONE_MDTC);
     if (desc_conv(d) && (odd_c || (ks >= 1 && ks < ks_built))) {
       // any width up to 256 and any kernel size up to the built one (kws_model.py:114,142-157 take any): run as the next
       // built shape, zero-padded -- exact, see pad_conv_shape
-      const int Cp = !odd_c ? C : C < 32 ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
+      const int Cp = !odd_c ? C : (C < 32 && d.backbone == WEKWS_HIP_BACKBONE_MDTC) ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
       if (C > 256) return create_generic(d, orig, n_elems, device, out);                    // wider than any built kernel
       // padding only ever ADDS zero taps: a kernel size above the built one cannot be served (pad_conv_shape would write
       // ks floats into a ks_built-wide slot)

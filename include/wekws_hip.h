@@ -275,7 +275,8 @@ enum wekws_hip_window {
 };
 
 typedef struct wekws_hip_fbank_cfg {
-  int32_t num_bins;     /* 40 (or 80) */
+  int32_t num_bins;     /* 40 (or 80); 1..128, every triangular filter must cover an FFT bin (else EINVAL: the reference's
+                           constructor CHECK-fails, fbank.h:81) */
   int32_t sample_rate;  /* 16000 */
   int32_t frame_length; /* samples, 400; 65..512 (the reference's 128- / 256- / 512-point FFT cases, fbank.h:43; else EUNSUPPORTED) */
   int32_t frame_shift;  /* samples, 160 */

@@ -59,3 +59,22 @@ def ref_fbank(wave, num_bins=40, sample_rate=16000, first_push=0):
     n = _ref.ref_fbank(wave.ctypes.data, wave.size, num_bins, sample_rate, first_push, out.ctypes.data)
     assert n == nf, (n, nf)
     return out
+
+
+def has_empty_filter(num_bins=40, sample_rate=16000, frame_length=400):
+    """Does a triangular filter of this bank cover no FFT bin?  The reference's constructor CHECK-fails then (fbank.h:51-81;
+    same float32 arithmetic as there), and wekws_hip_fbank_create refuses the configuration."""
+    n = 1
+    while n < frame_length:
+        n *= 2
+    f32 = np.float32
+    mel = lambda f: f32(1127.0) * np.log(f32(1.0) + f32(f) / f32(700.0), dtype=np.float32)   # noqa: E731
+    lo, hi = mel(f32(20.0)), mel(f32(sample_rate // 2))
+    delta = f32((hi - lo) / f32(num_bins + 1))
+    width = f32(sample_rate) / f32(n)
+    m = np.array([mel(width * f32(i)) for i in range(n // 2)], np.float32)
+    for b in range(num_bins):
+        left, right = lo + f32(b) * delta, lo + f32(b + 2) * delta
+        if not np.any((m > left) & (m < right)):
+            return True
+    return False

@@ -105,3 +105,45 @@ def test_80_bin_tolerance_end_to_end(error_report):
     error_report["fbank80_end_to_end/features"] = worst_f
     error_report["fbank80_end_to_end/posteriors"] = worst_y
     assert worst_f <= TOL80 and worst_y <= 1e-4, (worst_f, worst_y)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_framings_against_the_c_oracle(seed):
+    """Seeded fuzz of the extractor's configuration space (fbank.h:33-97 takes any bin count / frame length; feature_pipeline.cc
+    any sample count): random sample rates, frame lengths 65 .. 512, shifts, bin counts, windows, batch sizes and lengths around
+    the framing boundaries, float and int16 input, against the plain-C oracle (bit-exact against the compiled reference front-end,
+    tests/test_fbank_oracle.py)."""
+    rng = np.random.default_rng(4200 + seed)
+    for trial in range(10):
+        sr = int(rng.choice([16000, 16000, 8000, 4000]))
+        flen = int(rng.choice([sr // 1000 * 25, int(rng.integers(65, 513))]))
+        shift = int(rng.choice([sr // 1000 * 10, int(rng.integers(1, 400))]))
+        bins = int(rng.choice([40, 80, 23, 64, 128]))
+        window = str(rng.choice(["hamming", "povey"]))
+        B = int(rng.choice([1, 3, 17]))
+        nf = int(rng.integers(0, 40))
+        nsamp = max(0, flen + (nf - 1) * shift + int(rng.integers(0, shift))) if nf else int(rng.integers(0, flen))
+        kind = str(rng.choice(["noise", "sine"]))
+        pcm = synth.synth_pcm(B, max(nsamp, 1), seed=trial, kind=kind)[:, :nsamp]
+        if fbank_oracle.has_empty_filter(bins, sr, flen):   # the reference's constructor CHECK-fails (fbank.h:81): refused, not wrong
+            with pytest.raises(Exception, match="covers no FFT bin"):
+                Fbank(num_bins=bins, sample_rate=sr, frame_length=flen, frame_shift=shift, window=window)
+            continue
+        fb = Fbank(num_bins=bins, sample_rate=sr, frame_length=flen, frame_shift=shift, window=window)
+        what = (seed, trial, sr, flen, shift, bins, window, B, nsamp, kind)
+        got = fb(torch.from_numpy(np.ascontiguousarray(pcm)).cuda()).cpu().numpy()
+        assert got.shape == (B, fbank_oracle.num_frames(nsamp, flen, shift), bins), what
+        tol = TOL if bins <= 40 else TOL80
+        for i in range(B):
+            ref = fbank_oracle.fbank(pcm[i], bins, sr, flen, shift, 0 if window == "hamming" else 1)
+            assert got[i].shape == ref.shape, (what, i)
+            if ref.size:
+                # bins within 60 dB (13.8 in natural-log energy) of the frame's peak: the module's tolerance; below that the
+                # value is the rounding noise of the FFT itself (the reference's float32 sine-table recurrence vs exactly
+                # rounded twiddles, see the module docstring): 20 x
+                err = np.abs(got[i] - ref)
+                near = ref >= ref.max(axis=-1, keepdims=True) - 13.8
+                assert float(err[near].max()) <= tol and float(err.max()) <= 20 * tol, (what, i, float(err[near].max()), float(err.max()))
+        if nsamp:
+            i16 = torch.from_numpy(np.ascontiguousarray(pcm).astype(np.int16)).cuda()
+            assert torch.equal(fb(i16), fb(i16.float())), what

@@ -403,6 +403,40 @@ def test_narrow_tcn_runs_as_the_64_wide_kernel(ds, hidden):
         assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (precision, max_abs(ys, ry), max_abs(cs, rc))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_fsmn_shapes_against_the_oracle(seed):
+    """Seeded fuzz of the FSMN routing (fsmn.py:462-495; the split-fp16 tile kernel, its zero-padded widths and the any-shape
+    path): random affine / linear / projection widths, memory orders, depths, class counts, feature widths, batch sizes and a
+    random cut into chunks with the carried 4-D cache, against the numpy oracle, default precision and exact f32."""
+    from wekws_amd import pack
+    rng = np.random.default_rng(9100 + seed)
+    for trial in range(8):
+        cfg = {"input_dim": int(rng.choice([40, 120, 400, 57])), "output_dim": int(rng.choice([2, 11, 300, 2599])),
+               "hidden_dim": 0, "preprocessing": {"type": "none"},
+               "backbone": {"type": "fsmn", "input_affine_dim": int(rng.choice([32, 72, 140, 200])), "num_layers": int(rng.integers(1, 7)),
+                            "linear_dim": int(rng.choice([64, 100, 250, 300])), "proj_dim": int(rng.choice([24, 40, 128, 160])),
+                            "left_order": int(rng.integers(1, 14)), "right_order": int(rng.integers(1, 4)), "left_stride": 1,
+                            "right_stride": 1, "output_affine_dim": int(rng.choice([40, 56, 140]))},
+               "classifier": {"type": "identity", "dropout": 0.1}, "activation": {"type": "identity"}}
+        cfg["hidden_dim"] = cfg["backbone"]["linear_dim"]
+        sd = synth.synth_state_dict(pack.model_spec(cfg), 900 + 7 * seed + trial)
+        B, T = int(rng.choice([1, 2, 5])), int(rng.integers(1, 120))
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=trial)
+        _, c0 = kws_oracle.forward(cfg, sd, x[:, :1], None)
+        cin = (0.5 * np.random.default_rng(trial).standard_normal(c0.shape)).astype(np.float32) if rng.integers(0, 2) else None
+        ry, rc = kws_oracle.forward(cfg, sd, x, cin)
+        for precision in ("default", "f32"):
+            model = build(cfg, sd).set_precision(precision)
+            what = (seed, trial, precision, cfg, B, T, cin is not None)
+            y, c = run(model, x, cache=cin)
+            assert y.shape == ry.shape and c.shape == rc.shape, what
+            assert max_abs(y, ry) <= tol_for(ry) and max_abs(c, rc) <= tol_for(rc), (what, max_abs(y, ry), max_abs(c, rc))
+            if T >= 2:
+                cut = int(rng.integers(1, T))
+                ys, cs = run(model, x, cache=cin, chunks=[cut, T - cut])
+                assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (what, cut, max_abs(ys, ry), max_abs(cs, rc))
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

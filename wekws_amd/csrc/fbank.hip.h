@@ -58,8 +58,10 @@ struct FbankParams {
 
 // Host: tables for the kernel.  Mel bank follows fbank.h:51-88 in float32 like the reference; the
 // window follows fbank.h:90-96 (double, stored as float); twiddles are exact-rounded from double.
-inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, int frame_shift, int window,
-                               FbankParams* fp, std::vector<float>* out) {
+// Returns -1, or the index of the first mel filter that covers no FFT bin (too many bins for this sample rate / frame length:
+// the reference CHECK-fails in its constructor, fbank.h:81; the caller refuses the configuration).
+inline int fbank_build_tables(int num_bins, int sample_rate, int frame_length, int frame_shift, int window,
+                              FbankParams* fp, std::vector<float>* out) {
   const int N = 512, NB = N / 2;
   std::vector<float>& t = *out;
   t.clear();
@@ -105,7 +107,7 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
         li = i;
       }
     }
-    if (fi < 0) { fi = 0; li = -1; }  // empty filter (reference CHECK-fails; here it yields the floor)
+    if (fi < 0) return b;             // empty filter: fbank.h:81
     first[b] = float(fi * stride);
     size[b] = float(li >= fi ? (li - fi) * stride + 1 : 0);
     start[b] = float(weights.size());
@@ -135,6 +137,7 @@ inline void fbank_build_tables(int num_bins, int sample_rate, int frame_length, 
   fp->slot_bin_off = int(t.size()); t.insert(t.end(), sbin.begin(), sbin.end());
   fp->slot_w_off = int(t.size()); t.insert(t.end(), sw.begin(), sw.end());
   fp->table_floats = int(t.size());
+  return -1;
 }
 
 // The LDS strip of a frame is private to one wave and a wave's LDS operations execute in program order, so

@@ -1699,8 +1699,13 @@ int wekws_hip_fbank_create(const wekws_hip_fbank_cfg* cfg, int device, wekws_hip
   if (!f) return fail(WEKWS_HIP_ENOMEM, "host allocation");
   f->device = device;
   std::vector<float> tables;
-  wekws::fbank_build_tables(cfg->num_bins, cfg->sample_rate, cfg->frame_length, cfg->frame_shift, cfg->window,
-                            &f->fp, &tables);
+  const int empty = wekws::fbank_build_tables(cfg->num_bins, cfg->sample_rate, cfg->frame_length, cfg->frame_shift, cfg->window,
+                                              &f->fp, &tables);
+  if (empty >= 0) {                                           // (the reference's constructor CHECK-fails: fbank.h:81)
+    delete f;
+    return fail(WEKWS_HIP_EINVAL, "fbank: mel filter %d of %d covers no FFT bin (sample_rate %d, frame_length %d): fewer bins", empty,
+                cfg->num_bins, cfg->sample_rate, cfg->frame_length);
+  }
   hipError_t e = hipMalloc(&f->d_tables, tables.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(f->d_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {

@@ -93,3 +93,23 @@ def test_det_through_the_score_text_file():
         fah = max(nfa, 1e-6) / (dur / 3600.0)
         ref_rows.append((float(t), fah, frr))
     assert rows == ref_rows
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_det_shapes(seed):
+    """Seeded fuzz of the two reductions: random batch / length / keyword counts, ragged lengths (some empty), window sizes and
+    threshold steps, bit-exact against the Python oracle."""
+    rng = np.random.default_rng(800 + seed)
+    for _ in range(12):
+        B, T, K = int(rng.integers(1, 50)), int(rng.integers(1, 200)), int(rng.integers(1, 5))
+        kw, ws, step = int(rng.integers(0, K)), int(rng.integers(1, 120)), float(rng.choice([0.01, 0.05, 0.13]))
+        s = np.random.default_rng(int(rng.integers(0, 1000))).random((B, T, K), dtype=np.float32)
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int32)
+        st, lt = torch.from_numpy(s).cuda(), torch.from_numpy(lengths).cuda()
+        mx, am = det.max_pool_scores(st, lt)
+        rmx, ram = det_oracle.max_pool(s, lengths)
+        assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(am.cpu().numpy(), ram), (seed, B, T, K)
+        th = det.det_thresholds(step)
+        al = det.false_alarm_counts(st, kw, th, ws, lt).cpu().numpy()
+        want = np.asarray([[det_oracle.false_alarms(s[b, :lengths[b], kw].tolist(), t, ws) for t in th] for b in range(B)])
+        assert np.array_equal(al, want), (seed, B, T, K, kw, ws, step)

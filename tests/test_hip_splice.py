@@ -64,3 +64,16 @@ def test_fbank80_splice_fsmn_chain():
     assert np.abs(y.cpu().numpy() - ry).max() <= 1e-4 * max(1.0, float(np.abs(ry).max()))
     assert cache.shape == (3, 128, 11, 4)
     assert np.abs(cache.cpu().numpy() - rc).max() <= 1e-4 * max(1.0, float(np.abs(rc).max()))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_splice_shapes(seed):
+    """Seeded fuzz: random batch / length / width / context / skip (init_dataset.py:24-68 takes any), bit-exact against the oracle."""
+    rng = np.random.default_rng(300 + seed)
+    for _ in range(25):
+        B, T, F = int(rng.integers(1, 40)), int(rng.integers(1, 130)), int(rng.choice([1, 3, 23, 40, 79, 80, 120]))
+        left, right, skip = int(rng.integers(0, 6)), int(rng.integers(0, 6)), int(rng.integers(1, 6))
+        x = case_input(B, T, F, seed=int(rng.integers(0, 1000)))
+        y = frontend.splice_skip(torch.from_numpy(x).cuda(), left, right, skip).cpu().numpy()
+        want = splice_oracle.splice_skip(x, left, right, skip)
+        assert y.shape == want.shape and np.array_equal(y, want), (seed, B, T, F, left, right, skip)

@@ -61,3 +61,22 @@ def test_fsmn_logits_to_first_beam_prune():
     for t, kept in enumerate(pruned):
         want = [(float(a), int(b)) for a, b in zip(tv[t].tolist(), ti[t].tolist()) if a > 0.05]
         assert [b for _, b in kept] == [b for _, b in want]
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_topk_shapes(seed):
+    """Seeded fuzz: random row counts, class counts (below, at and far above the wave width), k and logit scales against the
+    oracle: indices exact, probabilities <= 1e-6."""
+    rng = np.random.default_rng(600 + seed)
+    for _ in range(25):
+        rows, K = int(rng.integers(1, 300)), int(rng.choice([1, 2, 3, 12, 63, 64, 65, 300, 2599, 5000]))
+        k, scale = int(rng.integers(1, 9)), float(rng.choice([0.1, 1.0, 8.0, 40.0]))
+        x = case_logits(rows, K, scale, seed=int(rng.integers(0, 1000)))
+        p, i = ctc.softmax_topk(torch.from_numpy(x).cuda(), k)
+        kk = min(k, K)
+        rp, ri = topk_oracle.softmax_topk(x, kk)
+        # (distinct random logits: no ties, so the order is unique; K < k: the library pads with (-1, 0))
+        gi, gp = i.cpu().numpy(), p.cpu().numpy()
+        assert gi.shape == (rows, k) and np.array_equal(gi[:, :kk], ri), (seed, rows, K, k, scale)
+        assert np.abs(gp[:, :kk] - rp).max() <= TOL, (seed, rows, K, k, scale)
+        assert (gi[:, kk:] == -1).all() and (gp[:, kk:] == 0).all(), (seed, rows, K, k, scale)

@@ -437,6 +437,38 @@ def test_random_fsmn_shapes_against_the_oracle(seed):
                 assert max_abs(ys, ry) <= tol_for(ry) and max_abs(cs, rc) <= tol_for(rc), (what, cut, max_abs(ys, ry), max_abs(cs, rc))
 
 
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "ds_tcn_h64", "mdtc_h64", "mdtc_small", "tcn_h64", "gru_2x128", "fsmn_small"])
+def test_pointers_that_are_only_4_byte_aligned(name):
+    """The C ABI takes contiguous float buffers, not 16-byte aligned ones: features and the incoming cache that start 4 / 8 / 12
+    bytes into an allocation (a contiguous view of a larger tensor) give the results of aligned copies -- wide loads, and with
+    them the kernel of the family, are chosen per call from the pointers."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    model = build(cfg, sd)
+    B = 3
+    for T in (10, 80, 130):
+        x = torch.from_numpy(synth.synth_feats(B, T, cfg["input_dim"], seed=T)).cuda()
+        if cfg["backbone"]["type"] == "gru":
+            c0 = (0.3 * torch.randn(cfg["backbone"]["num_layers"], B, cfg["hidden_dim"], generator=torch.Generator().manual_seed(T))).cuda()
+        else:
+            _, c0 = model(x[:, :7])
+        y_ref, c_ref = model(x, c0)
+        for off in (1, 2, 3):
+            xb = torch.empty(x.numel() + 4, device="cuda")
+            xv = xb[off:off + x.numel()].view_as(x)
+            xv.copy_(x)
+            cb = torch.empty(c0.numel() + 4, device="cuda")
+            cv = cb[off:off + c0.numel()].view_as(c0)
+            cv.copy_(c0)
+            assert xv.is_contiguous() and xv.data_ptr() % 16 == 4 * off and cv.data_ptr() % 16 == 4 * off
+            y, c = model(xv, cv)
+            # (another kernel of the family may take the call -- the register-resident ones want 16-byte aligned features --, so
+            #  equal up to the summation order of the head, not bit for bit)
+            ey, ec = float((y - y_ref).abs().max()), float((c - c_ref).abs().max())
+            assert ey <= 2e-5 and ec <= 2e-5 * max(1.0, float(c_ref.abs().max())), (name, T, off, ey, ec)
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

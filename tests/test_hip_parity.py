@@ -328,6 +328,12 @@ def _random_model_config(rng):
         cfg["classifier"] = {"type": head, "dropout": 0.5}
     if rng.integers(0, 4) == 0:
         cfg["activation"] = {"type": "identity"}
+    if rng.integers(0, 3) == 0:                       # GlobalCMVN in front (cmvn.py:45-48), with or without the variance
+        cfg["cmvn"] = {"norm_var": bool(rng.integers(0, 2))}
+        cfg["_cmvn"] = True                          # (statistics come as buffers of the state dict, not from a cmvn_file)
+    if rng.integers(0, 6) == 0:                       # NoSubsampling (subsampling.py:35-36): features ARE the hidden tile
+        cfg["preprocessing"] = {"type": "none"}
+        cfg["input_dim"] = cfg["hidden_dim"]
     return cfg, head
 
 
@@ -345,7 +351,7 @@ def test_random_model_shapes_against_the_oracle(seed):
         B, T = int(rng.choice([1, 2, 3, 9, 9, 260])), int(rng.integers(1, 140) if rng.integers(0, 5) else rng.integers(140, 400))
         if B == 260:
             T = min(T, 120)
-        x = synth.synth_feats(B, T, cfg["input_dim"], seed=trial)
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=trial, cmvn_like="cmvn" in cfg)
         gru = cfg["backbone"]["type"] == "gru"
         softmax = head == "linear" and bool(rng.integers(0, 4) == 0)
         # the incoming state: GRU always has one (kws_model.py:73 needs h0); conv backbones start empty or from a random cache

@@ -1,8 +1,9 @@
+"""Development tool: tests/test_hip_parity.py::test_random_model_shapes_against_the_oracle over many more seeds than the suite runs\n(a few hundred random configurations per minute on the GPU box)."""
 import sys, traceback
 sys.path.insert(0, '.')
 import tests.test_hip_parity as t
 bad = 0
-for seed in range(0, 100):
+for seed in range(0, 60):
     try:
         t.test_random_model_shapes_against_the_oracle(seed)
     except AssertionError as e:
@@ -11,4 +12,4 @@ for seed in range(0, 100):
     except Exception as e:
         bad += 1
         print("ERROR seed", seed, repr(e)[:600], flush=True)
-print("model-shape fuzz: seeds 6..79,", bad, "failures")
+print("model-shape fuzz:", bad, "failures")

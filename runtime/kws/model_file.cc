@@ -558,6 +558,8 @@ void Append(std::vector<float>* blob, const std::vector<float>& v) { blob->inser
 int LowerActivation(const Tracer& tr, const std::string& t, bool linear_head) {
   if (t == "output") return WEKWS_HIP_ACT_IDENTITY;
   const ModelNode* n = tr.OnlyUser(t, {"Sigmoid", "Softmax"});
+  if (n && n->op == "Sigmoid" && tr.OnlyUser(n->out[0], {"Softmax"}))   // (CTC recipes set activation identity: ds_tcn_ctc.yaml:41-42)
+    Unrec("Softmax on top of a Sigmoid (forward_softmax of a sigmoid model) is no recipe of the reference");
   if (!n || n->out[0] != "output") Unrec("the classifier does not end in 'output'");
   if (n->op == "Sigmoid") {
     if (!linear_head) Unrec("Sigmoid after a non-linear head");
@@ -774,12 +776,12 @@ void LowerFsmn(const Tracer& tr, const std::string& start, Linear l1, wekws_hip_
     Conv left, right;
     bool have_left = false, have_right = false, have_keep = false, have_ident = false;
     int64_t lax = 0, la = 0, lz = 0, kax = 0, ka = 0, kz = 0, iax = 0, ia = 0, iz = 0;
-    std::string keep_out, ident_out;
+    std::string keep_out, ident_out, left_in;
     for (const ModelNode* s : tr.Users(u, {"Slice"})) {
       Conv c;
       int64_t ax, a, z;
       if (tr.TakeConv(s->out[0], &c)) {
-        left = c; have_left = true;
+        left = c; have_left = true; left_in = s->out[0];
         tr.SliceRange(*s, &lax, &la, &lz);
       } else if (!tr.Users(s->out[0], {"Slice"}).empty()) {
         if (!tr.TakeConv(tr.Users(s->out[0], {"Slice"})[0]->out[0], &right)) Unrec("FSMN right-context convolution");
@@ -790,6 +792,11 @@ void LowerFsmn(const Tracer& tr, const std::string& start, Linear l1, wekws_hip_
       }
     }
     (void)kz;
+    if (!have_ident && have_left && left.W->dims.size() == 4 && left.W->dims[2] == 1) {
+      // left_order 1: the window of the left taps IS the identity window (fsmn.py:231,235 slice the same range; the exporter
+      // keeps one Slice for both)
+      have_ident = true; iax = lax; ia = la; iz = lz; ident_out = left_in;
+    }
     if (!have_left || !have_right || !have_keep || !have_ident) Unrec("FSMN memory block");
     const ModelTensor& wl = *left.W;
     const ModelTensor& wr = *right.W;
@@ -850,6 +857,8 @@ ModelGraph ParseModelBytes(const std::string& bytes) {
   return ParseOnnx(p, bytes.size());
 }
 
+void CheckMeta(const ModelGraph& g, const wekws_hip_desc& dd);
+
 void LowerGraph(const ModelGraph& g, wekws_hip_desc* d, std::vector<float>* blob) {
   if (g.inputs != std::vector<std::string>({"input", "cache"}) || g.outputs != std::vector<std::string>({"output", "r_cache"}))
     Unrec("graph inputs / outputs are not the exporter's input,cache / output,r_cache");
@@ -875,6 +884,31 @@ void LowerGraph(const ModelGraph& g, wekws_hip_desc* d, std::vector<float>* blob
     }
   }
   Linear first = tr.TakeLinear(t);
+  if (!first.ok) {
+    const ModelNode* tp = tr.OnlyUser(t, {"Transpose"});
+    if (tp && Tracer::AttrInts(*tp, "perm") == std::vector<int64_t>({0, 2, 1})) {
+      // NoSubsampling (subsampling.py:35-36) in front of a (B,C,T) backbone: the features are the hidden tile.  The blob starts
+      // with the identity "Linear" wekws_amd/pack.py writes for it (CMVN folded in), preproc_relu = 0.
+      std::vector<float> rest;
+      d->preproc_relu = 0;
+      LowerConvFamily(tr, t, d, &rest);
+      const int64_t C = d->hdim;
+      if (cmvn && static_cast<int64_t>(mean.size()) != C) Unrec("CMVN width in front of a backbone without a preprocessing Linear");
+      first.ok = first.has_bias = true;
+      first.out_dim = first.in_dim = C;
+      first.W.assign(static_cast<size_t>(C * C), 0.f);
+      for (int64_t c = 0; c < C; ++c) first.W[c * C + c] = 1.f;
+      first.b.assign(static_cast<size_t>(C), 0.f);
+      if (cmvn) {
+        if (norm_var && istd.size() != mean.size()) Unrec("CMVN vector length");
+        FoldCmvn(&first, mean, istd, norm_var);
+      }
+      d->idim = static_cast<int32_t>(C);
+      Append(blob, first.W); Append(blob, first.b); Append(blob, rest);
+      CheckMeta(g, *d);
+      return;
+    }
+  }
   if (!first.ok || !first.has_bias) Unrec("the first layer is not a Linear");
   if (cmvn) {
     if (static_cast<int64_t>(mean.size()) != first.in_dim || (norm_var && istd.size() != mean.size())) Unrec("CMVN vector length");
@@ -891,7 +925,12 @@ void LowerGraph(const ModelGraph& g, wekws_hip_desc* d, std::vector<float>* blob
   } else {
     LowerFsmn(tr, t, first, d, blob);
   }
-  // metadata the reference runtime reads (keyword_spotting.cc:33-40) must agree with the recovered geometry
+  CheckMeta(g, *d);
+}
+
+// metadata the reference runtime reads (keyword_spotting.cc:33-40) must agree with the recovered geometry
+void CheckMeta(const ModelGraph& g, const wekws_hip_desc& dd) {
+  const wekws_hip_desc* d = &dd;
   auto meta = [&](const char* k) { auto it = g.meta.find(k); return it == g.meta.end() ? int64_t(-1) : std::stoll(it->second); };
   int64_t cache_dim = d->hdim, cache_len = 0;
   if (d->backbone == WEKWS_HIP_BACKBONE_FSMN) { cache_dim = d->num_stack; cache_len = d->kernel_size - 1 + d->stack_size; }

@@ -15,7 +15,7 @@ generator issues the same export call on the live reference model.  Two accommod
 Recorded next to the files: a seeded input/cache and the reference PyTorch outputs for them (T differs from the
 export's dummy T to exercise the dynamic axis).
 
-    PYTHONPATH=/root/reference:/root/repo python tests/golden/make_onnx_golden.py
+    PYTHONPATH=/root/reference:/root/repo python tests/golden/make_onnx_golden.py [case names: only those]
 """
 import contextlib
 import io
@@ -48,6 +48,15 @@ CASES = {
     "mdtc_small_global12": dict(cfg=dict(synth.MODEL_CONFIGS["mdtc_small_global12"]), T=50),
     # the exporter sizes the cache with model.hdim (export_onnx.py:55), so FSMN exports need hidden_dim == proj_dim
     "fsmn_small_ctc": dict(cfg=dict(synth.MODEL_CONFIGS["fsmn_small"], hidden_dim=40), T=19, softmax=True),
+    # round 5 (found by tools/probe/fuzz_onnx_reader.py): NoSubsampling in front of a conv backbone -- the features are the
+    # hidden tile, CMVN in front --, and an FSMN with left_order 1 (the exporter keeps ONE Slice for the left taps' window and
+    # the identity window)
+    "ds_tcn_h40_nopre_cmvn": dict(cfg=dict(input_dim=40, output_dim=2, hidden_dim=40, preprocessing=dict(type="none"),
+                                           backbone=dict(type="tcn", ds=True, num_layers=3, kernel_size=8, dropout=0.1),
+                                           _cmvn=True, cmvn=dict(norm_var=True)), T=29),
+    "fsmn_lorder1_ctc": dict(cfg=dict(synth.MODEL_CONFIGS["fsmn_small"], hidden_dim=40,
+                                      backbone=dict(synth.MODEL_CONFIGS["fsmn_small"]["backbone"], left_order=1, right_order=2)),
+                             T=17, softmax=True),
 }
 
 
@@ -69,8 +78,12 @@ def metadata_entry(key, value):
 
 def main():
     os.makedirs(os.path.join(HERE, "onnx"), exist_ok=True)
-    out = {}
+    only = set(sys.argv[1:])                     # names on the command line: (re)make only those, keep the rest of the npz
+    npz = os.path.join(HERE, "onnx_golden.npz")
+    out = dict(np.load(npz)) if only and os.path.exists(npz) else {}
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         cfg = dict(case["cfg"])
         with contextlib.redirect_stdout(io.StringIO()):
             model = init_model(cfg)

@@ -1143,7 +1143,8 @@ def test_concurrent_streams_and_models():
             assert torch.equal(y, serial[i])
 
 
-EXPORTED = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc"]
+EXPORTED = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc", "ds_tcn_h40_nopre_cmvn",
+            "fsmn_lorder1_ctc"]
 
 
 @pytest.mark.gpu

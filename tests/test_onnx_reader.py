@@ -16,7 +16,7 @@ from wekws_amd.utils import onnx_model
 from wekws_amd.utils.onnx_lower import load_model_file, lower
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc"]
+CASES = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc", "ds_tcn_h40_nopre_cmvn", "fsmn_lorder1_ctc"]
 REF_ORT = "/root/reference/runtime/android/app/src/main/assets/kws.ort"
 
 

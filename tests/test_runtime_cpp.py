@@ -41,7 +41,8 @@ def test_builds_and_rejects_bad_usage():
     assert r.returncode != 0 and "cannot read" in r.stderr
 
 
-EXPORTED = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc"]
+EXPORTED = ["ds_tcn_h64_cmvn", "tcn_h32", "mdtc_small", "mdtc_small_global12", "fsmn_small_ctc", "ds_tcn_h40_nopre_cmvn",
+            "fsmn_lorder1_ctc"]
 
 
 def _python_packed(path):

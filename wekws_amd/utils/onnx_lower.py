@@ -256,6 +256,10 @@ def _lower_activation(tr: _Tracer, t: str, cfg: dict) -> bool:
         cfg["activation"] = dict(type="identity")
         return False
     n = tr.only_user(t, "Sigmoid", "Softmax")
+    if n is not None and n.op == "Sigmoid" and tr.only_user(n.outputs[0], "Softmax") is not None:
+        # forward_softmax of a model whose activation is the sigmoid: the exporter takes forward_softmax for CTC recipes
+        # (export_onnx.py:46-48), and those set activation identity (ds_tcn_ctc.yaml:41-42, fsmn_ctc.yaml:55-56)
+        _fail("Softmax on top of a Sigmoid (forward_softmax of a sigmoid model) is no recipe of the reference")
     if n is None or n.outputs[0] != "output":
         _fail("the classifier does not end in 'output'")
     if n.op == "Sigmoid":
@@ -383,7 +387,7 @@ def _lower_fsmn(tr: _Tracer, t: str, cfg: dict, sd: dict) -> bool:
         for s in tr.users(u, "Slice"):
             c = tr.take_conv(s.outputs[0])
             if c is not None:
-                left = (c, tr.slice_range(s))
+                left = (c, tr.slice_range(s), s)
             elif tr.users(s.outputs[0], "Slice"):
                 c = tr.take_conv(tr.users(s.outputs[0], "Slice")[0].outputs[0])
                 if c is None:
@@ -393,6 +397,10 @@ def _lower_fsmn(tr: _Tracer, t: str, cfg: dict, sd: dict) -> bool:
                 keep = (s, tr.slice_range(s))
             else:
                 ident = (s, tr.slice_range(s))
+        if ident is None and left is not None and left[0]["W"].ndim == 4 and left[0]["W"].shape[2] == 1:
+            # left_order 1: the window of the left taps IS the identity window (fsmn.py:231,235 slice the same range; the
+            # exporter keeps one Slice for both)
+            ident = (left[2], left[1])
         if left is None or right is None or keep is None or ident is None:
             _fail("FSMN layer %d: memory block" % layers)
         wl, wr = left[0]["W"], right["W"]
@@ -468,6 +476,14 @@ def _lower(g: Graph):
         cfg["input_dim"] = int(cm[0].size)
     first = tr.take_linear(t)
     if first is None:
+        tp = tr.only_user(t, "Transpose")
+        if tp is not None and list(tp.attrs.get("perm", [])) == [0, 2, 1]:
+            # NoSubsampling (subsampling.py:35-36) in front of a (B,C,T) backbone: the features are the hidden tile
+            cfg["preprocessing"] = dict(type="none")
+            softmax = _lower_conv_family(tr, t, cfg, sd)
+            if cfg.setdefault("input_dim", cfg["hidden_dim"]) != cfg["hidden_dim"]:
+                _fail("CMVN width %d in front of a %d-channel backbone without a preprocessing Linear" % (cfg["input_dim"], cfg["hidden_dim"]))
+            return _finish(g, cfg, sd, softmax)
         _fail("the first layer is not a Linear")
     cfg.setdefault("input_dim", int(first[0].shape[1]))
     after, relu = tr.take_relu(first[2]) if first[1] is not None else (first[2], False)
@@ -479,6 +495,10 @@ def _lower(g: Graph):
     else:
         cfg["preprocessing"] = dict(type="none")
         softmax = _lower_fsmn(tr, t, cfg, sd)
+    return _finish(g, cfg, sd, softmax)
+
+
+def _finish(g: Graph, cfg: dict, sd: dict, softmax: bool):
     want = g.meta.get("cache_len")
     info = dict(softmax=softmax, producer=g.producer, meta=dict(g.meta))
     if want is not None:

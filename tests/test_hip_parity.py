@@ -749,6 +749,26 @@ def test_long_input_tiling_matches_oracle():
         assert max_abs(cache, rc) <= tol_for(rc)
 
 
+@pytest.mark.parametrize("name", ["ds_tcn_h256", "mdtc_h64", "gru_2x128", "fsmn_small", "tcn_h64"])
+def test_two_minutes_of_audio_in_one_call(name):
+    """T = 12,000 frames (two minutes; the reference's forward takes any length): 108 tiles handing the context over / a
+    12,000-step recurrence in one call, against the oracle's one-shot forward, and equal to the same frames streamed in 1,000-frame
+    calls."""
+    from wekws_amd import pack
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 6)
+    model = build(cfg, sd)
+    T = 12000
+    x = synth.synth_feats(1, T, cfg["input_dim"], seed=12)
+    h0 = np.zeros((cfg["backbone"]["num_layers"], 1, cfg["hidden_dim"]), np.float32) if cfg["backbone"]["type"] == "gru" else None
+    y, cache = run(model, x, cache=h0)
+    ry, rc = kws_oracle.forward(cfg, sd, x, h0)
+    assert y.shape == ry.shape and max_abs(y, ry) <= tol_for(ry), max_abs(y, ry)
+    assert max_abs(cache, rc) <= tol_for(rc)
+    ys, cs = run(model, x, cache=h0, chunks=[1000] * 12)
+    assert max_abs(ys, y) <= 2e-5 * max(1.0, float(np.abs(y).max())) and max_abs(cs, cache) <= 2e-5 * max(1.0, float(np.abs(cache).max()))
+
+
 def test_no_cpu_fallback():
     cfg = dict(synth.MODEL_CONFIGS["ds_tcn_h64"])
     m = init_model(cfg)

@@ -128,7 +128,8 @@ def test_model_readers_survive_corrupted_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,chunk", [("ds_tcn_h64", 80), ("mdtc_small", 33), ("ds_tcn_h256", 10), ("gru_2x128", 25)])
+@pytest.mark.parametrize("name,chunk", [("ds_tcn_h64", 80), ("mdtc_small", 33), ("ds_tcn_h256", 10), ("gru_2x128", 25),
+                                        ("ds_tcn_h256", 1), ("mdtc_h64", 200), ("tcn_h64", 113), ("ds_tcn_h256", 80)])
 def test_kws_main_matches_oracle(tmp_path, name, chunk):
     build_runtime()
     cfg = dict(synth.MODEL_CONFIGS[name])

@@ -110,3 +110,37 @@ def build_tiny_ort():
                (9, "ref", lambda: w.refs([T([(0, "ref", S("cache_dim")), (1, "ref", S("4"))])]))])
     root = w.table([(0, "ref", S("1.12.0")), (1, "ref", model)])
     return w.finish(root), vals
+
+
+def random_model_config(rng):
+    """A configuration init_model accepts (kws_model.py:97-214), drawn around the thresholds between the specialised kernels and
+    the any-shape path: hidden sizes on and off the built widths, kernel sizes, depths, feature widths, class counts, heads."""
+    kind = str(rng.choice(["ds", "tcn", "mdtc", "gru"]))
+    idim = int(rng.choice([40, 80, 23, 64]))
+    odim = int(rng.choice([1, 2, 3, 12, 20]))
+    cfg = {"input_dim": idim, "output_dim": odim, "preprocessing": {"type": "linear"}}
+    if kind in ("ds", "tcn"):
+        h = int(rng.choice([16, 32, 64, 96, 128, 256, 256, 320] if kind == "ds" else [16, 32, 64, 80, 128]))
+        cfg["hidden_dim"] = h
+        cfg["backbone"] = {"type": "tcn", "ds": kind == "ds", "num_layers": int(rng.integers(1, 8)),
+                           "kernel_size": int(rng.choice([3, 5, 8, 8, 8, 9])), "dropout": 0.1}
+    elif kind == "mdtc":
+        h = int(rng.choice([16, 32, 48, 64, 64, 128, 160]))
+        cfg["hidden_dim"] = h
+        cfg["backbone"] = {"type": "mdtc", "num_stack": int(rng.integers(1, 6)), "stack_size": int(rng.choice([1, 2, 3, 4, 4, 5, 6])),
+                           "kernel_size": int(rng.choice([3, 5, 5, 5, 7])), "hidden_dim": h, "causal": True}
+    else:
+        cfg["hidden_dim"] = int(rng.choice([32, 64, 128, 128, 160]))
+        cfg["backbone"] = {"type": "gru", "num_layers": int(rng.integers(1, 6))}
+    head = str(rng.choice(["linear", "linear", "global", "last"]))
+    if head != "linear":
+        cfg["classifier"] = {"type": head, "dropout": 0.5}
+    if rng.integers(0, 4) == 0:
+        cfg["activation"] = {"type": "identity"}
+    if rng.integers(0, 3) == 0:                       # GlobalCMVN in front (cmvn.py:45-48), with or without the variance
+        cfg["cmvn"] = {"norm_var": bool(rng.integers(0, 2))}
+        cfg["_cmvn"] = True                          # (statistics come as buffers of the state dict, not from a cmvn_file)
+    if rng.integers(0, 6) == 0:                       # NoSubsampling (subsampling.py:35-36): features ARE the hidden tile
+        cfg["preprocessing"] = {"type": "none"}
+        cfg["input_dim"] = cfg["hidden_dim"]
+    return cfg, head

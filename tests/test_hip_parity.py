@@ -12,7 +12,7 @@ import torch
 from oracle import kws_oracle
 from tests.golden.cases import (GRU_INPUT_CASES, HETERO_CASES, SCALE_CASES, SHAPE_CASES, hetero_case_weights,
                                 scaled_case_weights, shape_case_config)
-from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs
+from tests.helpers import CASES, case_in_cache, case_input, case_weights, max_abs, random_model_config as _random_model_config
 from wekws_amd.model.kws_model import init_model
 from wekws_amd.utils import synth
 
@@ -301,40 +301,6 @@ def test_random_chunkings_cross_the_kernel_families(name, precision):
         assert max_abs(ys, ry) <= tol_for(ry), (what, max_abs(ys, ry))
         assert max_abs(cs, rc) <= tol_for(rc), (what, max_abs(cs, rc))
         assert max_abs(ys, y1) <= 2e-5 and max_abs(cs, c1) <= 2e-5 * max(1.0, float(np.abs(c1).max())), what
-
-
-def _random_model_config(rng):
-    """A configuration init_model accepts (kws_model.py:97-214), drawn around the thresholds between the specialised kernels and
-    the any-shape path: hidden sizes on and off the built widths, kernel sizes, depths, feature widths, class counts, heads."""
-    kind = str(rng.choice(["ds", "tcn", "mdtc", "gru"]))
-    idim = int(rng.choice([40, 80, 23, 64]))
-    odim = int(rng.choice([1, 2, 3, 12, 20]))
-    cfg = {"input_dim": idim, "output_dim": odim, "preprocessing": {"type": "linear"}}
-    if kind in ("ds", "tcn"):
-        h = int(rng.choice([16, 32, 64, 96, 128, 256, 256, 320] if kind == "ds" else [16, 32, 64, 80, 128]))
-        cfg["hidden_dim"] = h
-        cfg["backbone"] = {"type": "tcn", "ds": kind == "ds", "num_layers": int(rng.integers(1, 8)),
-                           "kernel_size": int(rng.choice([3, 5, 8, 8, 8, 9])), "dropout": 0.1}
-    elif kind == "mdtc":
-        h = int(rng.choice([16, 32, 48, 64, 64, 128, 160]))
-        cfg["hidden_dim"] = h
-        cfg["backbone"] = {"type": "mdtc", "num_stack": int(rng.integers(1, 6)), "stack_size": int(rng.choice([1, 2, 3, 4, 4, 5, 6])),
-                           "kernel_size": int(rng.choice([3, 5, 5, 5, 7])), "hidden_dim": h, "causal": True}
-    else:
-        cfg["hidden_dim"] = int(rng.choice([32, 64, 128, 128, 160]))
-        cfg["backbone"] = {"type": "gru", "num_layers": int(rng.integers(1, 6))}
-    head = str(rng.choice(["linear", "linear", "global", "last"]))
-    if head != "linear":
-        cfg["classifier"] = {"type": head, "dropout": 0.5}
-    if rng.integers(0, 4) == 0:
-        cfg["activation"] = {"type": "identity"}
-    if rng.integers(0, 3) == 0:                       # GlobalCMVN in front (cmvn.py:45-48), with or without the variance
-        cfg["cmvn"] = {"norm_var": bool(rng.integers(0, 2))}
-        cfg["_cmvn"] = True                          # (statistics come as buffers of the state dict, not from a cmvn_file)
-    if rng.integers(0, 6) == 0:                       # NoSubsampling (subsampling.py:35-36): features ARE the hidden tile
-        cfg["preprocessing"] = {"type": "none"}
-        cfg["input_dim"] = cfg["hidden_dim"]
-    return cfg, head
 
 
 @pytest.mark.parametrize("seed", range(6))

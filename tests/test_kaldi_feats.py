@@ -183,3 +183,30 @@ def test_training_recipes_audio_to_posteriors(error_report):
     error_report["kaldi/end_to_end/mdtc80_mfcc_posteriors"] = e1
     error_report["kaldi/end_to_end/fsmn_spliced_posteriors"] = e2
     assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
+
+
+def test_oracle_against_the_hf_port_on_random_framings():
+    """Beyond the recorded goldens (16 kHz, 25 / 10 ms, 40 / 80 bins): the float64 restatement against Hugging Face's port of
+    kaldi.fbank computed on the spot -- random sample rates, window lengths, shifts, bin counts, signal lengths."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    rng = np.random.default_rng(5)
+    for trial in range(24):
+        sr = int(rng.choice([16000, 8000]))
+        flen_ms, shift_ms = float(rng.choice([25.0, 20.0, 32.0])), float(rng.choice([10.0, 8.0]))
+        bins = int(rng.choice([23, 40, 64, 80]))
+        n = int(rng.integers(sr // 20, sr * 2))
+        pcm = synth.synth_pcm(1, n, seed=trial, kind=str(rng.choice(["noise", "sine"])))[0]
+        fl, hop = int(sr * flen_ms / 1000), int(sr * shift_ms / 1000)
+        nfft = 1
+        while nfft < fl:
+            nfft *= 2
+        got = kf.fbank(pcm, bins, sr, flen_ms, shift_ms)
+        if n < fl:
+            assert got.shape == (0, bins)
+            continue
+        mel = audio_utils.mel_filter_bank(num_frequency_bins=nfft // 2 + 1, num_mel_filters=bins, min_frequency=20, max_frequency=sr // 2,
+                                          sampling_rate=sr, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+        ref = audio_utils.spectrogram(pcm.astype(np.float64), audio_utils.window_function(fl, "povey", periodic=False), frame_length=fl,
+                                      hop_length=hop, fft_length=nfft, power=2.0, center=False, preemphasis=0.97, mel_filters=mel,
+                                      log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T.astype(np.float32)
+        assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= 2e-5, (sr, flen_ms, shift_ms, bins, n)

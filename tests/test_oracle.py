@@ -183,3 +183,60 @@ def test_oracle_matches_any_shape_golden(case):
         ys, cs = kws_oracle.forward_streaming(cfg, sd, x, [t1, case["T"] - t1], None)
         assert max_abs(ys, g[name + "/y_stream"]) <= Y_TOL * max(1.0, float(np.abs(gy).max()))
         assert max_abs(cs, g[name + "/cache_stream"]) <= Y_TOL * max(1.0, float(np.abs(gc).max()))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_against_the_live_reference_on_random_configurations(seed):
+    """The GPU fuzz tests (tests/test_hip_parity.py::test_random_model_shapes_against_the_oracle) trust the oracle on random
+    configurations no golden covers.  Where the reference tree is present (the build container; not the GPU box) the oracle is run
+    against the LIVE reference model on those very configurations -- random incoming caches, a chunk cut, CMVN, NoSubsampling,
+    forward_softmax.  (tools/probe/fuzz_oracle_vs_reference.py is the same loop over hundreds of seeds: worst 7.2e-7.)"""
+    import contextlib
+    import io
+    import os
+    import sys
+    if not os.path.isdir("/root/reference/wekws"):
+        pytest.skip("reference tree not present (GPU box)")
+    import torch
+    sys.path.insert(0, "/root/reference")
+    try:
+        from wekws.model.cmvn import GlobalCMVN
+        from wekws.model.kws_model import init_model as ref_init_model
+    finally:
+        sys.path.remove("/root/reference")
+    from tests.helpers import random_model_config
+    rng = np.random.default_rng(7000 + seed)
+    for trial in range(12):
+        cfg, head = random_model_config(rng)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ref_init_model({k: v for k, v in cfg.items() if k not in ("_cmvn", "cmvn")})
+        if cfg.get("_cmvn"):
+            model.global_cmvn = GlobalCMVN(torch.zeros(cfg["input_dim"]), torch.ones(cfg["input_dim"]), cfg["cmvn"]["norm_var"])
+        sd = synth.synth_state_dict(synth.module_spec(model), 500 + 13 * seed + trial)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model.eval()
+        B, T = int(rng.choice([1, 2, 3, 9])), int(rng.integers(1, 200))
+        x = synth.synth_feats(B, T, cfg["input_dim"], seed=trial, cmvn_like="cmvn" in cfg)
+        gru = cfg["backbone"]["type"] == "gru"
+        softmax = head == "linear" and bool(rng.integers(0, 4) == 0)
+        fwd = model.forward_softmax if softmax else model.forward
+        with torch.no_grad():
+            h00 = torch.zeros(cfg["backbone"]["num_layers"], B, cfg["hidden_dim"]) if gru else None
+            _, c0 = model(torch.from_numpy(x[:, :1]), h00) if gru else model(torch.from_numpy(x[:, :1]))
+            cin = (0.5 * np.random.default_rng(trial).standard_normal(tuple(c0.shape))).astype(np.float32) \
+                if gru or rng.integers(0, 2) else None
+            args = (torch.from_numpy(cin),) if cin is not None else ()
+            ty, tc = fwd(torch.from_numpy(x), *args)
+        oy, oc = kws_oracle.forward(cfg, sd, x, cin, softmax=softmax)
+        what = (seed, trial, cfg, B, T, softmax)
+        assert oy.shape == tuple(ty.shape) and oc.shape == tuple(tc.shape), what
+        assert max_abs(oy, ty.numpy()) <= 2e-5 * max(1.0, float(ty.abs().max())), what
+        assert max_abs(oc, tc.numpy()) <= 2e-5 * max(1.0, float(tc.abs().max())), what
+        if head == "linear" and T >= 2 and not softmax:
+            cut = int(rng.integers(1, T))
+            with torch.no_grad():
+                y1, c1 = model(torch.from_numpy(x[:, :cut]), *args)
+                y2, c2 = model(torch.from_numpy(x[:, cut:]), c1)
+            oys, ocs = kws_oracle.forward_streaming(cfg, sd, x, [cut, T - cut], cin)
+            assert max_abs(oys, torch.cat([y1, y2], 1).numpy()) <= 2e-5 * max(1.0, float(ty.abs().max())), (what, cut)
+            assert max_abs(ocs, c2.numpy()) <= 2e-5 * max(1.0, float(c2.abs().max())), (what, cut)

@@ -24,7 +24,7 @@ from wekws.model.cmvn import GlobalCMVN  # noqa: E402
 
 from oracle import kws_oracle  # noqa: E402
 from tests.golden.make_onnx_golden import metadata_entry  # noqa: E402
-from tests.test_hip_parity import _random_model_config  # noqa: E402
+from tests.helpers import random_model_config as _random_model_config  # noqa: E402
 from wekws_amd import pack  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 from wekws_amd.utils.onnx_lower import load_model_file  # noqa: E402

@@ -18,7 +18,7 @@ from wekws.model.kws_model import init_model  # noqa: E402  (the reference)
 from wekws.model.cmvn import GlobalCMVN  # noqa: E402
 
 from oracle import kws_oracle  # noqa: E402
-from tests.test_hip_parity import _random_model_config  # noqa: E402
+from tests.helpers import random_model_config as _random_model_config  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20

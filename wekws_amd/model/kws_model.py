@@ -280,7 +280,7 @@ class KWSModel(nn.Module):
             # of that utterance (torch.relu(nan) = nan); the kernels here do NOT: their ReLUs are v_max_f32, which returns the
             # operand that is a number, so such an utterance comes back with finite, meaningless scores (measured:
             # tools/probe/nonfinite.py).  Features made by fbank are finite by construction (floored at FLT_EPSILON before the log,
-            # fbank.h:188-194); a caller that cannot vouch for its inputs sets `model.validate_inputs = True`.
+            # fbank.h:187-189); a caller that cannot vouch for its inputs sets `model.validate_inputs = True`.
             if not bool(torch.isfinite(x).all()) or (isinstance(in_cache, torch.Tensor) and in_cache.numel() > 0
                                                      and not bool(torch.isfinite(in_cache).all())):
                 raise ValueError("non-finite values in x / in_cache")

@@ -21,38 +21,31 @@ the average launch duration the roofline uses (`roofline.kernel_ms`).  `step_ms`
 taken right after the timed region, each the mean of 4 back-to-back steps between two HIP events (an event pair around
 every single launch adds ~7 us to it and to the job).
 
-Rank 0 prints ONE JSON line.  Besides the contract fields:
-  roofline        dominant kernel of `value` (default precision: ds256_g16_kernel, 3 x fp16 MFMA per MAC on block-floating
-                  hi/lo operands, so the peak for ALGORITHMIC flops is 2500 / 3 TF).  `kernel` and `traffic` (HBM bytes per
-                  launch from rocprofv3 PMC passes) are reported only when profiles/pmc_traffic.json was taken with
-                  the very library file this run loads (sha-256 match) on this workload -- else omitted.
-  value_single_output_buffer   the same steps with the result dropped at once: the caching allocator then recycles ONE
-                  110 MB cache buffer whose rewrites hit the 256 MB memory-side cache; `value` keeps the result bound
-                  across the next call (two buffers alternate), as `logits, _ = model(feats)` in score.py:125 does.
-  comm            (N > 1) what the one collective of the job cost: backend, world size as torch.distributed reports it,
-                  bytes and wall time of the weight broadcast; `per_rank_utts_per_s` min / max over the ranks.
-  f32             the same batch with precision F32 (exact-f32 MFMA kernel: each product rounded once, the reference's
-                  own arithmetic), with its own roofline against the 157.3 TF f32 matrix peak.
-  latency_chunk80 the same with 80-frame chunks (the Android caller's size) for DS-TCN h64 (the shipped model's shape), DS-TCN h256
-                  and MDTC h64.
-  latency         streaming, 10-frame chunks with the carried cache (stream_kws_ctc.py:482-514, keyword_spotting.cc:56-95):
-                  us per frame, median / p10 / p90 over 1000 chunks, for GRU 2x128 (BASELINE config 3), DS-TCN h256 and
-                  MDTC h64 at 1 and 256 concurrent streams; `cpu` = the reference's PyTorch CPU operators on the same
-                  chunks (oracle/torch_ref.py), B = 1.
-  rooflines_other ds256_stream_kernel at 4096 streams (HBM-bound by construction: the cache round trip) and fbank_kernel.
-  also / score_only   MDTC h64 on the same batch; the DS-TCN batch with the cache hand-over dropped (score.py:125).
+Rank 0 prints the contract as ONE compact JSON line, LAST on stdout (< 6 KB: the driver keeps an 8 KB tail): the contract
+fields, `config`, `roofline`, `cpu_baseline`, `value_no_preheat`, `step_ms` and a `summary` of the secondary workloads.  Everything
+else -- the verbose records below -- goes to `gpurun_out/bench_extras.json` (`--extras-out`) and to EARLIER stdout lines of
+the form `extras <key> = <json>` (which do not start with '{').
+  roofline        dominant kernel of `value` (default precision: ds256 register-resident kernel, 3 x fp16 MFMA per MAC on
+                  block-floating hi/lo operands, so the peak for ALGORITHMIC flops is 2500 / 3 TF).  `kernel` and `traffic` (HBM
+                  bytes per launch from rocprofv3 PMC passes: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950
+                  correction) are reported only when profiles/pmc_traffic.json was taken with the very library file this run
+                  loads (sha-256 match) on this workload -- else null.
   value_no_preheat   the contract's W + K steps taken FIRST, on the idle GPU, before any preheat (`--preheat 0` gives the same
                   as `value`): both readings of "W warm-up steps" exist in one line.
-  config4_shard / config5   BASELINE.json configs 4 and 5 as ONE GPU sees them: B = 8192 utterances per launch (DS-TCN h256, MDTC
-                  h64; default precision), and the 12-class MDTC + GlobalClassifier with precision "f16" (fp16 operands, ONE
-                  fp16 MFMA per product -- the roofline there is the full 2500 TF) at B = 1024 and 8192, next to the same
-                  model in the default precision.
-  audio_to_posteriors   fbank_kernel + the headline forward back to back on 1024 x 1 s of PCM (the whole device-side pipeline).
-  cpu_baseline    the reference's CPU path (PyTorch CPU operator sequence, oracle/torch_ref.py) on this box's host cores:
-                  B = 1024 batches with all hardware threads, with one core, a short sweep of thread counts, and rows
-                  with one OpenMP thread PINNED per physical core (OMP_PROC_BIND=close, OMP_PLACES=cores, affinity to one
-                  hardware thread per core; separate worker processes, because the binding is read at OpenMP start-up);
-                  `value` is the best of all of them.
+  cpu_baseline    the reference's CPU path (PyTorch CPU operator sequence, oracle/torch_ref.py) on this box's host cores; the
+                  best of: all hardware threads, one core, a thread sweep, one pinned OpenMP thread per physical core, and
+                  P processes x 4 pinned threads (utterances split as over GPU ranks); rows in extras `cpu_baseline_detail`.
+extras (side file):
+  value_single_output_buffer   the same steps with the result dropped at once (one 110 MB cache buffer recycled).
+  f32             the same batch with precision F32 (exact-f32 MFMA kernel), roofline against the 157.3 TF f32 matrix peak.
+  also / score_only / gru / small_recipes   MDTC h64 (BASELINE config 2's model), posteriors only, GRU 2x128, DS-TCN h64, MDTC small.
+  config4_shard / config5   BASELINE.json configs 4 and 5 as ONE GPU sees them: B = 8192 per launch; the 12-class MDTC +
+                  GlobalClassifier with precision "f16" (ONE fp16 MFMA per product; roofline = the full 2500 TF).
+  latency / latency_chunk80   streaming with the carried cache (stream_kws_ctc.py:482-514, keyword_spotting.cc:56-95): us per
+                  frame, median / p10 / p90 over consecutive chunks, at 1 and 256 streams; `cpu` = the CPU port, B = 1.
+  rooflines_other ds256_stream_kernel at 4096 streams (HBM-bound: the cache round trip) and fbank_kernel.
+  audio_to_posteriors   fbank_kernel + the headline forward back to back on 1024 x 1 s of PCM.
+  comm            (N > 1, in the line) backend, world size, bytes and wall time of the ONE weight broadcast; per-rank rates.
 """
 import argparse
 import hashlib
@@ -78,6 +71,7 @@ CACHE_BYTES = {"ds_tcn_h256": 256 * 105 * 4, "mdtc_h64": 64 * 244 * 4, "gru_2x12
 PEAK_F32_TFLOPS = 157.3                            # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_F16_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+MAX_LINE_BYTES = 6000                              # the driver keeps an 8 KB tail of stdout: the contract line must fit in it
 
 
 def pct(ts):
@@ -166,6 +160,37 @@ def attach_profile(roof, model_name, B, precision):
         pass
     roof["traffic"] = None
     roof["traffic_note"] = "no PMC profile of this library build under profiles/ (see tools/pmc.sh)"
+
+
+def compact_roofline(r):
+    """The fields of the contract line (the verbose record, with the notes on how the counters are read, goes to the extras)."""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "kernel_avg_ms_rocprof", "traffic",
+            "traffic_source", "flop_per_launch", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_launch_with_cache_out",
+            "hbm_frac")
+    out = {k: r[k] for k in keep if k in r}
+    out.setdefault("traffic", None)
+    out["peak_note"] = {PEAK_F32_TFLOPS: "f32 MFMA peak", PEAK_F16_TFLOPS: "dense fp16 MFMA peak"}.get(
+        r["peak"], "dense fp16 MFMA peak 2500 TF / 3 products per MAC (hi/lo split operands); algorithmic flops")
+    return out
+
+
+def emit(out, extra, extras_out):
+    """Rank 0's output: the extras as earlier stdout lines that do NOT start with '{' and as a side file; then, LAST, the one
+    compact JSON line of the contract (the driver parses the last line and keeps an 8 KB tail of stdout)."""
+    path = extras_out or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"contract_line": out, "extras": extra}, f, indent=1)
+        out["extras_file"] = os.path.relpath(path, ROOT)
+    except OSError as e:
+        out["extras_file"] = f"not written: {e}"[:120]
+    for k, v in extra.items():
+        print(f"extras {k} = {json.dumps(v)}")
+    line = json.dumps(out)
+    assert len(line) <= MAX_LINE_BYTES, f"contract line grew to {len(line)} bytes (limit {MAX_LINE_BYTES})"
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def secondary(torch, init_model, pack, synth, dev, name, B, T, steps=30, score_only=False, precision="default"):
@@ -394,12 +419,13 @@ def cpu_baseline(cfg, sd, T, idim, model_name="ds_tcn_h256"):
                 reps.append(r["utts_per_s"])
     spread = {"samples": len(reps), "median": round(float(np.median(reps)), 1), "p10": round(float(np.percentile(reps, 10)), 1),
               "p90": round(float(np.percentile(reps, 90)), 1), "min": round(min(reps), 1), "max": round(max(reps), 1)}
-    return {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port", "spread": spread,
-            "sample": f"batches of T={T} utterances through oracle/torch_ref.py -- the reference's PyTorch CPU operator sequence "
-                      f"(F.linear / conv1d / batch_norm, fp32) -- for 3 .. 8 s per row; reported: {how}; host has {ncpu} hardware "
-                      f"threads on {nphys} physical cores (of those this process may use); the port against the real "
-                      "KWSModel.forward on the build box: profiles/r04_cpu_port_vs_reference.json",
-            "rows": rows}
+    compact = {"value": round(value, 1), "unit": "utts/s", "cores": vcores, "kind": "port",
+               "sample": f"{model_name}, batches of T={T} utterances through oracle/torch_ref.py (the reference's PyTorch CPU operator "
+                         f"sequence, fp32), 3-8 s per row, ~25 s in all; best row reported: {how}",
+               "host": f"{ncpu} hardware threads / {nphys} physical cores",
+               "one_core": rows["one_core"]["utts_per_s"],
+               "port_vs_reference": "profiles/r06_cpu_port_vs_reference.json (build box: same outputs, 0.9-1.1x the real KWSModel.forward)"}
+    return compact, {"spread": spread, "rows": rows}
 
 
 def self_launch(args, script=None, need_gpus=True):
@@ -431,7 +457,8 @@ def main():
                          "of work at lower clocks (measured: 0.293 ms per step after 10 steps, 0.244 ms after 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # model,threads,T,seconds: see cpu_pinned_rows
-    ap.add_argument("--no-extras", action="store_true", help="only the contract fields + roofline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (the contract line is the same)")
+    ap.add_argument("--extras-out", default=None, help="where the extras go (default gpurun_out/bench_extras.json)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="PLUMBING TEST ONLY (tests/test_hip_bench.py on a 1-GPU box): all ranks use cuda:0 and talk over gloo, so "
                          "that every multi-rank statement of this file runs on a GPU at least once; the line is marked "
@@ -570,24 +597,21 @@ def main():
             "config": {"workload": f"{args.model} forward, {B} x 1-s utterances per GPU, T=98 frames x {idim}-d fbank in "
                                    f"HBM -> (B,98,{cfg['output_dim']}) posteriors + the streaming cache",
                        "batch_per_gpu": B, "frames": T, "feat_dim": idim, "precision": prec,
-                       "preheat": f"{args.preheat} s ({n_pre} steps) of the same forward before the {args.warmup} warm-up steps "
-                                  "(GPU clock ramp out of idle); then exactly K timed steps",
-                       "input": "every step reads the SAME 16 MB feature batch (it stays in the 256 MB memory-side cache), so "
-                                "`hbm_*` are nominal figures; irrelevant to the bound: the kernel is matrix-pipe-bound "
-                                "(3,346 FLOP per algorithmic byte)",
+                       "preheat_s": args.preheat, "preheat_steps": n_pre,
                        "parallelism": f"utterance-parallel x{world}"},
-            "value_no_preheat": {"value": round(B * world * args.steps / cold_s, 1), "unit": "utts/s",
-                                 "ms_per_step": round(cold_s / args.steps * 1e3, 4),
-                                 "note": f"the same {args.warmup} + {args.steps} steps taken first, on the idle GPU, before the preheat "
-                                         "(wall clock, barriers + synchronize on both sides, MAX over ranks)"},
+            "value_no_preheat": round(B * world * args.steps / cold_s, 1),
+            "ms_per_step_no_preheat": round(cold_s / args.steps * 1e3, 4),
             "step_ms": dict(pct(step_ms), samples=len(step_ms), launches_per_sample=GROUP),
-            "value_single_output_buffer": {
-                "value": round(B * world / float(np.median(step_ms_single)) * 1e3, 1), "unit": "utts/s",
-                "step_ms": pct(step_ms_single),
-                "note": "result dropped at once: ONE 110 MB cache buffer is recycled and its rewrites hit the 256 MB "
-                        "memory-side cache; `value` / `step_ms` keep the result bound across the next call (two buffers "
-                        "alternate), as score.py:125 does"},
         }
+        # everything that is not the contract goes to the side file / earlier stdout lines (see emit())
+        extra = {"lib_sha16": lib_sha16(), "value_single_output_buffer": {
+            "value": round(B * world / float(np.median(step_ms_single)) * 1e3, 1), "unit": "utts/s",
+            "step_ms": pct(step_ms_single),
+            "note": "result dropped at once: ONE 110 MB cache buffer is recycled and its rewrites hit the 256 MB "
+                    "memory-side cache; `value` / `step_ms` keep the result bound across the next call (two buffers "
+                    "alternate), as score.py:125 does"},
+            "value_no_preheat_note": f"the same {args.warmup} + {args.steps} steps taken first, on the idle GPU, before the preheat "
+                                     "(wall clock, barriers + synchronize on both sides, MAX over ranks)"}
         if world > 1:
             out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "collectives_in_timed_region": 0, "broadcast_bytes": bc_bytes,
@@ -596,7 +620,8 @@ def main():
                                    "the forward itself has no collective"}
             out["per_rank_utts_per_s"] = {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1),
                                           "all": [round(r, 1) for r in rank_rates]}
-            out["comm"]["ranks"] = places
+            out["comm"]["ranks"] = [f"r{p['rank']}:{p['device']}@{p['host']}/{p['pid']} {p['cus']}cu" for p in places]
+            extra["ranks"] = places
             if args.share_gpu:
                 out["test_mode"] = "--share-gpu: all ranks on cuda:0 over gloo (plumbing test, NOT a measurement)"
             else:
@@ -605,7 +630,8 @@ def main():
             roof = mfma_roofline(args.model, B, kern_ms, prec)
             roof["kernel_ms_note"] = "HIP events around the K timed steps / K"
             attach_profile(roof, args.model, B, prec)
-            out["roofline"] = roof
+            extra["roofline_verbose"] = roof
+            out["roofline"] = compact_roofline(roof)
         extras = world == 1 and args.model == "ds_tcn_h256" and not args.no_extras
         if extras:
             if prec != "f32":        # the same batch at the reference's own arithmetic
@@ -613,24 +639,24 @@ def main():
                 med = float(np.median(ts))
                 roof32 = mfma_roofline(args.model, B, med, "f32")
                 attach_profile(roof32, args.model, B, "f32")
-                out["f32"] = {"workload": out["config"]["workload"], "precision": "f32", "value": round(B / med * 1e3, 1),
+                extra["f32"] = {"workload": out["config"]["workload"], "precision": "f32", "value": round(B / med * 1e3, 1),
                               "unit": "utts/s", "step_ms": pct(ts), "steps": 30, "roofline": roof32}
             # BASELINE.json configs[1] words the single-GPU case as "MDTC ... batch 1024 x 1 s" while its metric names
             # the DS-TCN: the DS-TCN is `value`; the MDTC 4x4 h64 recipe on the same batch is reported beside it.
-            out["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
-            out["score_only"] = secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", B, T, score_only=True)
+            extra["also"] = secondary(torch, init_model, pack, synth, dev, "mdtc_h64", B, T)
+            extra["score_only"] = secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", B, T, score_only=True)
             # BASELINE config 3's model as a batch (the layer wavefront, gru_pipe.hip.h) and the small recipes (hey_snips
             # ds_tcn.yaml, mdtc_small.yaml: the register-resident kernels of round 4), each with its own roofline
-            out["gru"] = secondary(torch, init_model, pack, synth, dev, "gru_2x128", B, T)
-            out["small_recipes"] = {n: secondary(torch, init_model, pack, synth, dev, n, B, T) for n in ("ds_tcn_h64", "mdtc_small")}
+            extra["gru"] = secondary(torch, init_model, pack, synth, dev, "gru_2x128", B, T)
+            extra["small_recipes"] = {n: secondary(torch, init_model, pack, synth, dev, n, B, T) for n in ("ds_tcn_h64", "mdtc_small")}
             # ---- BASELINE.json configs 4 and 5 as one GPU sees them
-            out["config4_shard"] = {
+            extra["config4_shard"] = {
                 "note": "configs[3] shards B = 8192 over 8 GPUs (1024 per GPU = `value` / `also`); these are 8192 utterances in ONE "
                         "launch on one GPU -- eight resident rounds instead of one, the throughput figure of the kernels",
                 "ds_tcn_h256": secondary(torch, init_model, pack, synth, dev, "ds_tcn_h256", 8192, T, steps=20),
                 "mdtc_h64": secondary(torch, init_model, pack, synth, dev, "mdtc_h64", 8192, T, steps=20),
                 "small_recipes": {n: secondary(torch, init_model, pack, synth, dev, n, 8192, T, steps=20) for n in ("ds_tcn_h64", "mdtc_small")}}
-            out["config5"] = {
+            extra["config5"] = {
                 "note": "configs[4]: 12-class MDTC h64 + GlobalClassifier, fp16 weights + ONE fp16 MFMA per pointwise product "
                         "(precision 'f16': posterior error ~1e-3, stated in tests/test_hip_parity.py::test_precision_f16_mode), "
                         "roofline against the full 2500 TF; the default precision (f16x3, <= 1e-4) beside it",
@@ -642,14 +668,14 @@ def main():
             lat = {"unit": "us per frame (10-frame chunks; median / p10 / p90 over 1000 consecutive chunks, HIP events)"}
             for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
                 lat[name] = {f"B{b}": stream_latency(torch, init_model, pack, synth, dev, name, b) for b in (1, 256)}
-            out["latency"] = lat
+            extra["latency"] = lat
             # ... and with the Android caller's chunk size (80 frames, runtime/android/app/src/main/cpp/wekws.cc:84-97; the
             # shipped model is the DS-TCN h64 shape): chunks with a carried cache run the register-resident kernels'
             # context variants since round 5
             lat80 = {"unit": "us per frame (80-frame chunks with the carried cache; median / p10 / p90 over 300 consecutive chunks)"}
             for name in ("ds_tcn_h64", "ds_tcn_h256", "mdtc_h64"):
                 lat80[name] = {f"B{b}": stream_latency(torch, init_model, pack, synth, dev, name, b, chunk=80, n=300) for b in (1, 256)}
-            out["latency_chunk80"] = lat80
+            extra["latency_chunk80"] = lat80
             # ---- HBM-bound kernels
             other = []
             Bs = 4096
@@ -678,21 +704,35 @@ def main():
                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / (med * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                           "step_ms": pct(ts), "utts_per_s": round(1024 / med * 1e3, 1),
                           "note": "instruction-bound radix-4 FFT + mel slots (~2.6 MFLOP per utterance), not HBM-bound"})
-            out["rooflines_other"] = other
+            extra["rooflines_other"] = other
             # ---- the whole device-side pipeline: PCM in HBM -> log-mel -> posteriors + cache (two launches per step)
             ts = time_steps(torch, lambda: model(fb(pcm)), 50, 10)
             med = float(np.median(ts))
-            out["audio_to_posteriors"] = {"workload": "1024 x 1 s of 16 kHz PCM (f32, in HBM) -> fbank_kernel -> ds_tcn_h256 forward",
+            extra["audio_to_posteriors"] = {"workload": "1024 x 1 s of 16 kHz PCM (f32, in HBM) -> fbank_kernel -> ds_tcn_h256 forward",
                                           "value": round(1024 / med * 1e3, 1), "unit": "utts/s", "step_ms": pct(ts), "steps": 50,
                                           "pcie_note": "with the PCM coming over PCIe Gen5 x16 (~63 GB/s, 64 KB per utterance) the "
                                                        "host link caps the pipeline at ~0.98 M utt/s (f32 PCM; int16: ~1.97 M)"}
+        if extras:                            # a few numbers of the extras in the contract line (the rest: extras_file)
+            lat, l80 = extra["latency"], extra["latency_chunk80"]
+            out["summary"] = {
+                "unit": "utts/s at B=1024 unless said; latency = us per frame, median, streaming with the carried cache",
+                "f32": {"value": extra["f32"]["value"], "frac_of_157.3TF": extra["f32"]["roofline"]["frac"]},
+                "mdtc_h64": {"value": extra["also"]["value"], "frac": extra["also"]["roofline"]["frac"]},
+                "gru_2x128": {"value": extra["gru"]["value"], "frac": extra["gru"]["roofline"]["frac"]},
+                "B8192": {n: extra["config4_shard"][n]["value"] for n in ("ds_tcn_h256", "mdtc_h64")},
+                "config5_f16_B8192": {"value": extra["config5"]["f16_B8192"]["value"],
+                                      "frac_of_2500TF": extra["config5"]["f16_B8192"]["roofline"]["frac"]},
+                "latency_chunk10": {n: {b: lat[n][b]["median"] for b in ("B1", "B256")} for n in ("gru_2x128", "ds_tcn_h256", "mdtc_h64")},
+                "latency_chunk80": {n: {b: l80[n][b]["median"] for b in ("B1", "B256")} for n in ("ds_tcn_h64", "ds_tcn_h256", "mdtc_h64")},
+                "hbm_bound": {o["kernel"]: {"ms": o["step_ms"]["median"], "frac": o["frac"]} for o in extra["rooflines_other"]},
+                "audio_to_posteriors": extra["audio_to_posteriors"]["value"]}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, T, idim, args.model)
+            out["cpu_baseline"], extra["cpu_baseline_detail"] = cpu_baseline(cfg, sd, T, idim, args.model)
             if extras:
                 for name in ("gru_2x128", "ds_tcn_h256", "mdtc_h64"):
                     c2 = dict(synth.MODEL_CONFIGS[name])
-                    out["latency"][name]["cpu"] = cpu_stream_latency(c2, synth.synth_state_dict(pack.model_spec(c2), 1234))
-        print(json.dumps(out))
+                    extra["latency"][name]["cpu"] = cpu_stream_latency(c2, synth.synth_state_dict(pack.model_spec(c2), 1234))
+        emit(out, extra, args.extras_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -87,7 +87,8 @@ enum wekws_hip_precision {
   WEKWS_HIP_PRECISION_DEFAULT = 0, /* library's choice: F16X3 */
   WEKWS_HIP_PRECISION_F32 = 1,     /* exact-f32 matrix instructions: each product rounded once like the reference's fp32
                                       math (conv backbones and GRU: MFMA kernels; FSMN, and every shape without a specialised
-                                      kernel: the any-shape path of csrc/generic.hip.h, v_fma_f32) */
+                                      kernel: the any-shape path of csrc/generic.hip.h -- v_mfma_f32_16x16x4_f32 for the
+                                      matrix products, v_fma_f32 for the depthwise taps and the GRU cell) */
   WEKWS_HIP_PRECISION_F16X3 = 2,   /* operands split into fp16 hi + lo, three fp16 matrix products per term, with BLOCK
                                       FLOATING POINT: every weight matrix and every operand tile carries an exact
                                       power-of-two scale chosen from its magnitude, so the accuracy is fp32-level (~2^-22

@@ -893,6 +893,7 @@ void LowerGraph(const ModelGraph& g, wekws_hip_desc* d, std::vector<float>* blob
       d->preproc_relu = 0;
       LowerConvFamily(tr, t, d, &rest);
       const int64_t C = d->hdim;
+      if (C <= 0 || C > 4096) Unrec("hidden width of a backbone without a preprocessing Linear");   // (C x C floats are allocated below)
       if (cmvn && static_cast<int64_t>(mean.size()) != C) Unrec("CMVN width in front of a backbone without a preprocessing Linear");
       first.ok = first.has_bias = true;
       first.out_dim = first.in_dim = C;

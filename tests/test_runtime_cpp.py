@@ -244,3 +244,31 @@ def test_packed_files_written_under_abi_1_still_load(tmp_path):
     assert r.returncode == 0, r.stderr
     d3, b3 = pack.load_packed(new)
     assert d3["abi_version"] == pack.ABI_VERSION and np.array_equal(b3, blob)
+
+
+STREAM_TEST = os.path.join(ROOT, "runtime", "build", "stream_kws_test")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,chunk", [("ds_tcn_h64", 80), ("mdtc_small", 10), ("gru_2x128", 10)])
+def test_producer_and_consumer_threads_equal_the_offline_run(tmp_path, name, chunk):
+    """wenet::FeaturePipeline is a hand-off between a producer thread (AcceptWaveform) and a consumer thread (Read)
+    (runtime/core/frontend/feature_pipeline.h:48-54; the reference's stream_kws_main.cc:63-93).  Four streams at once, each
+    with its own HIP stream, FeaturePipeline and KeywordSpotting, a producer pushing uneven PCM pieces and a consumer blocking in
+    Read(chunk) -> Forward: every stream prints exactly what the single-threaded offline tool prints."""
+    build_runtime()
+    cfg = dict(synth.MODEL_CONFIGS[name])
+    sd = synth.synth_state_dict(pack.model_spec(cfg), 1234)
+    desc, blob = pack.pack(cfg, sd)
+    model = str(tmp_path / "model.wekwship")
+    pack.save_packed(model, desc, blob)
+    pcm = (synth.synth_pcm(1, 48000, seed=21, kind="noise")[0] * 0.5 + synth.synth_pcm(1, 48000, kind="sine")[0])
+    pcm = np.clip(np.round(pcm), -32768, 32767).astype(np.int16)
+    wav = str(tmp_path / "t.wav")
+    write_wav(wav, pcm)
+    off = subprocess.run([KWS_MAIN, "40", str(chunk), model, wav], capture_output=True, text=True, timeout=120)
+    assert off.returncode == 0, off.stderr
+    thr = subprocess.run([STREAM_TEST, "40", str(chunk), model, wav, "4", "1600", "37", "4001", "160", "799", "12000"],
+                         capture_output=True, text=True, timeout=180)
+    assert thr.returncode == 0, thr.stderr
+    assert thr.stdout == off.stdout and len(off.stdout.splitlines()) == 1 + (48000 - 400) // 160

@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
-"""fbank kernel time for a library variant (WEKWS_DBG_LIB) and its error against the default library's features."""
-import os, sys, json
-import numpy as np, torch
+"""Development tool: fbank_kernel time per 1024 x 1 s (HIP events, many calls)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from wekws_amd import _capi
-if os.environ.get("WEKWS_DBG_LIB"):
-    _capi._LIB_PATH = os.environ["WEKWS_DBG_LIB"]
-from tools.bench_configs import timeit
-from wekws_amd.frontend import Fbank
-from wekws_amd.utils import synth
-fb = Fbank(40)
+from wekws_amd.frontend import Fbank  # noqa: E402
+from wekws_amd.utils import synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
 for B in (1024, 8192):
-    pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=3)).cuda()
-    med, p10, p90 = timeit(lambda: fb(pcm), warm=3, reps=15, group=10)
-    f = fb(pcm); torch.cuda.synchronize()
-    print(json.dumps(dict(lib=os.environ.get("WEKWS_DBG_LIB", "default"), B=B, ms=round(med, 5), checksum=float(f.double().sum()))), flush=True)
+    fb = Fbank(num_bins=40, device=dev)
+    pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=0, kind="noise")).to(dev)
+    for _ in range(200):
+        fb(pcm)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(50):
+            fb(pcm)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / 50 * 1e3)
+    print(os.environ.get("WEKWS_HIP_LIB", "product"), f"B={B}: median {np.median(ts):.1f} us  min {min(ts):.1f}", flush=True)

@@ -33,6 +33,8 @@
 #include <atomic>
 #include <type_traits>
 
+#include "nonfinite.hip.h"
+
 namespace wekws {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -125,7 +127,61 @@ struct CallArgs {
   int32_t T_total;        // frames of the whole call (GLOBAL mean divisor)
   int32_t first_tile, last_tile;
   int32_t head_slices;    // ds256_mm, CTC-sized heads: gridDim.y workgroups per utterance share the head's o-tiles (0/1: off)
+  const NfCtx* nf;        // utterances with a non-finite input are re-computed in exact IEEE f32 (nonfinite.hip.h)
 };
+
+// Utterance b of this call has a NaN / Inf in its features or incoming cache: the reference's arithmetic instead of the kernel's.
+// NOT inlined: one copy per translation unit, called from a cold branch with nothing live (arguments by value, in registers).
+static __device__ __attribute__((noinline, unused)) void nf_repair_conv_call(const NfCtx* nf, const float* x, int64_t xs_b, const float* ic,
+                                                                             float* oc, float* y, int64_t ys_b, float* gsum, int T,
+                                                                             int T_total, int first_tile, int last_tile, int b) {
+  nf_repair_conv(nf, x, xs_b, ic, oc, y, ys_b, gsum, T, T_total, first_tile, last_tile, b);
+}
+__device__ __forceinline__ void nf_repair_call(const CallArgs& A, int b) {
+#ifdef WEKWS_NF_NOCALL                                       // (A/B builds only: the detection without the re-computation)
+  return;
+#endif
+  nf_repair_conv_call(A.nf, A.x, A.xs_b, A.in_cache, A.out_cache, A.y, A.ys_b, A.gsum, A.T, A.T_total, A.first_tile, A.last_tile, b);
+}
+
+// PERSISTENT kernels (a workgroup walks over utterances): an utterance with a non-finite input is noted here and re-computed
+// behind the loop, where nothing is live -- the hot loop gets one scalar compare per utterance.
+struct NfList {
+  int n, flag;
+  int list[30];
+};
+__device__ __forceinline__ void nf_list_init(NfList& L) {
+  if (threadIdx.x == 0) { L.n = 0; L.flag = 0; }
+}
+// Called by ALL threads of the workgroup, which all decided to come here from the same LDS words behind the same barrier; the
+// barrier inside keeps those words until every wave has read them.
+__device__ __forceinline__ void nf_list_note(NfList& L, int b) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (L.n < 30) L.list[L.n] = b;
+    ++L.n;
+    L.flag = 0;
+  }
+}
+// Behind the loop.  `per_wg` utterances per loop step start at b = first, first + stride, ... (first = blockIdx.x * per_wg).
+__device__ inline void nf_list_drain(NfList& L, const CallArgs& A, int idim, int cache_elems, int first, int stride, int per_wg = 1) {
+  __syncthreads();
+  const int nbad = __builtin_amdgcn_readfirstlane(L.n);
+  if (nbad == 0) return;
+  if (nbad <= 30) {
+    for (int i = 0; i < nbad; ++i) nf_repair_call(A, __builtin_amdgcn_readfirstlane(L.list[i]));
+    return;
+  }
+  // more than the list holds: look at every utterance of this workgroup again
+  __shared__ unsigned nf_cell;
+  for (int b0 = first; b0 < A.B; b0 += stride)
+    for (int u = 0; u < per_wg && b0 + u < A.B; ++u) {
+      const int bb = b0 + u;
+      bool bad = nf_scan_rows(A.x + int64_t(bb) * A.xs_b, A.T, idim, idim, &nf_cell);
+      if (!bad && A.in_cache) bad = nf_scan(A.in_cache + int64_t(bb) * cache_elems, cache_elems, &nf_cell);
+      if (bad) nf_repair_call(A, bb);
+    }
+}
 
 template <int KIND, int C, int NT>
 struct Geom {
@@ -352,7 +408,7 @@ __device__ __forceinline__ void conv_stack_head(const StackParams& P, const Call
         const float* w1 = W + P.head_w + j * C;
         float s = W[P.head_b + j];
         for (int c = 0; c < C; ++c) s = fmaf(w1[c], mvec[u * C + c], s);
-        hid[e] = fmaxf(s, 0.f);
+        hid[e] = nf_relu(s);                                 // (a NaN carried in by the running sums of an earlier tile stays one)
       }
       __syncthreads();
       for (int e = tid; e < U * K; e += NTHR) {
@@ -402,6 +458,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_kernel(const StackPara
   f32x4 acc[OW][NT];
   f32x4 zsum[KIND == KIND_MDTC ? OW : 1][KIND == KIND_MDTC ? NT : 1];
   if constexpr (KIND == KIND_MDTC) zero_acc(zsum);
+
+  // ---- a NaN / Inf among the features or the incoming caches of this workgroup's utterances: the reference's IEEE arithmetic
+  //      for all of them (nonfinite.hip.h).  This kernel has no operand maxima to ride on: one pass over its inputs (L2).
+  {
+    __shared__ unsigned nf_cell;
+    bool bad = false;
+    for (int u = 0; u < U && b0 + u < A.B; ++u) {
+      bad = bad || nf_scan_rows(A.x + int64_t(b0 + u) * A.xs_b, T, P.idim, P.idim, &nf_cell);
+      if (!bad && A.in_cache) bad = nf_scan(A.in_cache + int64_t(b0 + u) * C * Pc, int64_t(C) * Pc, &nf_cell);
+    }
+    if (bad) {
+      for (int u = 0; u < U && b0 + u < A.B; ++u) nf_repair_call(A, b0 + u);
+      return;
+    }
+  }
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {

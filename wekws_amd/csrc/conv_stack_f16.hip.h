@@ -137,6 +137,22 @@ __device__ __forceinline__ void amax_publish(AmaxCell* cell, float v) {
 }
 __device__ __forceinline__ float amax_read(const AmaxCell* cell) { return __uint_as_float(cell->v); }
 
+// INPUT maxima (features, incoming cache) are taken on the bit patterns of |v| -- v_and + v_max_u32 instead of v_max_f32 --: for
+// finite values that is the same maximum, and a NaN or an infinity (patterns 0x7f800000 and above) ends up on top instead of being
+// dropped by fmaxf.  A cell at or above 0x7f800000 after the barrier = "this utterance's input holds a non-finite value": the
+// utterance leaves the fast path (nonfinite.hip.h).  The running maximum `m` is a non-negative float used as its bit pattern.
+__device__ __forceinline__ float amax_acc(float m, float v) {
+  return __uint_as_float(max(__float_as_uint(m), __float_as_uint(v) & 0x7fffffffu));
+}
+__device__ __forceinline__ float amax_merge(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+// cells[0] = features, cells[1] = incoming cache (zero when there is none); workgroup-uniform, scalar
+__device__ __forceinline__ bool amax_inputs_bad(const AmaxCell* cells) {
+#ifdef WEKWS_NF_OFF                                          // (A/B builds only: tools/abvar.sh)
+  return false;
+#endif
+  return unsigned(__builtin_amdgcn_readfirstlane(int(max(cells[0].v, cells[1].v)))) >= 0x7f800000u;
+}
+
 // The block table, copied into LDS once: reading a descriptor at a block boundary then costs an LDS round trip instead of
 // a trip to L2 that every wave of the workgroup waits for (a uniform global load is not scalarised here: the kernels
 // also store to global memory).
@@ -160,6 +176,22 @@ __device__ __forceinline__ float amax_span(const float* __restrict__ p, int n, f
     }
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  return m;
+}
+// the same on the bit patterns of |v| (amax_acc): NaN / Inf stay on top (the kernels that look for non-finite inputs themselves)
+template <int NTHR>
+__device__ __forceinline__ float amax_span_bits(const float* __restrict__ p, int n, float m) {
+  constexpr int DEPTH = 8;
+  for (int e0 = threadIdx.x; e0 < n; e0 += NTHR * DEPTH) {
+    float v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+      const int e = e0 + k * NTHR;
+      v[k] = p[e < n ? e : e0];
+    }
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) m = amax_acc(m, v[k]);
   }
   return m;
 }
@@ -251,9 +283,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stack_f16_kernel(const Stack
   __syncthreads();
   for (int u = 0; u < U; ++u) {
     if (b0 + u < A.B) {                                    // workgroup-uniform
-      amax_publish(amax_cells + u * kAmaxCells, amax_span<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      amax_publish(amax_cells + u * kAmaxCells, amax_span_bits<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
       if (A.in_cache)
-        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span_bits<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+    }
+  }
+  __syncthreads();
+  {                                                          // a NaN / Inf feature or cache element among this workgroup's utterances:
+    bool bad = false;                                        // the reference's arithmetic for all of them (nonfinite.hip.h)
+    for (int u = 0; u < U; ++u) bad |= amax_inputs_bad(amax_cells + u * kAmaxCells);
+    if (bad) {
+      for (int u = 0; u < U; ++u)
+        if (b0 + u < A.B) nf_repair_call(A, b0 + u);
+      return;
     }
   }
 

@@ -110,10 +110,20 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
   __syncthreads();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
-      amax_publish(amax_cells + u * kAmaxCells, amax_span<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      amax_publish(amax_cells + u * kAmaxCells, amax_span_bits<kThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
       if (A.in_cache)
-        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span_bits<kThreads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
     }
+  __syncthreads();
+  {                                                          // a NaN / Inf feature or cache element among this workgroup's utterances:
+    bool bad = false;                                        // the reference's arithmetic for all of them (nonfinite.hip.h)
+    for (int u = 0; u < U; ++u) bad |= amax_inputs_bad(amax_cells + u * kAmaxCells);
+    if (bad) {
+      for (int u = 0; u < U; ++u)
+        if (b0 + u < A.B) nf_repair_call(A, b0 + u);
+      return;
+    }
+  }
   // scale of utterance u's h planes while they are the input of block bi (bi = nblocks: the backbone output)
   auto h_scale = [&](int u, int bi, float* inv) __attribute__((always_inline)) -> float {       // u wave-uniform
     return pow2_scale(fmaxf(amax_read(amax_cells + u * kAmaxCells + 2 + bi), amax_read(amax_cells + u * kAmaxCells + 1)), inv);
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(kThreads, 2) void dense_stack_f16_kernel(const Dens
         const float* w1 = W + P.head_w + j * C;
         float s = W[P.head_b + j];
         for (int c = 0; c < C; ++c) s = fmaf(w1[c], mvec[u * C + c], s);
-        hid[e] = fmaxf(s, 0.f);
+        hid[e] = nf_relu(s);                                 // (a NaN carried in by the running sums of an earlier tile stays one)
       }
       __syncthreads();
       for (int e = tid; e < U * K; e += kThreads) {

@@ -321,6 +321,10 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   // ---- block floating point (conv_stack_f16.hip.h): maximum of the feature tile
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
+  // utterances of this workgroup with a NaN / Inf input (nonfinite.hip.h): they leave the fast path and are re-computed behind the
+  // loop, where nothing is live
+  __shared__ NfList nfl;
+  nf_list_init(nfl);
   // depthwise taps + bias of the CURRENT block, [256][12] floats (the 12-float records of BlockDesc::dw_pk): staged for
   // block bi + 1 behind block bi's matrix phase (block 0: during the preprocessing), read back as 16-byte broadcasts
   __shared__ __attribute__((aligned(16))) float taps[C * 12];
@@ -410,6 +414,15 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       }
     }
   };
+  // A NaN / Inf among this utterance's features or incoming cache (cells [0] / [1] at or above 0x7f800000): noted for the tail, the
+  // next utterance's features requested as the classifier would have, on to the next one.  Every wave takes this branch or none
+  // does (they read the same cells behind the same barrier), and the barrier inside keeps the cells until all of them have.
+  auto skip_bad = [&]() __attribute__((always_inline)) {
+    nf_list_note(nfl, b);
+    if constexpr (FAST) {
+      if (b + int(gridDim.x) < A.B) prefetch_x(b + gridDim.x);
+    }
+  };
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   // The features are requested before the barrier: the table's trip to L2 (first utterance), the barrier and the request
   // for block 0's taps (whose address is in the table) all happen while the features are on their way from HBM.
@@ -422,12 +435,12 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   __syncthreads();                                           // table staged, cells zeroed; the utterance before is done with LDS
   stage_taps(blk[0]);
   if constexpr (CTX)     // block floating point: the depthwise rows are bounded through max(tile, incoming cache), like ds256_w16
-    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+    amax_publish(amax_cells + 1, amax_span_bits<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
   if constexpr (FAST) xi = g16_take_x<NT, PB>(xbuf, T, P.idim, nk, tid);
   if (one_trip) {
-    amax_publish(amax_cells, w16_x_amax(xi));
+    amax_publish(amax_cells, w16_x_amax_bits(xi));
   } else {
-    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+    amax_publish(amax_cells, amax_span_bits<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
   }
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
@@ -446,6 +459,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         a[st].l = __builtin_bit_cast(f16x8, q[64]);
       }
       __syncthreads();
+      if (amax_inputs_bad(amax_cells)) { skip_bad(); continue; }
       sx = pow2_scale(amax_read(amax_cells), &cpre);
       w16_store_x<PB, SPLIT>(xi, sx, planes);
       __syncthreads();
@@ -453,7 +467,9 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
       for (int st = 0; st < 2; ++st)                         // (compile-time indices: a runtime-indexed fragment array spills)
         if (st < nk)
           g16_mfma_step<NT, SPLIT>(acc, a[st], planes + st * 2 * PB + frag_off, planes + st * 2 * PB + PB + frag_off);
-    } else
+    } else {
+    __syncthreads();
+    if (amax_inputs_bad(amax_cells)) { skip_bad(); continue; }
     for (int k0 = 0; k0 < nk; k0 += 2) {                     // two K steps staged per pass
       const int steps = min(2, nk - k0);
       __syncthreads();
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
         load_a16<1>(a, ap + (k0 + st) * 128, 0);
         g16_mfma_step<NT, SPLIT>(acc, a[0], planes + st * 2 * PB + frag_off, planes + st * 2 * PB + PB + frag_off);
       }
+    }
     }
     cpre *= P.pre_inv_s;                                     // 1 / (feature scale * weight scale)
     float hmax = 0.f;
@@ -700,6 +717,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g16_kernel(const StackParam
   G16_PH(7);                                                 // [7] classifier
   if constexpr (!FAST) break;                                // (one utterance per workgroup: no loop for the compiler to hoist out of)
   }                                                          // next utterance of this workgroup
+  // ---- utterances with non-finite inputs: the reference's IEEE arithmetic (nonfinite.hip.h).  Cold; nothing is live here.
+  nf_list_drain(nfl, A, P.idim, C * P.cache_len, blockIdx.x, gridDim.x);
   G16_PH_DUMP;                                               // (stamp builds: sums over this workgroup's utterances)
 }
 

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
 
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
   __shared__ __attribute__((aligned(16))) float taps[C * 12];   // taps + bias of the current block ([256][12] records)
+  __shared__ NfList nfl;                                     // utterances with a NaN / Inf feature (nonfinite.hip.h)
+  nf_list_init(nfl);
   {
     const int ntbl = P.nblocks * int(sizeof(BlockDesc) / 4);
     const int t0 = threadIdx.x;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
   {
     const int ng = P.kpre / 16;
     // B items of the features: item (group g, lq, column n) = x[frame(n)][16 g + 4 s + lq], s = 0..3
+    unsigned xbits = 0;                                      // max of the |x| bit patterns: NaN / Inf end up on top
     for (int e = tid; e < ng * 4 * TT; e += kW16Threads) {
       const int n = e % TT, q = e / TT;
       const int f = NT * (n & 15) + (n >> 4);
@@ -146,14 +149,21 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
       v.y = (f < T && k0 + 4 < P.idim) ? xr[4] : 0.f;
       v.z = (f < T && k0 + 8 < P.idim) ? xr[8] : 0.f;
       v.w = (f < T && k0 + 12 < P.idim) ? xr[12] : 0.f;
+      xbits = max(max(xbits, nf_abs_bits(v.x)), max(max(nf_abs_bits(v.y), nf_abs_bits(v.z)), nf_abs_bits(v.w)));
       *reinterpret_cast<float4*>(planes + (q >> 2) * PB + ((q & 3) * TT + n) * 16) = v;
     }
+    if (nf_bad_bits(xbits)) nfl.flag = 1;
     const float4* ap = reinterpret_cast<const float4*>(W + P.pre_a) + size_t(wave) * ng * 64 + lane;
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
     float4 an = ap[0];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(nfl.flag)) {          // a NaN / Inf feature: noted, re-computed behind the loop
+      nf_list_note(nfl, b);
+      if (b + int(gridDim.x) < A.B) prefetch_x(b + gridDim.x);
+      continue;
+    }
     for (int g = 0; g < ng; ++g) {
       const float4 a = an;
       an = ap[min(g + 1, ng - 1) * 64];
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
   }
   G16_PH(7);                                                 // [7] classifier
   }                                                          // next utterance of this workgroup
+  nf_list_drain(nfl, A, P.idim, 0, blockIdx.x, gridDim.x);
   G16_PH_DUMP;
 }
 

@@ -66,9 +66,14 @@ __global__ __launch_bounds__(kW16Threads) void ds256_mm_kernel(const StackParams
   amax_zero<kW16Threads>(amax_cells, kAmaxCells);
   stage_block_table<kW16Threads>(blk, P.blocks, P.nblocks);
   __syncthreads();
-  amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  amax_publish(amax_cells, amax_span_bits<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
   if constexpr (HAS_CACHE)
-    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+    amax_publish(amax_cells + 1, amax_span_bits<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+  __syncthreads();
+  if (amax_inputs_bad(amax_cells)) {                         // a NaN / Inf feature or cache element: the reference's arithmetic
+    if (blockIdx.y == 0) nf_repair_call(A, b);               // (head slices: every slice sees it, one of them re-computes)
+    return;
+  }
   auto h_amax = [&](int bi) __attribute__((always_inline)) -> float {
     return HAS_CACHE ? fmaxf(amax_read(amax_cells + 2 + bi), amax_read(amax_cells + 1)) : amax_read(amax_cells + 2 + bi);
   };

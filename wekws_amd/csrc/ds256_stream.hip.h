@@ -95,8 +95,8 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
 
   if (tid < tbl_n) reinterpret_cast<uint32_t*>(blk)[tid] = tbl_v;
   __syncthreads();
-  if (one_trip) amax_publish(amax_cells, w16_x_amax(xi));
-  else amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+  if (one_trip) amax_publish(amax_cells, w16_x_amax_bits(xi));
+  else amax_publish(amax_cells, amax_span_bits<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
@@ -162,10 +162,14 @@ __global__ __launch_bounds__(kW16Threads) void ds256_stream_kernel(const StackPa
       const f32x4 q = has_cache ? cv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < n4) reinterpret_cast<f32x4*>(cch)[e] = q;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cm = fmaxf(cm, fabsf(q[r]));   // (clamped duplicates past n4 repeat the last item)
-    }
+      for (int r = 0; r < 4; ++r) cm = amax_acc(cm, q[r]);       // (clamped duplicates past n4 repeat the last item; bit-pattern
+    }                                                            //  maximum: a NaN / Inf stays on top, see amax_acc)
     amax_publish(amax_cells + 1, cm);
     __syncthreads();                                         // activations, cache image and both maxima complete
+  }
+  if (amax_inputs_bad(amax_cells)) {                         // a NaN / Inf in the chunk's features or the carried cache: the
+    nf_repair_call(A, b);                                    // reference's arithmetic for this stream (nonfinite.hip.h)
+    return;
   }
 
   // ======================================= residual blocks =======================================

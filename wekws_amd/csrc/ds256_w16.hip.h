@@ -79,6 +79,14 @@ __device__ __forceinline__ float w16_x_amax(const W16XItem& it) {
   for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(it.v[i]));
   return it.ok ? m : 0.f;
 }
+// the same on the bit patterns of |v| (amax_acc): a NaN / Inf among the item's values stays on top -- the kernels that look for
+// non-finite inputs themselves (nonfinite.hip.h) publish this one
+__device__ __forceinline__ float w16_x_amax_bits(const W16XItem& it) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m = amax_acc(m, it.v[i]);
+  return it.ok ? m : 0.f;
+}
 // scale, split and store the item at slab + dst (hi) / + lo_off (lo)
 template <bool SPLIT>
 __device__ __forceinline__ void w16_put_x(const W16XItem& it, float sx, char* slab, int lo_off) {
@@ -157,12 +165,17 @@ __global__ __launch_bounds__(kW16Threads) void ds256_w16_kernel(const StackParam
   W16XItem xi;
   if (one_trip) {
     xi = w16_load_x<TT, PB>(A.x + int64_t(b) * A.xs_b, T, P.idim, nk);
-    amax_publish(amax_cells, w16_x_amax(xi));
+    amax_publish(amax_cells, w16_x_amax_bits(xi));
   } else {
-    amax_publish(amax_cells, amax_span<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
+    amax_publish(amax_cells, amax_span_bits<kW16Threads>(A.x + int64_t(b) * A.xs_b, T * P.idim, 0.f));
   }
   if constexpr (HAS_CACHE)
-    amax_publish(amax_cells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+    amax_publish(amax_cells + 1, amax_span_bits<kW16Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+  __syncthreads();
+  if (amax_inputs_bad(amax_cells)) {                         // a NaN / Inf feature or cache element: the reference's arithmetic
+    nf_repair_call(A, b);
+    return;
+  }
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {

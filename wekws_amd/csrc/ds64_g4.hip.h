@@ -79,13 +79,13 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
     const bool has = e < nitems;
     xi[i].dst = has ? ((st & 1) * 4 + oct) * TT * 16 + n * 16 : -1;
     w16_fetch_x(xi[i], A.x + int64_t(b) * A.xs_b + int64_t(f) * P.idim + kf, A.x, has && f >= 0 && f < T && kf < P.idim);
-    xmax = fmaxf(xmax, w16_x_amax(xi[i]));
+    xmax = amax_merge(xmax, w16_x_amax_bits(xi[i]));          // (bit patterns: a NaN / Inf stays on top)
   }
   __syncthreads();                                           // cells zeroed, table staged
   stage_taps(0, lane);
   amax_publish(amax_cells, xmax);
   if constexpr (CTX)     // the depthwise rows are bounded through max(tile, incoming cache), like conv_stack_f16.hip.h
-    amax_publish(amax_cells + 1, amax_span<kG4Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+    amax_publish(amax_cells + 1, amax_span_bits<kG4Threads>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
@@ -293,6 +293,16 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
       if (P.sigmoid) v = sigmoidf_(v);
       A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
     }
+  }
+  // A NaN / Inf feature or cache element (cells [0] / [1], untouched since the top, at or above 0x7f800000): what the kernel
+  // computed for this utterance is garbage (and touched nothing else); the utterance is re-computed with the reference's arithmetic
+  // HERE, where nothing is live.  (Measured, round 6: a detection branch with an early exit near the top of this kernel moved its
+  // register allocation and brought back the rare wrong posteriors of round 4 -- several workgroups per CU, ~2 % of the utterances
+  // of a large batch, tools/probe/d64_diag.py -- although no spill and no instruction of the fast path was involved that could be
+  // named; with the branch at the very end the fast path's code is the same as without it, and so are its results.)
+  if (amax_inputs_bad(amax_cells)) {                         // (workgroup-uniform, scalar)
+    __syncthreads();
+    nf_repair_call(A, blockIdx.x);
   }
 }
 

@@ -37,7 +37,10 @@ namespace wekws {
 
 constexpr int kFbankMaxBins = 128;
 constexpr int kFbankMaxFft = 512;   // frames of up to 512 samples; the 512-point transform serves the reference's 128 / 256 / 512-point cases
-constexpr int kFbankWaves = 4;      // frames in flight per workgroup
+#ifndef WEKWS_FBANK_WAVES
+#define WEKWS_FBANK_WAVES 4
+#endif
+constexpr int kFbankWaves = WEKWS_FBANK_WAVES;      // waves per workgroup (each with kFbankFW frames in flight)
 
 struct FbankParams {
   const float* tables;  // device: [tw256: 256 x (cos,sin)] [tw512: 256 x (cos,sin)] [window: 512] [mel...]

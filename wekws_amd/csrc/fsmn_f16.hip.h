@@ -94,7 +94,12 @@ struct FsmnArgs {
   int64_t ys_b;
   int32_t B, T;           // T: valid frames in this tile (1..16*NT)
   int32_t head_slices;    // >= 1: gridDim.y workgroups per tile share the o-tiles of out_linear2 (small calls, below)
+  const NfCtx* nf;        // utterances with a non-finite input are re-computed in exact IEEE f32 (nonfinite.hip.h)
 };
+static __device__ __attribute__((noinline, unused)) void nf_repair_fsmn_call(const NfCtx* nf, const float* x, int64_t xs_b, const float* ic,
+                                                                             float* oc, float* y, int64_t ys_b, int T, int b) {
+  nf_repair_fsmn(nf, x, xs_b, ic, oc, y, ys_b, T, b);
+}
 
 // LDS plan for a tile of TT frames = U utterances x TT / U frames (bytes); shared by host (capacity check) and device
 struct FsmnLds {
@@ -229,12 +234,23 @@ __global__ __launch_bounds__(kFsmnThreads) void fsmn_f16_kernel(const FsmnParams
   __syncthreads();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
-      amax_publish(cells + u * kFsmnCells, amax_span<kFsmnThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+      amax_publish(cells + u * kFsmnCells, amax_span_bits<kFsmnThreads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
       if (A.in_cache)
         amax_publish(cells + u * kFsmnCells + 1,
-                     amax_span<kFsmnThreads>(A.in_cache + int64_t(b0 + u) * P.proj * P.P * P.nlayers, P.proj * P.P * P.nlayers, 0.f));
+                     amax_span_bits<kFsmnThreads>(A.in_cache + int64_t(b0 + u) * P.proj * P.P * P.nlayers, P.proj * P.P * P.nlayers, 0.f));
     }
   __syncthreads();                                           // the staging below scales x with its maximum
+  {                                                          // a NaN / Inf feature or cache element among this workgroup's utterances:
+    bool bad = false;                                        // the reference's arithmetic for all of them (nonfinite.hip.h)
+    for (int u = 0; u < U; ++u)
+      bad |= unsigned(__builtin_amdgcn_readfirstlane(int(max(cells[u * kFsmnCells].v, cells[u * kFsmnCells + 1].v)))) >= 0x7f800000u;
+    if (bad) {
+      if (blockIdx.y == 0)                                   // (head slices: every slice sees it, one of them re-computes)
+        for (int u = 0; u < U; ++u)
+          if (b0 + u < A.B) nf_repair_fsmn_call(A.nf, A.x, A.xs_b, A.in_cache, A.out_cache, A.y, A.ys_b, T, b0 + u);
+      return;
+    }
+  }
   float cin[U], sout[U], sinv[U], mtrk[U];
   float bnd[U], inv_cur[U];                                  // bound (or exact maximum) and 1 / scale of the planes being read
   // a dense layer reading those planes: cin = 1 / (their scale * the matrix scale); its output planes get the scale

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(const GenGemm g) {
       if (!(g.flags & GEN_PARTIAL)) {
         if (g.bias) v += g.bias[n];
         if ((g.flags & GEN_RES_BEFORE) && rrow) v += rrow[n];
-        if (g.flags & GEN_RELU) v = fmaxf(v, 0.f);
+        if (g.flags & GEN_RELU) v = nf_relu(v);                // (torch.relu: a NaN stays a NaN -- this path is plain IEEE f32)
         if ((g.flags & GEN_RES_AFTER) && rrow) v += rrow[n];
         if (g.flags & GEN_SIGMOID) v = sigmoidf_(v);
       }
@@ -162,7 +162,7 @@ __global__ void gen_dw_kernel(float* __restrict__ out, const float* __restrict__
     const float* wp = w + int64_t(c) * ks;
     float acc = bias ? bias[c] : 0.f;
     for (int j = 0; j < ks; ++j) acc = fmaf(wp[j], up[int64_t(j) * dil * C], acc);
-    out[i] = relu ? fmaxf(acc, 0.f) : acc;
+    out[i] = relu ? nf_relu(acc) : acc;
   }
 }
 
@@ -207,7 +207,21 @@ __global__ void gen_gru_cell_kernel(const float* __restrict__ gi, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// y[r][c] = [ReLU](w[c * ld + c] x[r][c] + bias[c]): the diagonal preprocessing of NoSubsampling (subsampling.py:35-36: the features
+// ARE the hidden tile; the diagonal carries a folded CMVN).  Channel by channel like the reference -- through the matrix product
+// an Inf in one channel would meet the zeros of every other row (0 * Inf = NaN).
+__global__ void gen_diag_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                int64_t rows, int C, int ld, int relu) {
+  const int64_t n = rows * C;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int c = int(i % C);
+    const float v = fmaf(w[int64_t(c) * ld + c], x[i], bias[c]);
+    y[i] = relu ? nf_relu(v) : v;
+  }
+}
+
 struct GenericModel {
+  bool pre_diag = false;         // the preprocessing matrix is diagonal (NoSubsampling)
   wekws_hip_desc d{};
   const float* w = nullptr;      // the packer's blob on the device
   int cache_len = 0;             // conv: sum of paddings; fsmn: left_order - 1 + right_order; gru: 0
@@ -268,7 +282,12 @@ inline void gen_linear(hipStream_t st, const float* X, const float* W, const flo
 // The forward of wekws_hip_forward for a GenericModel (everything but the trailing softmax, which the caller applies).
 // ws: gen_workspace_bytes(m, B, T) bytes of scratch.  Returns 0, or -3 if a launch failed.
 inline int generic_forward(const GenericModel& m, const float* x, int B, int T, const float* in_cache, float* y, float* out_cache,
-                           char* ws, hipStream_t st) {
+                           char* ws, hipStream_t st, hipError_t* launch_error = nullptr) {
+  auto done = [&]() {                                       // (hipGetLastError resets the sticky error: read once, hand it back)
+    const hipError_t e = hipGetLastError();
+    if (launch_error) *launch_error = e;
+    return e == hipSuccess ? 0 : -3;
+  };
   const wekws_hip_desc& d = m.d;
   const int64_t rows = int64_t(B) * T;
   const int C = d.hdim, W = gen_width(d);
@@ -309,11 +328,15 @@ inline int generic_forward(const GenericModel& m, const float* x, int B, int T, 
     gen_linear(st, h, p, p + size_t(A1) * C, nullptr, o, rows, C, A1, 0);                             // out_linear1
     p += size_t(A1) * C + A1;
     gen_linear(st, o, p, p + size_t(d.odim) * A1, nullptr, y, rows, A1, d.odim, act);                 // out_linear2
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return done();
   }
 
   // ---- preprocessing: LinearSubsampling1 (subsampling.py:53-57) or the CMVN-only diagonal (preproc_relu = 0)
-  gen_linear(st, x, p, p + size_t(C) * d.idim, nullptr, h, rows, d.idim, C, d.preproc_relu ? GEN_RELU : 0);
+  if (m.pre_diag)
+    hipLaunchKernelGGL(gen_diag_kernel, dim3(gen_grid(rows * C)), dim3(256), 0, st, h, x, p, p + size_t(C) * d.idim, rows, C, d.idim,
+                       d.preproc_relu);
+  else
+    gen_linear(st, x, p, p + size_t(C) * d.idim, nullptr, h, rows, d.idim, C, d.preproc_relu ? GEN_RELU : 0);
   p += size_t(C) * d.idim + C;
 
   if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
@@ -396,7 +419,7 @@ inline int generic_forward(const GenericModel& m, const float* x, int B, int T, 
     p += size_t(HH) * C + HH;
     gen_linear(st, hid, p, p + size_t(d.odim) * HH, nullptr, y, B, HH, d.odim, act);
   }
-  return hipGetLastError() == hipSuccess ? 0 : -3;
+  return done();
 }
 
 }  // namespace wekws

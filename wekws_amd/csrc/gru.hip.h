@@ -245,4 +245,16 @@ inline int launch_gru(const GruParams& P, const float* x, int B, int T, const fl
   return big ? launch_gru_nn<4>(P, x, B, T, h0, y, hn, stream) : launch_gru_nn<1>(P, x, B, T, h0, y, hn, stream);
 }
 
+// GRU: one workgroup per stream, behind the GRU kernels of the call (their loads sanitise, see nf_clean): a stream whose
+// features or incoming states hold a NaN / Inf is re-computed; the others cost one pass over their features.
+__global__ __launch_bounds__(256) void gru_nf_fix_kernel(const NfCtx* R, const float* x, int B, int T, const float* h0, float* hn,
+                                                                float* y) {
+  __shared__ unsigned cell;
+  const int b = blockIdx.x;
+  const int idim = R->d.idim, H = R->d.hdim, L = R->d.num_layers;
+  bool bad = nf_scan(x + int64_t(b) * T * idim, int64_t(T) * idim, &cell);
+  if (!bad && h0) bad = nf_scan_rows(h0 + int64_t(b) * H, L, H, int64_t(B) * H, &cell);
+  if (bad) nf_repair_gru(R, x, int64_t(T) * idim, h0, hn, y, int64_t(T) * R->d.odim, B, T, b);
+}
+
 }  // namespace wekws

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
     if (h0)
       for (int e = tid; e < MB * H; e += kThreads) {
         const int sidx = b0 + e / H;
-        if (sidx < bend) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
+        if (sidx < bend) m = fmaxf(m, fabsf(nf_clean(h0[(int64_t(l) * B + sidx) * H + (e % H)])));
       }
     amax_publish(gru_cells + l, m);
     __syncthreads();
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       for (int nn = 0; nn < NN; ++nn) {
         const int f = (nn * kThreads + tid) * 4, sidx = b0 + f / H;
         h0v[l][nn] = (h0vec && l < P.nlayers && sidx < bend)
-                         ? *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + sidx) * H + (f % H)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                         ? nf_clean_vec<f32x4, 4>(*reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + sidx) * H + (f % H)))
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
                 if (k0 + j < idim) v[j] = src[j];
             }
           }
-          xr[ks][nn] = v;
+          xr[ks][nn] = nf_clean_vec<gru_f32x8, 8>(v);        // (a NaN / Inf feature enters as 0: nonfinite.hip.h)
         }
     };
     if (packed) {
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
                 if (k0 + j < idim) v[j] = src[j];
             }
           }
+          v = nf_clean_vec<gru_f32x8, 8>(v);                  // (a NaN / Inf feature enters as 0: nonfinite.hip.h)
           xr[ks] = v;
 #pragma unroll
           for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fabsf(v[j]));
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void gru_f16_kernel(const GruF16Params Q,
       for (int nn = 0; nn < NN; ++nn) {
         const int s = b0 + nn * 16 + l15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (h0 && s < bend) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
+        if (h0 && s < bend) v = nf_clean_vec<f32x4, 4>(*reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0));
         hreg[nn] = v;
         f16x4 vh, vl;
         gru_split4(v * shl, vh, vl);

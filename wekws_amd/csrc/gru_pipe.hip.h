@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     if (h0)
       for (int e = tid; e < MB * H; e += kThreads) {
         const int sidx = b0 + e / H;
-        if (sidx < bend) m = fmaxf(m, fabsf(h0[(int64_t(l) * B + sidx) * H + (e % H)]));
+        if (sidx < bend) m = fmaxf(m, fabsf(nf_clean(h0[(int64_t(l) * B + sidx) * H + (e % H)])));
       }
     amax_publish(&gp_cell, m);
     __syncthreads();
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             if (k0 + j < idim) v[j] = src[j];
         }
       }
-      return v;
+      return nf_clean_vec<gru_f32x8, 8>(v);                  // (a NaN / Inf feature enters as 0: nonfinite.hip.h)
     };
     // A chunk of a few streams is served in ONE time-packed pass, and the whole launch waits for it: its features are the
     // first thing this stage asks for -- in front of 100 KB of weight fragments and of the handshake (measured at B = 1,
@@ -644,8 +644,9 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
             const int t = t0c + pdt;
             if (t < T) {
               const gru_f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              const gru_f32x8 k0 = xv0 ? gru_f32x8{xq1[0][0], xq1[0][1], xq1[0][2], xq1[0][3], xq1[1][0], xq1[1][1], xq1[1][2], xq1[1][3]} : z8;
-              const gru_f32x8 k1 = xv1 ? gru_f32x8{xq1[2][0], xq1[2][1], xq1[2][2], xq1[2][3], xq1[3][0], xq1[3][1], xq1[3][2], xq1[3][3]} : z8;
+              // (a NaN / Inf feature enters as 0: nonfinite.hip.h)
+              const gru_f32x8 k0 = xv0 ? nf_clean_vec<gru_f32x8, 8>(gru_f32x8{xq1[0][0], xq1[0][1], xq1[0][2], xq1[0][3], xq1[1][0], xq1[1][1], xq1[1][2], xq1[1][3]}) : z8;
+              const gru_f32x8 k1 = xv1 ? nf_clean_vec<gru_f32x8, 8>(gru_f32x8{xq1[2][0], xq1[2][1], xq1[2][2], xq1[2][3], xq1[3][0], xq1[3][1], xq1[3][2], xq1[3][3]}) : z8;
               float ax = 0.f;                                     // max|x[t]| over the tile
 #pragma unroll
               for (int j = 0; j < 8; ++j) ax = fmaxf(ax, fmaxf(fabsf(k0[j]), fabsf(k1[j])));
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
       {
         const int s = b0 + l15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (h0 && s < bend) v = *reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0);
+        if (h0 && s < bend) v = nf_clean_vec<f32x4, 4>(*reinterpret_cast<const f32x4*>(h0 + (int64_t(l) * B + s) * H + u0));
         hreg = v;
         f16x4 vh, vl;
         gru_split4(v * shl, vh, vl);

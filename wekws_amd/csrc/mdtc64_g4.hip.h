@@ -192,13 +192,13 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
     const bool has = e < nitems;
     xi[i].dst = has ? ((st % KS) * 4 + oct) * TT * 16 + n * 16 : -1;   // (KS K steps fit the planes: later ones are staged where earlier ones were)
     w16_fetch_x(xi[i], A.x + int64_t(b) * A.xs_b + int64_t(f) * P.idim + kf, A.x, has && f >= 0 && f < T && kf < P.idim);
-    xmax = fmaxf(xmax, w16_x_amax(xi[i]));
+    xmax = amax_merge(xmax, w16_x_amax_bits(xi[i]));          // (bit patterns: a NaN / Inf stays on top)
   }
   __syncthreads();                                           // cells zeroed, table staged
   stage_taps(0, lane);
   amax_publish(amax_cells, xmax);
   if constexpr (CTX)     // the depthwise rows are bounded through max(tile, incoming cache), like mdtc64_w16
-    amax_publish(amax_cells + 1, amax_span<NTHR>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
+    amax_publish(amax_cells + 1, amax_span_bits<NTHR>(A.in_cache + int64_t(b) * C * Pc, C * Pc, 0.f));
 
   // ============================ preprocessing: h0 = [ReLU](x Wpre^T + b) ============================
   {
@@ -516,6 +516,13 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
         A.y[int64_t(b) * A.ys_b + int64_t(t) * K + k] = v;
       }
     }
+  }
+  // A NaN / Inf feature or cache element (cells [0] / [1], untouched since the top, at or above 0x7f800000): the utterance is
+  // re-computed with the reference's arithmetic HERE, where nothing is live (ds64_g4.hip.h says why not earlier).  Pooled heads
+  // only run on first tiles (no incoming cache), so the running sums the kernel wrote are simply written again.
+  if (amax_inputs_bad(amax_cells)) {                         // (workgroup-uniform, scalar)
+    __syncthreads();
+    nf_repair_call(A, blockIdx.x);
   }
 }
 

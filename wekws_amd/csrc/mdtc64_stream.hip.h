@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_stream_kernel(const StackP
       const int e = e0 + k * kW16Threads;
       if (e < tot) {
         reinterpret_cast<f32x4*>(cch)[e] = q[k];
-        const float qm = fmaxf(fmaxf(fabsf(q[k][0]), fabsf(q[k][1])), fmaxf(fabsf(q[k][2]), fabsf(q[k][3])));
-        if (e < n4) cm[0] = fmaxf(cm[0], qm); else cm[1] = fmaxf(cm[1], qm);
+        const float qm = amax_acc(amax_acc(amax_acc(amax_acc(0.f, q[k][0]), q[k][1]), q[k][2]), q[k][3]);   // (bit patterns: NaN / Inf on top)
+        if (e < n4) cm[0] = amax_merge(cm[0], qm); else cm[1] = amax_merge(cm[1], qm);
       }
     }
   };
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_stream_kernel(const StackP
     if (P.nblocks > 0) {
       if (mx_wave) bnext = load_bias(0); else tnext = load_taps(0);
     }
-    if (xi.dst >= 0) amax_publish(amax_cells + (tid >= nk * 4 * TT ? kAmaxCells : 0), w16_x_amax(xi));
+    if (xi.dst >= 0) amax_publish(amax_cells + (tid >= nk * 4 * TT ? kAmaxCells : 0), w16_x_amax_bits(xi));
   }
   cache_commit(tid);
   for (int e0 = tid + kInFlight * kW16Threads; e0 < tot; e0 += kInFlight * kW16Threads) {   // (longer caches)
@@ -162,6 +162,10 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_stream_kernel(const StackP
   {
     const float4 bias = *reinterpret_cast<const float4*>(W + P.pre_b + o0);
     __syncthreads();                                         // the feature (and cache) maxima are published
+    if (amax_inputs_bad(amax_cells) || amax_inputs_bad(amax_cells + kAmaxCells)) {   // a NaN / Inf in a stream's chunk or cache:
+      for (int u = 0; u < nu; ++u) nf_repair_call(A, b0 + u);                         // the reference's arithmetic for both streams
+      return;
+    }
     if (xi.dst >= 0) {
       float inv_unused;
       const float sx = pow2_scale(amax_read(amax_cells + (tid >= nk * 4 * TT ? kAmaxCells : 0)), &inv_unused);

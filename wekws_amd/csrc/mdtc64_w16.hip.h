@@ -97,17 +97,27 @@ __global__ __launch_bounds__(kW16Threads) void mdtc64_w16_kernel(const StackPara
     const int kf = st * 32 + oct * 8;
     xi.dst = u * UB + ((st * 4 + oct) * TT + t) * 16;
     w16_fetch_x(xi, A.x + int64_t(b0 + u) * A.xs_b + int64_t(t) * P.idim + kf, A.x, (b0 + u) < A.B && t < T && kf < P.idim);
-    amax_publish(amax_cells + u * kAmaxCells, w16_x_amax(xi));
+    amax_publish(amax_cells + u * kAmaxCells, w16_x_amax_bits(xi));
   };
 
   if (one_trip) load_item();
   for (int u = 0; u < U; ++u)
     if (b0 + u < A.B) {
       if (!one_trip)
-        amax_publish(amax_cells + u * kAmaxCells, amax_span<kW16Threads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
+        amax_publish(amax_cells + u * kAmaxCells, amax_span_bits<kW16Threads>(A.x + int64_t(b0 + u) * A.xs_b, T * P.idim, 0.f));
       if (HAS_CACHE)
-        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span<kW16Threads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
+        amax_publish(amax_cells + u * kAmaxCells + 1, amax_span_bits<kW16Threads>(A.in_cache + int64_t(b0 + u) * C * Pc, C * Pc, 0.f));
     }
+  __syncthreads();
+  {                                                          // a NaN / Inf feature or cache element among this workgroup's utterances:
+    bool bad = false;                                        // the reference's arithmetic for all of them (nonfinite.hip.h)
+    for (int u = 0; u < U; ++u) bad |= amax_inputs_bad(amax_cells + u * kAmaxCells);
+    if (bad) {
+      for (int u = 0; u < U; ++u)
+        if (b0 + u < A.B) nf_repair_call(A, b0 + u);
+      return;
+    }
+  }
 
   // weight fragments of one GEMM (2 K steps, hi | lo)
   auto load_frags = [](F16Frag (&a)[2], const uint4* __restrict__ ap) __attribute__((always_inline)) {

@@ -301,6 +301,18 @@ static __global__ void cache_remap_kernel(float* __restrict__ dst, const float* 
   }
 }
 
+// The same re-computation as its own launch, behind a kernel that is left exactly as it was (the register-resident kernels of
+// ds64_g4.hip.h / mdtc64_g4.hip.h: one utterance per small workgroup, several workgroups per CU, at the register limit -- a
+// detection branch inside them moved their register allocation into scratch).  One workgroup per utterance: a pass over its
+// features (and incoming cache); what the kernel before wrote for an utterance with a NaN / Inf input is overwritten.
+static __global__ __launch_bounds__(256) void conv_nf_fix_kernel(const wekws::CallArgs A, int idim, int cache_elems) {
+  __shared__ unsigned cell;
+  const int b = blockIdx.x;
+  bool bad = wekws::nf_scan_rows(A.x + int64_t(b) * A.xs_b, A.T, idim, idim, &cell);
+  if (!bad && A.in_cache) bad = wekws::nf_scan(A.in_cache + int64_t(b) * cache_elems, cache_elems, &cell);
+  if (bad) wekws::nf_repair_call(A, b);
+}
+
 struct wekws_hip_model {
   wekws_hip_desc desc;
   int device = 0;
@@ -347,9 +359,98 @@ struct wekws_hip_model {
   // struct is used then.
   bool generic = false;
   wekws::GenericModel gm{};
+  // Utterances with a NaN / Inf input leave the fast path and are re-computed in exact IEEE f32 (nonfinite.hip.h): the
+  // descriptor + packer-order blob the kernels' shape corresponds to, and scratch slots, on the device.
+  wekws::NfCtx nf_host{};
+  wekws::NfCtx* nf_dev = nullptr;
+  float* nf_w = nullptr;
+  float* nf_scratch = nullptr;
+  unsigned* nf_slots = nullptr;
   std::vector<StreamBuf> ws;       // per-stream workspaces (stream_workspace())
   std::mutex ws_mu;
 };
+
+// NoSubsampling (subsampling.py:35-36) arrives as a square preprocessing matrix that is diagonal (the packer folds a CMVN into it)
+static bool pre_is_diagonal(const wekws_hip_desc& d, const float* blob) {
+  if (d.backbone == WEKWS_HIP_BACKBONE_FSMN || d.idim != d.hdim) return false;
+  for (int r = 0; r < d.hdim; ++r)
+    for (int k = 0; k < d.idim; ++k)
+      if (r != k && blob[size_t(r) * d.idim + k] != 0.f) return false;
+  return true;
+}
+
+// (measurement aid: WEKWS_NF_FIX_ALL=1 runs the separate non-finite pass behind EVERY conv kernel, to price the extra launch)
+static bool nf_fix_all() {
+  static const bool v = [] { const char* e = std::getenv("WEKWS_NF_FIX_ALL"); return e && e[0] == '1'; }();
+  return v;
+}
+static thread_local bool g_route_last_g4 = false;            // the conv launch just made was a ds64_g4 / mdtc_g4 kernel
+
+// The device-side context of nonfinite.hip.h for a model whose kernels run shape `d` on packer-order blob `blob` (host).
+// tmax: most frames one kernel call covers.  Returns a WEKWS_HIP_* code.
+static int nf_setup(wekws_hip_model* m, const wekws_hip_desc& d, const float* blob, size_t n_elems, int tmax) {
+  wekws::NfCtx& c = m->nf_host;
+  c = wekws::NfCtx{};
+  c.d = d;
+  c.nslots = 16;
+  c.skip_zero = 0;
+  c.tmax = tmax;
+  int64_t slot = 0;
+  if (d.backbone == WEKWS_HIP_BACKBONE_GRU) {
+    c.width = d.hdim;
+    slot = int64_t(d.num_layers) * d.hdim + 7 * int64_t(d.hdim);
+  } else if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
+    c.cache_len = d.kernel_size - 1 + d.stack_size;
+    c.pmax = c.cache_len;
+    c.width = std::max(std::max(d.hdim, d.num_stack), std::max(d.aux[0], d.aux[1]));
+    slot = 4 * int64_t(tmax) * c.width + int64_t(c.pmax + tmax) * d.num_stack;
+  } else {
+    int pmax = 0, sum = 0;
+    for (int i = 0; i < n_blocks(d); ++i) {
+      const int dil = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? ((i == 0) ? 1 : (1 << ((i - 1) % d.stack_size))) : (1 << i);
+      const int pad = (d.kernel_size - 1) * dil;
+      pmax = std::max(pmax, pad);
+      sum += pad;
+    }
+    c.cache_len = sum;
+    c.pmax = pmax;
+    c.width = std::max(d.hdim, d.head_hidden);
+    slot = 4 * int64_t(tmax) * c.width + int64_t(pmax + tmax) * d.hdim;
+  }
+  c.slot_floats = (slot + 63) / 64 * 64;
+  c.pre_diag = pre_is_diagonal(d, blob);
+  hipError_t e = hipMalloc(&m->nf_w, n_elems * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(m->nf_w, blob, n_elems * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->nf_scratch, size_t(c.slot_floats) * c.nslots * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&m->nf_slots, c.nslots * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(m->nf_slots, 0, c.nslots * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&m->nf_dev, sizeof(wekws::NfCtx));
+  c.w = m->nf_w;
+  c.scratch = m->nf_scratch;
+  c.slots = m->nf_slots;
+  if (e == hipSuccess) e = hipMemcpy(m->nf_dev, &c, sizeof(c), hipMemcpyHostToDevice);
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? WEKWS_HIP_ENOMEM : WEKWS_HIP_EDEVICE, "non-finite path setup: %s", hipGetErrorString(e));
+  return WEKWS_HIP_OK;
+}
+static void nf_teardown(wekws_hip_model* m) {
+  if (m->nf_w) (void)hipFree(m->nf_w);
+  if (m->nf_scratch) (void)hipFree(m->nf_scratch);
+  if (m->nf_slots) (void)hipFree(m->nf_slots);
+  if (m->nf_dev) (void)hipFree(m->nf_dev);
+  m->nf_w = m->nf_scratch = nullptr;
+  m->nf_slots = nullptr;
+  m->nf_dev = nullptr;
+}
+// a zero-padded model (pad_conv_shape / pad_gru_hidden): zero weights contribute nothing on the non-finite path
+static int nf_set_skip_zero(wekws_hip_model* m) {
+  m->nf_host.skip_zero = 1;
+  if (!m->nf_dev) return WEKWS_HIP_OK;
+  DeviceGuard guard(m->device);
+  if (hipMemcpy(m->nf_dev, &m->nf_host, sizeof(m->nf_host), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(WEKWS_HIP_EDEVICE, "non-finite path setup (padded model)");
+  return WEKWS_HIP_OK;
+}
 
 // -> device pointer to at least `need` bytes owned by (model, stream); nullptr + error text on failure
 static char* stream_workspace(wekws_hip_model* m, hipStream_t stream, size_t need, bool granules = false, unsigned layout = 0) {
@@ -578,6 +679,19 @@ static void balance_operand_channels(const wekws_hip_desc& d, float* w) {
 // path (generic.hip.h).  The reference's init_model takes any size (kws_model.py:114-170); before round 5 these were
 // WEKWS_HIP_EUNSUPPORTED.
 static int create_generic(const wekws_hip_desc& d, const float* blob, size_t n_elems, int device, wekws_hip_model** out) {
+  if (desc_conv(d)) {
+    // dilations are 1 << i and the cache length is their sum times (kernel_size - 1): a corrupt descriptor (hundreds of layers)
+    // must not reach the shift or overflow the int the kernels index with
+    const int depth = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? d.stack_size : d.num_layers;
+    if (depth > 24) return fail(WEKWS_HIP_EINVAL, "dilation 2^%d: %d layers per stack is beyond any receptive field", depth - 1, depth);
+    int64_t sum = 0;
+    for (int i = 0; i < n_blocks(d); ++i) {
+      const int dil = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? ((i == 0) ? 1 : (1 << ((i - 1) % d.stack_size))) : (1 << i);
+      sum += int64_t(d.kernel_size - 1) * dil;
+    }
+    if (sum * std::max(1, d.hdim) > int64_t(INT32_MAX) / 4)
+      return fail(WEKWS_HIP_EINVAL, "cache of %lld frames x %d channels per stream is out of range", (long long)sum, d.hdim);
+  }
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(WEKWS_HIP_EDEVICE, "device %d of %d", device, ndev);
@@ -598,6 +712,7 @@ static int create_generic(const wekws_hip_desc& d, const float* blob, size_t n_e
   }
   m->gm.d = d;
   m->gm.w = m->d_w;
+  m->gm.pre_diag = pre_is_diagonal(d, blob);
   m->gm.cache_len = m->cache_len = wekws::gen_cache_len(d);
   *out = m;
   return WEKWS_HIP_OK;
@@ -712,6 +827,12 @@ static int create_fsmn(const wekws_hip_desc& d, const float* blob_in, size_t n_e
   q.w = m->d_w;
   m->fq = q;
   m->spread_log2 = img.spread_log2;
+  if (const int rc = nf_setup(m, d, blob_in, n_elems, 16 * max_nt); rc != WEKWS_HIP_OK) {
+    nf_teardown(m);
+    (void)hipFree(m->d_w);
+    delete m;
+    return rc;
+  }
   *out = m;
   return WEKWS_HIP_OK;
 }
@@ -876,6 +997,7 @@ static int forward_fsmn(wekws_hip_model* m, const float* x, int B, int T, const 
     a.ys_b = int64_t(T) * d.odim;
     a.B = B;
     a.T = Tt;
+    a.nf = m->nf_dev;
     // short inputs: pack 2 or 4 utterances into one workgroup, as long as every CU still gets a workgroup
     const int nt = (Tt + 15) / 16;
     int u = 1;
@@ -950,6 +1072,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       if (rc != WEKWS_HIP_OK) return rc;
       wekws_hip_model* m = *out;
       m->user_hdim = C;
+      if (const int rz = nf_set_skip_zero(m); rz != WEKWS_HIP_OK) { wekws_hip_destroy(m); *out = nullptr; return rz; }
       // the caller's cache: per block (ks - 1) dil frames, the tail of the built kernel's (ks_built - 1) dil
       int uoff = 0, boff = 0;
       m->widen.nb = m->narrow.nb = n_blocks(d);
@@ -982,6 +1105,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       if (rc != WEKWS_HIP_OK) return rc;
       wekws_hip_model* m = *out;
       m->user_hdim = C;
+      if (const int rz = nf_set_skip_zero(m); rz != WEKWS_HIP_OK) { wekws_hip_destroy(m); *out = nullptr; return rz; }
       m->widen.nb = m->narrow.nb = 1;                        // states (L, B, H): one "slice" per row
       m->widen.s_off[0] = m->widen.d_off[0] = m->narrow.s_off[0] = m->narrow.d_off[0] = 0;
       m->widen.len[0] = m->narrow.len[0] = C;
@@ -1249,6 +1373,11 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   m->dp.blocks = m->d_dblocks;
   m->gp.w = m->d_w;
   m->gq.base = m->gp;
+  if (const int rc = nf_setup(m, d, orig, n_elems, WEKWS_HIP_TILE_FRAMES); rc != WEKWS_HIP_OK) {
+    nf_teardown(m);
+    cleanup();
+    return rc;
+  }
   *out = m;
   return WEKWS_HIP_OK;
 }
@@ -1259,6 +1388,7 @@ void wekws_hip_destroy(wekws_hip_model* m) {
   if (m->d_w) (void)hipFree(m->d_w);
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->d_dblocks) (void)hipFree(m->d_dblocks);
+  nf_teardown(m);
   bool gave_up = false;
   for (auto& e : m->ws) {
     // (the device memory first: hipFree waits for the work that may still use it -- the caller's stream handles are not
@@ -1272,7 +1402,12 @@ void wekws_hip_destroy(wekws_hip_model* m) {
     }
   }
   // (no return value to carry it: a failure nobody has asked about yet is at least left in wekws_hip_last_error())
-  if (gave_up) (void)fail(WEKWS_HIP_EDEVICE, "model destroyed with an unreported failure: a bounded wait of the GRU wavefront gave up");
+  if (gave_up) {
+    (void)fail(WEKWS_HIP_EDEVICE, "model destroyed with an unreported failure: a bounded wait of the GRU wavefront gave up");
+    // LOUD: this is the one failure no later call can report (the last forward of a script that never asked for
+    // wekws_hip_forward_status / release) -- the reference's Run would have thrown (keyword_spotting.cc:77-79)
+    std::fprintf(stderr, "libwekws_hip: ERROR: %s -- the outputs of the last forward(s) on that stream are not valid\n", g_err.c_str());
+  }
   delete m;
 }
 
@@ -1486,8 +1621,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
   if (m->generic) {
     char* base = stream_workspace(m, stream, workspace_need(m, B, T));
     if (!base) return WEKWS_HIP_ENOMEM;
-    const int rc = wekws::generic_forward(m->gm, x, B, T, in_cache, y, out_cache, base, stream);
-    if (rc) return fail(rc, "any-shape path: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    hipError_t lerr = hipSuccess;
+    const int rc = wekws::generic_forward(m->gm, x, B, T, in_cache, y, out_cache, base, stream, &lerr);
+    if (rc) return fail(rc, "any-shape path: launch failed: %s", hipGetErrorString(lerr));
   } else if (d.backbone == WEKWS_HIP_BACKBONE_FSMN) {
     const int rc = forward_fsmn(m, x, B, T, in_cache, y, out_cache, stream);
     if (rc) return rc;
@@ -1545,6 +1681,9 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       rc = wekws::launch_gru(m->gp, x, B, T, in_cache, y, out_cache, stream);
     }
     if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // streams with a NaN / Inf feature or state (their loads entered the kernels above as 0): the reference's arithmetic
+    hipLaunchKernelGGL(wekws::gru_nf_fix_kernel, dim3(B), dim3(256), 0, stream, m->nf_dev, x, B, T, in_cache, out_cache, y);
+    if (hipGetLastError() != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "gru non-finite pass: launch failed");
     if (user_h_out) {
       const size_t ue = size_t(d.num_layers) * B * m->user_hdim;
       const int grid = int(std::min<size_t>((ue + 255) / 256, 4096));
@@ -1601,11 +1740,13 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
       a.first_tile = (i == 0);
       a.last_tile = (i == ntiles - 1);
       a.head_slices = 0;
+      a.nf = m->nf_dev;
       if (m->mm_ok && d.odim >= 256 && B * 2 <= m->fsmn_cus) {       // CTC head, a handful of streams (ds256_mm.hip.h)
         const int sl = m->fsmn_cus / B;
         a.head_slices = m->fsmn_slices >= 0 ? m->fsmn_slices : (sl > 8 ? 8 : sl);
       }
       int rc;
+      g_route_last_g4 = false;
       const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32;  // DEFAULT -> split fp16 for the conv backbones
       const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
       // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
@@ -1628,7 +1769,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                      ? rc                                                                         // 16 waves, tile in registers (with a cache: its context variant)
                : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
                : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
-                  (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4)
+                  (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
                      ? rc                                                                         // one utterance per 4-wave workgroup
                                          : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
           break;
@@ -1648,18 +1789,22 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
                // at 65 .. 112 frames, where 17 blocks' context loads sit on one workgroup's critical path: 91 vs 75 us, measured)
                : (f16 && m->mdtc16_ok && m->g16_ok && m->mdtc_stream_eligible &&
                   (!a.in_cache || (m->g16_ctx && nt >= 2 && (B > 2 || nt < 7))) &&
-                  (rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream)) != -4)
+                  (rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
                    ? rc                                                                          // one utterance per 4-wave workgroup
                : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
                : (f16 && C == 32 && m->g16_ok && d.kernel_size == 5 && d.stack_size <= 4 &&
                   (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
-                  (rc = wekws::launch_mdtc32_g4(nt, split, m->sp, a, stream)) != -4)
+                  (rc = wekws::launch_mdtc32_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
                    ? rc                                                                          // one utterance per 2-wave workgroup
                : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
                    : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;
       }
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
+      if (nf_fix_all()) {                                    // (measurement aid only: the non-finite pass as its own launch)
+        hipLaunchKernelGGL(conv_nf_fix_kernel, dim3(B), dim3(256), 0, stream, a, d.idim, C * m->cache_len);
+        if (hipGetLastError() != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "non-finite pass: launch failed");
+      }
     }
     if (user_out_cache) {
       const size_t ue = size_t(B) * m->user_hdim * m->user_cache_len;

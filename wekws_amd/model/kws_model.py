@@ -275,15 +275,8 @@ class KWSModel(nn.Module):
     def _run(self, x: torch.Tensor, in_cache: Optional[torch.Tensor], softmax: bool, want_cache: bool = True):
         if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.size(2) != self.idim:
             raise ValueError(f"expected x of shape (B, T, {self.idim}), got {tuple(x.shape) if hasattr(x, 'shape') else x}")
-        if getattr(self, "validate_inputs", False):
-            # Opt-in (one reduction + a synchronisation per call).  The reference propagates a NaN / Inf feature into the posteriors
-            # of that utterance (torch.relu(nan) = nan); the kernels here do NOT: their ReLUs are v_max_f32, which returns the
-            # operand that is a number, so such an utterance comes back with finite, meaningless scores (measured:
-            # tools/probe/nonfinite.py).  Features made by fbank are finite by construction (floored at FLT_EPSILON before the log,
-            # fbank.h:187-189); a caller that cannot vouch for its inputs sets `model.validate_inputs = True`.
-            if not bool(torch.isfinite(x).all()) or (isinstance(in_cache, torch.Tensor) and in_cache.numel() > 0
-                                                     and not bool(torch.isfinite(in_cache).all())):
-                raise ValueError("non-finite values in x / in_cache")
+        # (NaN / Inf features or caches need no check here: the kernels return what the reference returns for them -- NaN / Inf in
+        # that utterance's causal receptive field, the other utterances untouched -- wekws_amd/csrc/nonfinite.hip.h)
         if not x.is_cuda:
             raise RuntimeError("wekws_amd.KWSModel runs on the MI355X HIP path only (no CPU fallback): "
                                "move the model and its inputs to a ROCm device")

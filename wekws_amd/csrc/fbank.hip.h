@@ -186,7 +186,7 @@ __device__ __forceinline__ float fb_wave_sum(float s) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
 }
 #ifndef WEKWS_FBANK_FW
-#define WEKWS_FBANK_FW 2
+#define WEKWS_FBANK_FW 1
 #endif
 constexpr int kFbankFW = WEKWS_FBANK_FW;   // frames per wave, interleaved through every phase (round 4)
 

@@ -33,6 +33,7 @@
 #include "gru_f16.hip.h"
 #include "gru_pipe.hip.h"
 #include "generic.hip.h"
+#include "route.h"
 #include "mfcc.hip.h"
 #include "splice.hip.h"
 #include "topk.hip.h"
@@ -357,6 +358,7 @@ struct wekws_hip_model {
   // A shape no specialised kernel is built for (wider / deeper / longer kernels than the reference's recipes use), or an FSMN
   // that must run exact f32: the any-shape path of generic.hip.h on the packer's blob as it is (d_w); nothing else of this
   // struct is used then.
+  wekws::RouteFlags rf{};   // what the model's shape admits (route.h); the bools above that say the same are kept for the options
   bool generic = false;
   wekws::GenericModel gm{};
   // Utterances with a NaN / Inf input leave the fast path and are re-computed in exact IEEE f32 (nonfinite.hip.h): the
@@ -384,7 +386,15 @@ static bool nf_fix_all() {
   static const bool v = [] { const char* e = std::getenv("WEKWS_NF_FIX_ALL"); return e && e[0] == '1'; }();
   return v;
 }
-static thread_local bool g_route_last_g4 = false;            // the conv launch just made was a ds64_g4 / mdtc_g4 kernel
+static thread_local wekws::Route g_last_route{};             // the route of this thread's last conv launch (tests: hooks build)
+static wekws::RouteOptions route_options(const wekws_hip_model* m) {
+  wekws::RouteOptions o;
+  o.w16_ok = m->w16_ok; o.g16_ok = m->g16_ok; o.g16_ctx = m->g16_ctx; o.g16_one_pass = m->g16_one_pass; o.stream_ok = m->stream_ok;
+  o.mdtc16_ok = m->mdtc16_ok; o.mm_ok = m->mm_ok;
+  o.f32 = m->desc.precision == WEKWS_HIP_PRECISION_F32 || m->auto_f32;
+  o.split = m->desc.precision != WEKWS_HIP_PRECISION_F16;
+  return o;
+}
 
 // The device-side context of nonfinite.hip.h for a model whose kernels run shape `d` on packer-order blob `blob` (host).
 // tmax: most frames one kernel call covers.  Returns a WEKWS_HIP_* code.
@@ -1048,21 +1058,15 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
   std::vector<float> balanced(blob, blob + n_elems);        // (exact power-of-two rescaling: see balance_operand_channels)
   balance_operand_channels(d, balanced.data());
   blob = balanced.data();
+  // which shape the kernels run: as it is, zero-padded to the next built one, or the any-shape path -- a pure function of the
+  // descriptor (route.h: conv_shape_plan; tests/test_route.py sweeps it on the CPU)
+  const wekws::ShapePlan plan = desc_conv(d) ? wekws::conv_shape_plan(d, wekws::kAmaxMaxBlocks) : wekws::ShapePlan{wekws::SHAPE_AS_IS, C, ks, nullptr};
+  if (plan.kind == wekws::SHAPE_GENERIC) return create_generic(d, orig, n_elems, device, out);
   {
-    const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
-    // built widths: 64 / 128 / 256, and 32 for MDTC (mdtc_small.yaml; no DS-TCN / TCN kernel is built for 32: they run as 64)
-    const bool odd_c = C != 64 && C != 128 && C != 256 && !(C == 32 && d.backbone == WEKWS_HIP_BACKBONE_MDTC);
-    if (desc_conv(d) && (odd_c || (ks >= 1 && ks < ks_built))) {
+    if (plan.kind == wekws::SHAPE_PADDED) {
       // any width up to 256 and any kernel size up to the built one (kws_model.py:114,142-157 take any): run as the next
       // built shape, zero-padded -- exact, see pad_conv_shape
-      const int Cp = !odd_c ? C : (C < 32 && d.backbone == WEKWS_HIP_BACKBONE_MDTC) ? 32 : C < 64 ? 64 : C < 128 ? 128 : 256;
-      if (C > 256) return create_generic(d, orig, n_elems, device, out);                    // wider than any built kernel
-      // padding only ever ADDS zero taps: a kernel size above the built one cannot be served (pad_conv_shape would write
-      // ks floats into a ks_built-wide slot)
-      if (ks > ks_built) return create_generic(d, orig, n_elems, device, out);
-      if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && Cp > 128) return create_generic(d, orig, n_elems, device, out);   // (the LDS tile holds 128)
-      if (n_blocks(d) > wekws::kAmaxMaxBlocks) return create_generic(d, orig, n_elems, device, out);   // (more blocks than the cache maps hold)
-      if (odd_c && d.head == WEKWS_HIP_HEAD_IDENTITY) return create_generic(d, orig, n_elems, device, out);   // (y is the C-wide tile itself)
+      const int Cp = plan.C, ks_built = plan.ks;
       wekws_hip_desc dd = d;
       dd.hdim = Cp;
       dd.kernel_size = ks_built;
@@ -1087,15 +1091,7 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
       return WEKWS_HIP_OK;
     }
   }
-  if (desc_conv(d)) {
-    if (d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 256) return create_generic(d, orig, n_elems, device, out);   // (does not fit the LDS tile)
-    // the conv kernels are specialised for the kernel sizes of the reference recipes
-    // (examples/*/s0/conf/{ds_tcn,tcn}.yaml: 8; mdtc*.yaml: 5)
-    const int ks_built = d.backbone == WEKWS_HIP_BACKBONE_MDTC ? 5 : 8;
-    if (ks != ks_built) return create_generic(d, orig, n_elems, device, out);
-    if (d.precision != WEKWS_HIP_PRECISION_F32 && n_blocks(d) > wekws::kAmaxMaxBlocks)
-      return create_generic(d, orig, n_elems, device, out);   // (the split-fp16 kernels track kAmaxMaxBlocks tile maxima)
-  } else {
+  if (!desc_conv(d)) {
     if (C < 128 && d.head == WEKWS_HIP_HEAD_LINEAR && d.num_layers <= wekws::kGruMaxLayers) {
       wekws_hip_desc dd = d;
       dd.hdim = 128;
@@ -1278,20 +1274,15 @@ int wekws_hip_create(const wekws_hip_desc* desc, const float* blob, size_t n_ele
     dp.head_w = sp.head_w; dp.head_b = sp.head_b; dp.head_w2 = sp.head_w2; dp.head_b2 = sp.head_b2; dp.cache_len = off;
     dp.pre_inv_s = pre_inv_s;
     sp.head_inv_s = dp.head_inv_s;
-    int max_pad = 0;
-    for (const auto& bb : blocks) max_pad = bb.pad > max_pad ? bb.pad : max_pad;
-    m->dense_ok = d.backbone == WEKWS_HIP_BACKBONE_TCN && max_pad <= 56 && C <= 128;
-    m->mdtc16_eligible = d.backbone == WEKWS_HIP_BACKBONE_MDTC && C == 64 && ks == 5;
-    m->ds_stream_eligible = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8;
-    for (const auto& bb : blocks)
-      if (!(bb.dil == 1 || bb.dil == 2 || bb.dil == 4 || bb.dil == 8) || bb.pad != 7 * bb.dil) m->ds_stream_eligible = false;
+    // what this shape can run on: one pure function of the descriptor (route.h), shared with the CPU tests
+    m->rf = wekws::conv_route_flags(d, int(wekws::mdtc64_stream_lds_bytes(off)));
+    if (m->rf.cache_len != off) { delete m; return fail(WEKWS_HIP_EINVAL, "internal: cache length %d vs %d", m->rf.cache_len, off); }
+    m->dense_ok = m->rf.dense_ok;
+    m->mdtc16_eligible = m->rf.mdtc16_eligible;
+    m->ds_stream_eligible = m->rf.ds_stream_eligible;
     m->mdtc16_ok = m->mdtc16_eligible;
-    m->mdtc_stream_eligible = m->mdtc16_eligible && sp.kpre16 <= 128 && (64 * off) % 4 == 0 &&
-                              wekws::mdtc64_stream_lds_bytes(off) <= 158 * 1024;
-    for (const auto& bb : blocks)
-      if (!(bb.dil == 1 || bb.dil == 2 || bb.dil == 4 || bb.dil == 8) || bb.pad != 4 * bb.dil) m->mdtc_stream_eligible = false;
-    m->mm_eligible = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN && C == 256 && ks == 8 && max_pad <= 56 &&
-                     d.head == WEKWS_HIP_HEAD_LINEAR;
+    m->mdtc_stream_eligible = m->rf.mdtc_stream_eligible;
+    m->mm_eligible = m->rf.mm_eligible;
     // default: on for CTC-sized heads (its activation planes feed an MFMA classifier directly), off for keyword heads
     // (the 16-wave kernel is 12 % faster there)
     m->mm_ok = m->mm_eligible && K > 16;
@@ -1592,6 +1583,50 @@ __global__ void debug_hog_kernel(unsigned long long ticks, int busy) {
   }
   if (c0[0] + c1[0] + v == 12345.f) hog_lds[1] = 1;
 }
+// The routing functions of route.h, callable WITHOUT a device (tests/test_route.py, hooks library only).
+//   desc: any conv descriptor wekws_hip_create accepts.  opts[9] (or NULL = the defaults for that precision): w16_ok, g16_ok, g16_ctx,
+//   g16_one_pass, stream_ok, mdtc16_ok, mm_ok (-1: the default: CTC-sized heads), f32, split.  call[8]: B, T (of the tile), ntiles,
+//   has_in, has_out, x16, cache16, cus.  out[14]: plan kind, built C, built ks, family, nt, split, ctx, fast, grid, threads, lds,
+//   utts_per_wg, cache_len (built shape), max_pad.  why: the reason text for "any-shape path" / "no kernel".  Returns 0.
+extern "C" int wekws_hip_debug_conv_route(const wekws_hip_desc* desc, const int* opts, const int* call, int* out, char* why, int why_len) {
+  if (!desc || !call || !out || !desc_conv(*desc)) return WEKWS_HIP_EINVAL;
+  for (int i = 0; i < 14; ++i) out[i] = 0;
+  if (why && why_len > 0) why[0] = 0;
+  auto say = [&](const char* t) { if (why && why_len > 0 && t) { std::strncpy(why, t, size_t(why_len) - 1); why[why_len - 1] = 0; } };
+  const wekws::ShapePlan plan = wekws::conv_shape_plan(*desc, wekws::kAmaxMaxBlocks);
+  out[0] = plan.kind; out[1] = plan.C; out[2] = plan.ks;
+  if (plan.kind == wekws::SHAPE_GENERIC) { say(plan.why); return WEKWS_HIP_OK; }
+  wekws_hip_desc d = *desc;
+  d.hdim = plan.C; d.kernel_size = plan.ks;
+  const wekws::RouteFlags f = wekws::conv_route_flags(d, 0);
+  wekws::RouteFlags ff = wekws::conv_route_flags(d, int(wekws::mdtc64_stream_lds_bytes(f.cache_len)));
+  wekws::RouteOptions o;
+  o.f32 = d.precision == WEKWS_HIP_PRECISION_F32;
+  o.split = d.precision != WEKWS_HIP_PRECISION_F16;
+  o.mdtc16_ok = ff.mdtc16_eligible;
+  o.mm_ok = ff.mm_eligible && d.odim > 16;
+  if (opts) {
+    o.w16_ok = opts[0]; o.g16_ok = opts[1]; o.g16_ctx = opts[2]; o.g16_one_pass = opts[3]; o.stream_ok = opts[4];
+    o.mdtc16_ok = ff.mdtc16_eligible && opts[5]; o.mm_ok = ff.mm_eligible && (opts[6] < 0 ? d.odim > 16 : opts[6] != 0);
+    o.f32 = opts[7]; o.split = opts[8];
+  }
+  wekws::RouteCall c{call[0], call[1], call[2], call[3], call[4], call[5], call[6], call[7]};
+  const wekws::Route r = wekws::select_conv_route(d, ff, o, c, int(wekws::ds256_stream_lds_bytes(ff.cache_len)),
+                                                  int(wekws::mdtc64_stream_lds_bytes(ff.cache_len)));
+  out[3] = r.family; out[4] = r.nt; out[5] = r.split; out[6] = r.ctx; out[7] = r.fast; out[8] = r.grid; out[9] = r.threads; out[10] = r.lds_bytes;
+  out[11] = r.utts_per_wg; out[12] = ff.cache_len; out[13] = ff.max_pad;
+  if (r.family == wekws::ROUTE_NONE) say(r.why_not);
+  else say(wekws::route_family_name(r.family));
+  return WEKWS_HIP_OK;
+}
+// the route of the calling thread's last conv launch: out[9] = family, nt, split, ctx, fast, grid, threads, lds, utts_per_wg
+extern "C" int wekws_hip_debug_last_route(int* out) {
+  if (!out) return WEKWS_HIP_EINVAL;
+  const wekws::Route& r = g_last_route;
+  out[0] = r.family; out[1] = r.nt; out[2] = r.split; out[3] = r.ctx; out[4] = r.fast; out[5] = r.grid; out[6] = r.threads; out[7] = r.lds_bytes;
+  out[8] = r.utts_per_wg;
+  return WEKWS_HIP_OK;
+}
 extern "C" int wekws_hip_debug_hog(int device, int blocks, int ms, void* stream_) {
   DeviceGuard guard(device);
   const int busy = ms < 0;
@@ -1724,8 +1759,6 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     for (int i = 0; i < ntiles; ++i) {
       const int t0 = i * TILE;
       const int Tt = (T - t0 < TILE) ? (T - t0) : TILE;
-      const int nt16 = (Tt + 15) / 16;
-      const int nt = nt16 <= 1 ? 1 : nt16 <= 2 ? 2 : nt16 <= 4 ? 4 : 7;
       wekws::CallArgs a{};
       a.x = x + size_t(t0) * d.idim;
       a.xs_b = int64_t(T) * d.idim;
@@ -1746,60 +1779,50 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
         a.head_slices = m->fsmn_slices >= 0 ? m->fsmn_slices : (sl > 8 ? 8 : sl);
       }
       int rc;
-      g_route_last_g4 = false;
-      const bool f16 = d.precision != WEKWS_HIP_PRECISION_F32 && !m->auto_f32;  // DEFAULT -> split fp16 for the conv backbones
-      const bool split = d.precision != WEKWS_HIP_PRECISION_F16;
-      // streaming chunk (T <= 16): the stream's cache lives in LDS for the whole step (ds256_stream.hip.h)
-      // (the streaming kernels move whole caches with 16-byte accesses: both cache pointers must be 16-byte aligned)
-      const bool cache16 = (reinterpret_cast<uintptr_t>(in_cache) | reinterpret_cast<uintptr_t>(out_cache)) % 16 == 0;
-      const bool strm = f16 && m->ds_stream_eligible && m->w16_ok && !m->mm_ok &&
-                        m->stream_ok && ntiles == 1 && T <= 16 && d.kernel_size == 8 && (in_cache || out_cache) && cache16 &&
-                        wekws::ds256_stream_lds_bytes(m->cache_len) <= 160 * 1024;
-      switch (d.backbone) {
-        case WEKWS_HIP_BACKBONE_DS_TCN:
-          rc = strm ? wekws::launch_ds256_stream(split, m->sp, a, stream)
-               : !f16 ? ((C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && !a.in_cache &&
-                          (rc = wekws::launch_ds256_g32(nt, m->sp, a, stream, m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
-                             ? rc                                                            // exact f32, tile in registers
-                             : wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream))
-               : m->mm_ok ? wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream)     // depthwise on MFMA
-               : (C == 256 && m->w16_ok && m->g16_ok && m->ds_stream_eligible && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&     // (chunks of <= 16 frames with a cache: ds256_stream, else ds256_w16)
-                  (rc = wekws::launch_ds256_g16(a.in_cache && nt < 4 ? 4 : nt, split, m->sp, a, stream,
-                                                m->g16_one_pass ? (1 << 30) : m->fsmn_cus)) != -4)
-                     ? rc                                                                         // 16 waves, tile in registers (with a cache: its context variant)
-               : (C == 256 && m->w16_ok) ? wekws::launch_ds256_w16(nt, split, m->sp, a, stream)   // 16-wave variant
-               : (C == 64 && m->g16_ok && d.kernel_size == 8 && d.num_layers <= 4 && (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
-                  (rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
-                     ? rc                                                                         // one utterance per 4-wave workgroup
-                                         : wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream);
-          break;
-        case WEKWS_HIP_BACKBONE_TCN:
-          rc = !f16 ? wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
-               : m->dense_ok ? wekws::launch_dense_stack_f16<wekws::KIND_TCN>(C, nt, m->dp, a, stream)
-                             : wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream);
+      // ---- which kernel: one pure function of (shape flags, options, call) -- route.h; tests/test_route.py sweeps it on the CPU
+      const wekws::RouteOptions ro = route_options(m);
+      wekws::RouteCall rcall{};
+      rcall.B = B; rcall.T = Tt; rcall.ntiles = ntiles;
+      rcall.has_in = a.in_cache != nullptr; rcall.has_out = a.out_cache != nullptr;
+      rcall.x16 = reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0;
+      // (the streaming kernels move whole caches with 16-byte accesses: both of the CALL's cache pointers must be 16-byte aligned)
+      rcall.cache16 = (reinterpret_cast<uintptr_t>(in_cache) | reinterpret_cast<uintptr_t>(out_cache)) % 16 == 0;
+      rcall.cus = m->fsmn_cus;
+      if (ntiles == 1) { rcall.has_in = in_cache != nullptr; rcall.has_out = out_cache != nullptr; }
+      const wekws::Route route = wekws::select_conv_route(d, m->rf, ro, rcall, int(wekws::ds256_stream_lds_bytes(m->cache_len)),
+                                                          int(wekws::mdtc64_stream_lds_bytes(m->cache_len)));
+      if (route.family == wekws::ROUTE_NONE) return fail(WEKWS_HIP_EUNSUPPORTED, "no kernel for this call: %s", route.why_not ? route.why_not : "?");
+      g_last_route = route;
+      const bool split = route.split != 0;
+      const int nt = route.nt;
+      const int grid_cus = m->g16_one_pass ? (1 << 30) : m->fsmn_cus;   // persistent kernels: the largest grid
+      switch (route.family) {
+        case wekws::ROUTE_DS256_STREAM: rc = wekws::launch_ds256_stream(split, m->sp, a, stream); break;
+        case wekws::ROUTE_DS256_G32: rc = wekws::launch_ds256_g32(nt, m->sp, a, stream, grid_cus); break;
+        case wekws::ROUTE_DS256_MM: rc = wekws::launch_ds256_mm(nt, m->sp, a, m->dp.head_a16, stream); break;
+        case wekws::ROUTE_DS256_G16: rc = wekws::launch_ds256_g16(nt, split, m->sp, a, stream, grid_cus); break;
+        case wekws::ROUTE_DS256_W16: rc = wekws::launch_ds256_w16(nt, split, m->sp, a, stream); break;
+        case wekws::ROUTE_DS64_G4: rc = wekws::launch_ds64_g4(nt, split, m->sp, a, stream); break;
+        case wekws::ROUTE_MDTC64_STREAM: rc = wekws::launch_mdtc64_stream(split, m->sp, a, stream); break;
+        case wekws::ROUTE_MDTC64_G4: rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream); break;
+        case wekws::ROUTE_MDTC64_W16: rc = wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream); break;
+        case wekws::ROUTE_MDTC32_G4: rc = wekws::launch_mdtc32_g4(nt, split, m->sp, a, stream); break;
+        case wekws::ROUTE_DENSE_F16: rc = wekws::launch_dense_stack_f16<wekws::KIND_TCN>(C, nt, m->dp, a, stream); break;
+        case wekws::ROUTE_CONV_F16:
+          rc = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN ? wekws::launch_conv_stack_f16<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+               : d.backbone == WEKWS_HIP_BACKBONE_TCN  ? wekws::launch_conv_stack_f16<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
+                                                        : wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;
         default:
-          // streaming chunk (T <= 16): both streams' caches live in LDS for the step (mdtc64_stream.hip.h).  The role-split
-          // kernel wins at every stream count (16384 streams: 1.28 vs 1.96 ms through the batch kernel), so there is no
-          // upper limit any more (round 1's LDS-cache variant tied with the batch kernel from 3072 streams on)
-          rc = (f16 && m->mdtc16_ok && m->mdtc_stream_eligible && m->stream_ok && ntiles == 1 && T <= 16 && (in_cache || out_cache) &&
-                cache16 && d.idim % 8 == 0 && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.xs_b % 4 == 0)
-                   ? wekws::launch_mdtc64_stream(split, m->sp, a, stream)
-               // (with a cache -- later chunks of 17 .. 112 frames --: the kernel's context variant, except for one or two streams
-               // at 65 .. 112 frames, where 17 blocks' context loads sit on one workgroup's critical path: 91 vs 75 us, measured)
-               : (f16 && m->mdtc16_ok && m->g16_ok && m->mdtc_stream_eligible &&
-                  (!a.in_cache || (m->g16_ctx && nt >= 2 && (B > 2 || nt < 7))) &&
-                  (rc = wekws::launch_mdtc64_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
-                   ? rc                                                                          // one utterance per 4-wave workgroup
-               : (f16 && m->mdtc16_ok) ? wekws::launch_mdtc64_w16(nt, split, m->sp, a, stream)
-               : (f16 && C == 32 && m->g16_ok && d.kernel_size == 5 && d.stack_size <= 4 &&
-                  (!a.in_cache || (m->g16_ctx && nt >= 2)) &&
-                  (rc = wekws::launch_mdtc32_g4(nt, split, m->sp, a, stream)) != -4 && (g_route_last_g4 = true))
-                   ? rc                                                                          // one utterance per 2-wave workgroup
-               : f16 ? wekws::launch_conv_stack_f16<wekws::KIND_MDTC>(C, nt, m->sp, a, stream)
-                   : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
+          rc = d.backbone == WEKWS_HIP_BACKBONE_DS_TCN ? wekws::launch_conv_stack<wekws::KIND_DS>(C, nt, m->sp, a, stream)
+               : d.backbone == WEKWS_HIP_BACKBONE_TCN  ? wekws::launch_conv_stack<wekws::KIND_TCN>(C, nt, m->sp, a, stream)
+                                                        : wekws::launch_conv_stack<wekws::KIND_MDTC>(C, nt, m->sp, a, stream);
           break;
       }
+      // (a launcher that refuses what the route chose: the two have drifted apart -- an internal error, never a silent fall-through)
+      if (rc == -4)
+        return fail(WEKWS_HIP_EUNSUPPORTED, "internal: kernel family %s refused the call the route chose for it (C=%d nt=%d T=%d cache %d/%d)",
+                    wekws::route_family_name(route.family), C, nt, Tt, rcall.has_in, rcall.has_out);
       if (rc) return fail(rc, "conv-stack launch failed (C=%d nt=%d): %s", C, nt, hipGetErrorString(hipGetLastError()));
       if (nf_fix_all()) {                                    // (measurement aid only: the non-finite pass as its own launch)
         hipLaunchKernelGGL(conv_nf_fix_kernel, dim3(B), dim3(256), 0, stream, a, d.idim, C * m->cache_len);

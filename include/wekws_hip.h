@@ -51,6 +51,8 @@ enum wekws_hip_error {
                                  configuration returns it: shapes beyond the specialised kernels (more than 256 channels, kernel
                                  sizes above 8 / 5, GRU hidden sizes above 128 or pooled heads on a GRU, ...) run on the
                                  any-shape exact-f32 path (csrc/generic.hip.h; wekws_hip_effective_precision reports F32).
+                                 That path is one launch per layer -- and for a GRU two launches per layer AND TIME STEP (2 T L
+                                 launches per call: a correctness path; do not capture long GRU calls of such shapes into a graph).
                                  Left: fbank frame lengths outside 65 .. 512 samples. */
 };
 

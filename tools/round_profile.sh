@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_{pytest_gpu.txt,parity_errors.json,f16x3.txt,f32.txt,stream_kernels.txt,pmc_traffic.json,bench.json,
 #    configs.jsonl}; the rocprofv3 databases are deleted at the end (gpurun merges at most 64 MiB back).
 set -u
-tag=${1:-r05j}
+tag=${1:-r06a}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
@@ -34,6 +34,6 @@ cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 python tools/prof_summary.py $(find $out -path "*prof_strm*" -name "*_results.db" | sort) > $out/${tag}_stream_kernels.txt
 rm -rf $out/prof_*
 # the bench line (reads the PMC traffic file written above: same library build) and the secondary configs
-python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python bench.py --extras-out $out/${tag}_bench_extras.json 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 python tools/bench_configs.py > $out/${tag}_configs.jsonl 2> $out/${tag}_configs.err
 ls -la $out | tail -20

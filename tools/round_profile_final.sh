@@ -5,7 +5,7 @@
 # secondary configs of the full session stay valid: those kernels are byte-identical.
 #   tools/round_profile_final.sh r05k
 set -u
-tag=${1:-r05k}
+tag=${1:-r06b}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
@@ -23,6 +23,6 @@ p=profiles/${tag}_traffic_passes.txt
 python tools/pmc_traffic.py ds_tcn_h256/B1024/f16x3=hl=$p ds_tcn_h256/B1024/f32=hl32=$p mdtc_h64/B1024/f16x3=md=$p gru_2x128/B1024/f16x3=gru=$p ds_tcn_h64/B1024/f16x3=d64=$p mdtc_small/B1024/f16x3=m32=$p > $out/${tag}_pmc_traffic.log 2>&1
 cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json
 rm -rf $out/prof_*
-python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python bench.py --extras-out $out/${tag}_bench_extras.json 2> $out/${tag}_bench.err | tail -1 > $out/${tag}_bench.json
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.txt 2>&1
 ls -la $out | tail -12

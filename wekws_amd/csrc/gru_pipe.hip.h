@@ -376,7 +376,17 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
     if (dead) return true;
     ++spins;
     if (spins > kGruPipeFastSpins) __builtin_amdgcn_s_sleep(100);
-    if ((spins & 63u) == 0u && gp_ld_ctl(ctl + 2) != 0u) { dead = 1u; return true; }
+    if ((spins & 63u) == 0u) {
+      if (const unsigned seen = gp_ld_ctl(ctl + 2); seen != 0u) {
+        // another workgroup's wait ran out -- in THIS launch, or in an earlier one whose device word could not be cleared yet (the
+        // host clears it when it reports the failure; during a graph capture it cannot).  Either way this launch's outputs are
+        // not valid: the host word says so again, so the call after this one reports it too (launches queued behind a
+        // failed one died silently once the first report had cleared the host word).
+        dead = 1u;
+        if (WS.err) __hip_atomic_store(WS.err, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
+      }
+    }
     if (spins <= kGruPipeSpinLimit) return false;
     dead = 1u;
     __hip_atomic_store(ctl + 2, what + unsigned(stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -556,12 +556,17 @@ static int stream_health(wekws_hip_model* m, hipStream_t stream) {
   if (!err_h) return WEKWS_HIP_OK;
   const unsigned code = *static_cast<volatile unsigned*>(err_h);
   if (!code) return WEKWS_HIP_OK;
-  *static_cast<volatile unsigned*>(err_h) = 0u;
+  // The host word is cleared only once the clear of the DEVICE word is really queued behind the launches that saw it (stream
+  // order): launches already queued behind the failed one still find the device word set, end at once and set the host word
+  // again -- the next call reports them too.  During a capture (or if the memset cannot be queued) both words stay: every call
+  // keeps failing until a call outside the capture can clear them.
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (ctl && !(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone))
-    (void)hipMemsetAsync(ctl + 2, 0, sizeof(unsigned), stream);
+  const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (ctl && !capturing && hipMemsetAsync(ctl + 2, 0, sizeof(unsigned), stream) == hipSuccess)
+    *static_cast<volatile unsigned*>(err_h) = 0u;
   return fail(WEKWS_HIP_EDEVICE, "a bounded wait of the GRU wavefront gave up (code 0x%x: %s of stage %u): the outputs of the "
-              "forwards issued on this stream since the last successful call are not valid", code,
+              "forwards issued on this stream since the last successful call -- including calls that returned OK while "
+              "the failed launch was still queued -- are not valid", code,
               (code >> 8) == 1 ? "data" : "credit", code & 0xffu);
 }
 

@@ -198,8 +198,11 @@ constexpr int kFbankFW = WEKWS_FBANK_FW;   // frames per wave, interleaved throu
 // instruction counts ~40 % vector, ~50 % LDS) but by the chain load -> butterfly -> store -> wave-level sync of every FFT
 // stage; with two independent frames between two syncs each lane has twice the work to cover the LDS round trips, the syncs
 // per frame halve, and the window / twiddle / mel-weight registers serve both frames.  Same arithmetic per frame, bit for bit.
+#ifndef WEKWS_FBANK_MINW
+#define WEKWS_FBANK_MINW 1
+#endif
 template <int ROUNDS, typename S>
-__global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
+__global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
                                                                  int B, int nsamp, int nframes,
                                                                  float* __restrict__ feats) {
   constexpr int FW = kFbankFW;
@@ -251,6 +254,28 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
   }
   // where the last stage puts its four outputs: X[64 m + rev3(lane)], natural order
   const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
+#ifndef WEKWS_FBANK_NO_ADDR
+  // Round 6: the swizzled strip positions of a lane are the same for every frame -- computed ONCE and held (made opaque, or the
+  // compiler re-derives them per frame: ~100 of the ~320 vector instructions of a frame were this address arithmetic).
+  int zpos[4][4];                                            // stage st exchanges elements base + k q (k = 0..3); stage 3 writes natural order
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int q = 64 >> (2 * st), blk = lane / q, j = lane - blk * q, base = blk * 4 * q + j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      zpos[st][k] = pz(base + k * q);
+      asm volatile("" : "+v"(zpos[st][k]));
+    }
+  }
+  int zout[4], upos[4], unpos[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    zout[m] = pz(64 * m + rev3);
+    upos[m] = pz(lane + 64 * m);
+    unpos[m] = pz((256 - (lane + 64 * m)) & 255);
+    asm volatile("" : "+v"(zout[m]), "+v"(upos[m]), "+v"(unpos[m]));
+  }
+#endif
 
   // Frame g of the launch is frame g % nframes of utterance g / nframes.  The wave walks g = g0, g0 + stride, ...: the pair
   // (utterance, frame) is carried and advanced by (stride / nframes, stride % nframes) with a carry -- round 3 divided a
@@ -343,12 +368,17 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
       const int L = 4 * q;                 // block size
       const int blk = lane / q, j = lane - blk * q;
       const int base = blk * L + j;
+      (void)base;
 #pragma unroll
       for (int w = 0; w < FW; ++w) {
         float2* const z = reinterpret_cast<float2*>(strip + w * kFbankStrip);
         float2 a0 = a[w][0], a1 = a[w][1], a2 = a[w][2], a3 = a[w][3];
         if (st > 0) {
+#ifndef WEKWS_FBANK_NO_ADDR
+          a0 = z[zpos[st][0]]; a1 = z[zpos[st][1]]; a2 = z[zpos[st][2]]; a3 = z[zpos[st][3]];
+#else
           a0 = z[pz(base)]; a1 = z[pz(base + q)]; a2 = z[pz(base + 2 * q)]; a3 = z[pz(base + 3 * q)];
+#endif
         }
         const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
         const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
@@ -363,11 +393,18 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
           o1 = cmul(o1, tws[st][0]);
           o2 = cmul(o2, tws[st][1]);
           o3 = cmul(o3, tws[st][2]);
-          z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
+#ifndef WEKWS_FBANK_NO_ADDR
+          z[zpos[st][0]] = o0; z[zpos[st][1]] = o1; z[zpos[st][2]] = o2; z[zpos[st][3]] = o3;
         } else {
           // positions 4 lane + m hold X[rev4(4 lane + m)] = X[64 m + rev3(lane)]: stored in natural order
+          z[zout[0]] = o0; z[zout[1]] = o1; z[zout[2]] = o2; z[zout[3]] = o3;
+        }
+#else
+          z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
+        } else {
           z[pz(rev3)] = o0; z[pz(64 + rev3)] = o1; z[pz(128 + rev3)] = o2; z[pz(192 + rev3)] = o3;
         }
+#endif
       }
       wave_sync();
     }
@@ -379,8 +416,14 @@ __global__ __launch_bounds__(64 * kFbankWaves) void fbank_kernel(const FbankPara
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int k = lane + 64 * m;
+#ifndef WEKWS_FBANK_NO_ADDR
+        const float2 zk = z[upos[m]];
+        const float2 zn = z[unpos[m]];
+        (void)k;
+#else
         const float2 zk = z[pz(k)];
         const float2 zn = z[pz((256 - k) & 255)];
+#endif
         const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const float2 o = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
         const float2 wo = cmul(twu[m], o);

@@ -96,7 +96,10 @@ constexpr int kGruPipeRingLog = 4, kGruPipeRing = 1 << kGruPipeRingLog;
 // control words (their own allocation per stream, zero when made, never re-allocated): [0] epoch, [1] workgroups done, [2] error,
 // [16 + 2 (slot * stages + stage)] 64-bit credits: {tag0, steps of this launch the stage's consumer has finished reading},
 // [16 + 2 slots * stages + slot * stages + stage] where the workgroup runs: tag0 << 4 | XCD
-constexpr int kGruPipeCtlWords = 16 + 3 * kGruPipeMaxSlots * kGruPipeStages;
+// [16 + 3 slots * stages + slot * stages + stage] round 6: "this recurrence stage has written the outputs of round r": tag0 + r
+//   (read only by the slot's non-finite workgroup, and only when a stream of the tile has a NaN / Inf input: below)
+constexpr int kGruPipeDoneWord = 16 + 3 * kGruPipeMaxSlots * kGruPipeStages;
+constexpr int kGruPipeCtlWords = 16 + 4 * kGruPipeMaxSlots * kGruPipeStages;
 constexpr size_t kGruPipeCtlBytes = (size_t(kGruPipeCtlWords) * 4 + 255) / 256 * 256;
 // Bound of ONE wait, in re-requests.  The first kGruPipeFastSpins are back to back (~0.5 .. 1 us each: a load's round trip);
 // from then on every re-request sleeps ~3 us first (s_sleep 100 = 6400 clocks), so the bound is 0.1 .. 0.2 s of EXECUTED
@@ -123,7 +126,13 @@ struct GruPipeWorkspace {
   float* sc;                    // [slot][T][16] time-packed tiles only: 1 / scale of the preprocessing output
   char* gi[kGruMaxLayers];      // granules [slot][kGruPipeRing][kGruPipeGiStep]: gate pre-activations of layer l
   char* hs[kGruMaxLayers];      // granules [region][T][kGruPipeHStep]: output sequence of layer l (l < L - 1)
+  const NfCtx* nf;              // round 6: streams with a NaN / Inf input are re-computed by the slot's non-finite workgroup
 };
+
+static __device__ __attribute__((noinline, unused)) void nf_repair_gru_call(const NfCtx* nf, const float* x, int64_t xs_b, const float* h0,
+                                                                            float* hn, float* y, int64_t ys_b, int B, int T, int b) {
+  nf_repair_gru(nf, x, xs_b, h0, hn, y, ys_b, B, T, b);
+}
 
 // measurement build (tools/probe/gru_stamps.py): 100 MHz wall-clock stamps of slot 0's stages, row k, step t
 #ifdef WEKWS_GRU_PIPE_STAMPS
@@ -308,9 +317,14 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   // producers first, and two launches that each got their producer half resident waited for consumers that had no CU
   // (their ring credits never came).
   const int nstg = 2 * Q.base.nlayers;
-  const int grp = blockIdx.x / (8 * nstg), gr = blockIdx.x - grp * (8 * nstg);
-  const int stage = gr >> 3, slot = grp * 8 + (gr & 7);
-  (void)slots_p;
+  // Round 6: behind the stage workgroups come `slots` NON-FINITE workgroups, one per slot (index = slots_p * stages + slot: the
+  // same XCD -- and L2 -- as the slot's stages).  Each looks at the features and incoming states of its slot's tiles while the
+  // pipeline runs; if they are all finite -- the normal case -- it is gone long before the pipeline is; if not, it waits for the
+  // slot's recurrence stages to finish the round and re-computes those streams (nonfinite.hip.h).  The stages never wait for it.
+  const bool nf_wg = WS.nf != nullptr && int(blockIdx.x) >= slots_p * nstg;
+  const int bx = nf_wg ? 0 : int(blockIdx.x);
+  const int grp = bx / (8 * nstg), gr = bx - grp * (8 * nstg);
+  const int stage = nf_wg ? nstg : gr >> 3, slot = nf_wg ? int(blockIdx.x) - slots_p * nstg : grp * 8 + (gr & 7);
   if (slot >= slots) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
@@ -336,12 +350,61 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
   // that nobody will read it again in this launch -- and no atomic round trip sits at the END of the launch, where a
   // 10-frame chunk would pay ~1 us for it.
   if (tid == 0) {
-    const unsigned nwg = unsigned(2 * P.nlayers * slots);
+    const unsigned nwg = unsigned((2 * P.nlayers + (WS.nf ? 1 : 0)) * slots);
     if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1u) {
       __hip_atomic_store(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned laps = unsigned((rounds * T - 1) >> RLOG) + 1u;   // a slot's steps are numbered g = round * T + t
+      unsigned laps = unsigned((rounds * T - 1) >> RLOG) + 1u;   // a slot's steps are numbered g = round * T + t
+      laps = laps < unsigned(rounds) ? unsigned(rounds) : laps;    // (the "round done" words are tag0 + round: unique across launches too)
       __hip_atomic_store(ctl, tag0 - 1u + laps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+  unsigned* const done_w = ctl + kGruPipeDoneWord + slot * kGruPipeStages;   // [stage] of this slot
+  auto round_tag = [&](int r) __attribute__((always_inline)) -> unsigned {
+    const unsigned v = tag0 + unsigned(r);
+    return v ? v : 0x80000000u;
+  };
+  if (nf_wg) {
+    __shared__ unsigned nfx_mask, nfx_ok;
+    int round = 0;
+#pragma unroll 1
+    for (int tile = slot; tile < tiles; tile += slots, ++round) {
+      const int b0 = tile * spw, nb = min(B, b0 + spw) - b0;
+      if (tid == 0) { nfx_mask = 0u; nfx_ok = 1u; }
+      __syncthreads();
+      const int per = T * idim;
+      unsigned mine = 0u;
+      for (int e = tid; e < nb * per; e += kThreads) {
+        const int sidx = e / per;
+        if (nf_bad(x[int64_t(b0) * per + e])) mine |= 1u << sidx;
+      }
+      if (h0)
+        for (int e = tid; e < L * nb * H; e += kThreads) {
+          const int lyr = e / (nb * H), rem = e - lyr * (nb * H), sidx = rem / H;
+          if (nf_bad(h0[(int64_t(lyr) * B + b0 + sidx) * H + (rem - sidx * H)])) mine |= 1u << sidx;
+        }
+      if (mine) atomicOr(&nfx_mask, mine);
+      __syncthreads();
+      const unsigned mask = unsigned(__builtin_amdgcn_readfirstlane(int(nfx_mask)));
+      if (!mask) continue;
+      // a stream of this tile has a NaN / Inf input: wait (bounded, like every wait of this kernel) until the slot's recurrence
+      // stages have written their outputs of this round -- garbage for that stream, its loads entered as 0 --, then write the
+      // reference's.  Same L2 as the stages (same XCD): their stores are there when their "round done" word is.
+      if (tid == 0) {
+        for (int lyr = 0; lyr < L && nfx_ok; ++lyr) {
+          unsigned spins = 0;
+          while (gp_ld_ctl(done_w + 2 * lyr + 1) != round_tag(round)) {
+            __builtin_amdgcn_s_sleep(100);
+            if (++spins > kGruPipeSpinLimit || gp_ld_ctl(ctl + 2) != 0u) { nfx_ok = 0u; break; }
+          }
+        }
+        if (!nfx_ok && WS.err) __hip_atomic_store(WS.err, 0x300u + unsigned(nstg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();
+      if (!__builtin_amdgcn_readfirstlane(int(nfx_ok))) return;
+      for (int sidx = 0; sidx < nb; ++sidx)
+        if (mask >> sidx & 1u) nf_repair_gru_call(WS.nf, x, int64_t(T) * idim, h0, hn, y, int64_t(T) * K, B, T, b0 + sidx);
+    }
+    return;
   }
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -1094,7 +1157,12 @@ __global__ __launch_bounds__(kThreads) void gru_pipe_kernel(const GruF16Params Q
           }
         }
       }
+      // (round 6) this stage's outputs of the round -- h_n, and y from the last layer -- are written: say so for the slot's
+      // non-finite workgroup.  Every thread's stores have been acknowledged (vmcnt(0)) before the barrier, the word follows it;
+      // the reader sits on this XCD, behind the same L2.  One store per round; nobody here waits for anything.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
+      if (WS.nf && tid == 0 && !dead) __hip_atomic_store(done_w + stage, round_tag(round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     // ===================== stage I_l (l >= 1): gi_l[t] = W_ih,l h_{l-1}[t] + b, every wave on its own =====================
@@ -1259,8 +1327,9 @@ inline int launch_gru_pipe(const GruF16Params& Q, const GruPipeWorkspace& ws, co
   auto kern = k2 ? (pk ? gru_pipe_kernel<2, true> : gru_pipe_kernel<2, false>) : (pk ? gru_pipe_kernel<4, true> : gru_pipe_kernel<4, false>);
   static_assert(kGruPipeLds >= int(G::LDS_BYTES), "staging buffers");
   if (grant_dynamic_lds(kern, kGruPipeLds, grant[(k2 ? 0 : 2) + (pk ? 1 : 0)])) return -3;
-  hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p), dim3(kThreads), kGruPipeLds, stream, Q, ws, x, B, T, h0, y, hn,
-                     g.tiles, g.slots, g.slots_p, g.spw);
+  // (+ one non-finite workgroup per slot behind the stage workgroups when the caller handed a context over: gru_pipe_kernel)
+  hipLaunchKernelGGL(kern, dim3(g.stages * g.slots_p + (ws.nf ? g.slots : 0)), dim3(kThreads), kGruPipeLds, stream, Q, ws, x, B, T, h0,
+                     y, hn, g.tiles, g.slots, g.slots_p, g.spw);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -1674,6 +1674,7 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     int rc = stream_health(m, stream);
     if (rc) return rc;
     float* user_h_out = nullptr;
+    bool gru_nf_in_kernel = false;
     if (m->user_hdim) {                                      // zero-padded hidden size: widened copies of the caller's states
       const size_t need = workspace_need(m, B, T);
       char* base = stream_workspace(m, stream, need);
@@ -1709,6 +1710,15 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
         ws.sc = reinterpret_cast<float*>(ws.seq_top + pb.seq);
         for (int l = 0; l < d.num_layers; ++l) { ws.gi[l] = gran; gran += pb.gi; }
         for (int l = 0; l + 1 < d.num_layers; ++l) { ws.hs[l] = gran; gran += pb.hs; }
+        // Non-finite pass: the wavefront's own extra workgroups (one per slot) where there are CUs left for them to run BESIDE the
+        // pipeline -- streaming chunks, small batches: no second launch, 2.68 -> 2.48 us per frame at B = 1 --; where the stage
+        // workgroups fill the device they would only start behind it and scan 16 streams each (measured at B = 1024 x 98:
+        // 0.186 ms against 0.176 with the separate launch, whose 1024 small workgroups scan in parallel): the launch stays.
+        static const bool nf_in_kernel_off = [] { const char* e = std::getenv("WEKWS_GRU_NF_IN_KERNEL"); return e && e[0] == '0'; }();   // (A/B aid)
+        if (!nf_in_kernel_off && (geo.stages + 1) * geo.slots <= m->fsmn_cus) {
+          ws.nf = m->nf_dev;
+          gru_nf_in_kernel = true;
+        }
         rc = wekws::launch_gru_pipe(m->gq, ws, x, B, T, in_cache, y, out_cache, m->fsmn_cus, stream);
       } else {
         wekws::gru_f16_workspace_bytes(B, T, m->fsmn_cus, &seq_b, &gi_b, &sc_b);
@@ -1722,8 +1732,10 @@ int wekws_hip_forward(wekws_hip_model* m, const float* x, int B, int T, const fl
     }
     if (rc) return fail(rc, "gru launch failed: %s", hipGetErrorString(hipGetLastError()));
     // streams with a NaN / Inf feature or state (their loads entered the kernels above as 0): the reference's arithmetic
-    hipLaunchKernelGGL(wekws::gru_nf_fix_kernel, dim3(B), dim3(256), 0, stream, m->nf_dev, x, B, T, in_cache, out_cache, y);
-    if (hipGetLastError() != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "gru non-finite pass: launch failed");
+    if (!gru_nf_in_kernel) {                                 // (the layer-major and exact-f32 kernels: their own launch behind them)
+      hipLaunchKernelGGL(wekws::gru_nf_fix_kernel, dim3(B), dim3(256), 0, stream, m->nf_dev, x, B, T, in_cache, out_cache, y);
+      if (hipGetLastError() != hipSuccess) return fail(WEKWS_HIP_EDEVICE, "gru non-finite pass: launch failed");
+    }
     if (user_h_out) {
       const size_t ue = size_t(d.num_layers) * B * m->user_hdim;
       const int grid = int(std::min<size_t>((ue + 255) / 256, 4096));

@@ -185,6 +185,103 @@ __device__ __forceinline__ float fb_wave_sum(float s) {
   s += fb_dppx<0x143, 0xc, false>(s);                       // row_bcast:31 -> rows 2 and 3 take in row 1: lane 63 holds the sum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
 }
+// ---- round 6: the butterflies as PACKED f32 instructions, written out.  A complex value is one 64-bit register pair and every
+// complex operation of the transform is one or two v_pk_*_f32 with the right op_sel / neg modifiers: -i (a1 - a3) is an operand
+// swap + one sign inside the add that consumes it, a complex product is v_pk_mul + v_pk_fma.  The compiler's own lowering of the
+// float2 source found the packed adds but built a complex product from v_pk_mov (swap the twiddle) + v_pk_mul + TWO v_pk_fma (one
+// per sign pattern) + a v_mov to pick a half of each, and transposed the inputs of the first stages through v_mov / v_pk_mov pairs:
+// 32 instead of 14 vector instructions per twiddled butterfly, 78 register moves per frame (ISA of round 6a).
+// gfx940+ forwarding hazard: the result of a packed (VOP3P) instruction must not be read by the very next VALU instruction
+// (LLVM's hasDstSelForwardingHazard: it puts an s_nop 0 there itself -- but cannot look into an asm block).  Inside the blocks
+// dependent instructions are >= 2 apart; every block starts and ends with an s_nop 0 for the instructions around it.
+typedef float fb_f2 __attribute__((ext_vector_type(2)));
+#define FB_SUB " neg_lo:[0,1] neg_hi:[0,1]"
+#define FB_CMUL1(r, a, w) "v_pk_mul_f32 %[" #r "], %[" #a "], %[" #w "] op_sel_hi:[0,1]\n\t"
+#define FB_CMUL2(r, a, w) "v_pk_fma_f32 %[" #r "], %[" #a "], %[" #w "], %[" #r "] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+// radix-4 DIF butterfly: o0 = a0 + a1 + a2 + a3, r1 = w1 (a0 - i a1 - a2 + i a3), r2 = w2 (a0 - a1 + a2 - a3), r3 = w3 (a0 + i a1 - a2 - i a3)
+// Registers are re-used by hand (an asm block's early-clobber outputs cannot share registers with its inputs, and the kernel lives
+// at 128): a0 -> t0 -> o2, a1 -> t2 -> r3, a2 -> o1, a3 -> o3, n1 = t1 -> o0, n2 = d -> r1, n3 = r2: seven pairs.
+template <bool TW>
+__device__ __forceinline__ void fb_bfly(fb_f2 a0, fb_f2 a1, fb_f2 a2, fb_f2 a3, fb_f2 w1, fb_f2 w2, fb_f2 w3,
+                                        fb_f2& o0, fb_f2& r1, fb_f2& r2, fb_f2& r3) {
+  fb_f2 n1, n2, n3;
+  if constexpr (TW) {
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[n1], %[a0], %[a2]" FB_SUB "\n\t"                                     // t1
+        "v_pk_add_f32 %[n2], %[a1], %[a3]" FB_SUB "\n\t"                                     // d
+        "v_pk_add_f32 %[a0], %[a0], %[a2]\n\t"                                               // t0
+        "v_pk_add_f32 %[a1], %[a1], %[a3]\n\t"                                               // t2
+        "v_pk_add_f32 %[a2], %[n1], %[n2] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"      // o1 = t1 + (d.y, -d.x)
+        "v_pk_add_f32 %[a3], %[n1], %[n2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"      // o3 = t1 - (d.y, -d.x)
+        "v_pk_add_f32 %[n1], %[a0], %[a1]\n\t"                                               // o0
+        "v_pk_add_f32 %[a0], %[a0], %[a1]" FB_SUB "\n\t"                                     // o2
+        FB_CMUL1(n2, a2, w1) FB_CMUL1(a1, a3, w3) FB_CMUL1(n3, a0, w2)
+        FB_CMUL2(n2, a2, w1) FB_CMUL2(a1, a3, w3) FB_CMUL2(n3, a0, w2)
+        "s_nop 0"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3)
+        : [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3));
+    o0 = n1; r1 = n2; r2 = n3; r3 = a1;
+  } else {
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[n1], %[a0], %[a2]" FB_SUB "\n\t"
+        "v_pk_add_f32 %[n2], %[a1], %[a3]" FB_SUB "\n\t"
+        "v_pk_add_f32 %[a0], %[a0], %[a2]\n\t"
+        "v_pk_add_f32 %[a1], %[a1], %[a3]\n\t"
+        "v_pk_add_f32 %[a2], %[n1], %[n2] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[a3], %[n1], %[n2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[n1], %[a0], %[a1]\n\t"
+        "v_pk_add_f32 %[a0], %[a0], %[a1]" FB_SUB "\n\t"
+        "s_nop 0"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [n1] "=&v"(n1), [n2] "=&v"(n2));
+    o0 = n1; r1 = a2; r2 = a0; r3 = a3;
+  }
+}
+// real-FFT untangle of TWO bins (fbank.h:173-175): X[k] = (Zk + conj(Zn)) / 2 - i w^k (Zk - conj(Zn)) / 2, n = 256 - k, with
+// wh = w^k / 2 (exact): e = Zk + conj(Zn), o = Zk - conj(Zn), wo = wh o, X = e / 2 + (wo.y, -wo.x): 5 packed instructions per bin
+// (the float2 source compiled to 14 plain ones).  ROT: the twiddle is -i wh = (wh.y, -wh.x) -- w^(k + 128) = -i w^k, so the bins
+// k + 128 take their twiddles from the registers of the bins k with other operand selects.  zk -> e -> X, zn -> wo.
+#define FB_UNT(zk, zn, o, wh)                                                                                          \
+  "v_pk_add_f32 %[" #o "], %[" #zk "], %[" #zn "] neg_lo:[0,1]\n\t"                                                    \
+  "v_pk_add_f32 %[" #zk "], %[" #zk "], %[" #zn "] neg_hi:[0,1]\n\t"
+template <bool ROT>
+__device__ __forceinline__ void fb_untangle2(fb_f2 zka, fb_f2 zna, fb_f2 wha, fb_f2 zkb, fb_f2 znb, fb_f2 whb, fb_f2& xa, fb_f2& xb) {
+  fb_f2 oa, ob;
+  if constexpr (!ROT) {
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[oa], %[zka], %[zna] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[ob], %[zkb], %[znb] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[zka], %[zka], %[zna] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[zkb], %[zkb], %[znb] neg_hi:[0,1]\n\t"
+        FB_CMUL1(zna, wha, oa) FB_CMUL1(znb, whb, ob)
+        FB_CMUL2(zna, wha, oa) FB_CMUL2(znb, whb, ob)
+        "v_pk_fma_f32 %[zka], %[zka], 0.5, %[zna] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f32 %[zkb], %[zkb], 0.5, %[znb] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : [zka] "+v"(zka), [zna] "+v"(zna), [zkb] "+v"(zkb), [znb] "+v"(znb), [oa] "=&v"(oa), [ob] "=&v"(ob)
+        : [wha] "v"(wha), [whb] "v"(whb));
+  } else {
+    // w' = (w.y, -w.x):  w' o = (w.y o.x + w.x o.y, w.y o.y - w.x o.x)
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[oa], %[zka], %[zna] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[ob], %[zkb], %[znb] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[zka], %[zka], %[zna] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[zkb], %[zkb], %[znb] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[zna], %[wha], %[oa] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[znb], %[whb], %[ob] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %[zna], %[wha], %[oa], %[zna] op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[znb], %[whb], %[ob], %[znb] op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[zka], %[zka], 0.5, %[zna] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f32 %[zkb], %[zkb], 0.5, %[znb] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : [zka] "+v"(zka), [zna] "+v"(zna), [zkb] "+v"(zkb), [znb] "+v"(znb), [oa] "=&v"(oa), [ob] "=&v"(ob)
+        : [wha] "v"(wha), [whb] "v"(whb));
+  }
+  xa = zka; xb = zkb;
+}
+#undef FB_UNT
+#undef FB_SUB
+#undef FB_CMUL1
+#undef FB_CMUL2
 #ifndef WEKWS_FBANK_FW
 #define WEKWS_FBANK_FW 1
 #endif
@@ -214,6 +311,7 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
   const float2* tw512 = reinterpret_cast<const float2*>(tab + 512);
   const float* win = tab + 1024;
   const int FL = P.frame_length;
+  const float inv_fl = 1.f / float(FL);
 
   // ---- per-lane constants of the whole launch (registers): window of its 8 samples, stage twiddles, untangle twiddles,
   //      scatter targets of its 4 FFT bins
@@ -224,16 +322,22 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
     wn[2 * m] = win[2 * n];
     wn[2 * m + 1] = win[2 * n + 1];
   }
-  float2 tws[3][3];                                         // stages 0..2: w^j, w^2j, w^3j of the stage's block size
+  fb_f2 tws[3][3];                                          // stages 0..2: w^j, w^2j, w^3j of the stage's block size
 #pragma unroll
   for (int st = 0; st < 3; ++st) {
     const int q = 64 >> (2 * st), L = 4 * q, j = lane % q, tstep = 256 / L;
 #pragma unroll
-    for (int r = 1; r <= 3; ++r) tws[st][r - 1] = tw256[(r * j * tstep) & 255];
+    for (int r = 1; r <= 3; ++r) {
+      const float2 t = tw256[(r * j * tstep) & 255];
+      tws[st][r - 1] = fb_f2{t.x, t.y};
+    }
   }
-  float2 twu[4];
+  fb_f2 twh[2];                                             // untangle twiddles of bins lane, lane + 64, halved (exact); + 128: -i times these
 #pragma unroll
-  for (int m = 0; m < 4; ++m) twu[m] = tw512[lane + 64 * m];
+  for (int m = 0; m < 2; ++m) {
+    const float2 t = tw512[lane + 64 * m];
+    twh[m] = fb_f2{0.5f * t.x, 0.5f * t.y};
+  }
   // mel slots of this lane: first FFT bin, mel bin, 16 weights (zero padded)
   int sfirst[ROUNDS], sbin[ROUNDS], scount[ROUNDS];          // scount: slots of the filter if this slot is its first, else 0
   float sw[ROUNDS][16];
@@ -254,7 +358,6 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
   }
   // where the last stage puts its four outputs: X[64 m + rev3(lane)], natural order
   const int rev3 = ((lane & 3) << 4) | (lane & 12) | (lane >> 4);
-#ifndef WEKWS_FBANK_NO_ADDR
   // Round 6: the swizzled strip positions of a lane are the same for every frame -- computed ONCE and held (made opaque, or the
   // compiler re-derives them per frame: ~100 of the ~320 vector instructions of a frame were this address arithmetic).
   int zpos[4][4];                                            // stage st exchanges elements base + k q (k = 0..3); stage 3 writes natural order
@@ -267,15 +370,14 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
       asm volatile("" : "+v"(zpos[st][k]));
     }
   }
-  int zout[4], upos[4], unpos[4];
+  int zout[4], unpos[4];
+  const int (&upos)[4] = zpos[0];                           // (stage 0 writes elements lane + 64 k: the untangle's own bins)
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     zout[m] = pz(64 * m + rev3);
-    upos[m] = pz(lane + 64 * m);
     unpos[m] = pz((256 - (lane + 64 * m)) & 255);
-    asm volatile("" : "+v"(zout[m]), "+v"(upos[m]), "+v"(unpos[m]));
+    asm volatile("" : "+v"(zout[m]), "+v"(unpos[m]));
   }
-#endif
 
   // Frame g of the launch is frame g % nframes of utterance g / nframes.  The wave walks g = g0, g0 + stride, ...: the pair
   // (utterance, frame) is carried and advanced by (stride / nframes, stride % nframes) with a carry -- round 3 divided a
@@ -287,7 +389,9 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
   int ub = int(f_first / nframes), ufr = int(f_first - int64_t(ub) * nframes);     // of the wave's CURRENT first frame
   // the sample pairs of a wave's NEXT frames are requested before the current ones are processed
   float2 vn[FW][4];
-  const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % (2 * sizeof(S)) == 0);
+  // even frame length and shift, aligned buffer: every element is one aligned pair inside or outside the frame -- loads under a lane
+  // mask, no branches (round 6: the general form below compiled to 25 branches per frame)
+  const bool pair_ok = (nsamp % 2 == 0) && (P.frame_shift % 2 == 0) && (FL % 2 == 0) && (reinterpret_cast<uintptr_t>(pcm) % (2 * sizeof(S)) == 0);
   auto fetch = [&](int b0, int fr0) __attribute__((always_inline)) {
 #pragma unroll
     for (int w = 0; w < FW; ++w) {
@@ -295,24 +399,32 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
       if (fr >= nframes) { fr -= nframes; ++b; }             // (FW <= nframes: at most one carry)
       const bool live = b < B;
       const S* src = pcm + int64_t(b) * nsamp + int64_t(fr) * P.frame_shift;
+      if (pair_ok) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int i = 2 * (lane + 64 * m);
-        float2 v = make_float2(0.f, 0.f);
-        if (live) {
-          if (pair_ok && i + 1 < FL) {
-            if constexpr (sizeof(S) == 4) {
-              v = *reinterpret_cast<const float2*>(src + i);
-            } else {
-              const short2 q = *reinterpret_cast<const short2*>(src + i);
-              v = make_float2(float(q.x), float(q.y));
-            }
+        for (int m = 0; m < 4; ++m) {
+          const int i = 2 * (lane + 64 * m);
+          const bool in = live && i < FL;
+          const S* at = in ? src + i : pcm;                   // (outside: any valid pair, dropped)
+          float2 v;
+          if constexpr (sizeof(S) == 4) {
+            v = *reinterpret_cast<const float2*>(at);
           } else {
+            const short2 q = *reinterpret_cast<const short2*>(at);
+            v = make_float2(float(q.x), float(q.y));
+          }
+          vn[w][m] = in ? v : make_float2(0.f, 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int i = 2 * (lane + 64 * m);
+          float2 v = make_float2(0.f, 0.f);
+          if (live) {
             if (i < FL) v.x = float(src[i]);
             if (i + 1 < FL) v.y = float(src[i + 1]);
           }
+          vn[w][m] = v;
         }
-        vn[w][m] = v;
       }
     }
   };
@@ -342,7 +454,7 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
     float2 a[FW][4];
 #pragma unroll
     for (int w = 0; w < FW; ++w) {
-      const float mu = mean[w] / float(FL);
+      const float mu = mean[w] * inv_fl;   // (one rounding away from the quotient; the sum's order differs from the reference's serial one anyway)
       // (no range masks: samples past the frame were fetched as zeros and their window values ARE zero -- whatever the
       //  mean subtraction and the pre-emphasis make of them is multiplied away; round 3 spent 27 selects per frame on them)
 #pragma unroll
@@ -361,74 +473,42 @@ __global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kern
         a[w][m].y = (xo - 0.97f * xe) * wn[2 * m + 1];
       }
     }
-    // ---- 256-point complex FFT, radix-4 DIF, 4 stages; both frames between two syncs
+    // ---- 256-point complex FFT, radix-4 DIF, 4 stages (stage st exchanges elements q = 64 >> 2 st apart)
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const int q = 64 >> (2 * st);        // quarter size: 64, 16, 4, 1
-      const int L = 4 * q;                 // block size
-      const int blk = lane / q, j = lane - blk * q;
-      const int base = blk * L + j;
-      (void)base;
 #pragma unroll
       for (int w = 0; w < FW; ++w) {
-        float2* const z = reinterpret_cast<float2*>(strip + w * kFbankStrip);
-        float2 a0 = a[w][0], a1 = a[w][1], a2 = a[w][2], a3 = a[w][3];
+        fb_f2* const z = reinterpret_cast<fb_f2*>(strip + w * kFbankStrip);
+        fb_f2 a0, a1, a2, a3, o0, o1, o2, o3;
         if (st > 0) {
-#ifndef WEKWS_FBANK_NO_ADDR
           a0 = z[zpos[st][0]]; a1 = z[zpos[st][1]]; a2 = z[zpos[st][2]]; a3 = z[zpos[st][3]];
-#else
-          a0 = z[pz(base)]; a1 = z[pz(base + q)]; a2 = z[pz(base + 2 * q)]; a3 = z[pz(base + 3 * q)];
-#endif
+        } else {
+          a0 = fb_f2{a[w][0].x, a[w][0].y}; a1 = fb_f2{a[w][1].x, a[w][1].y};
+          a2 = fb_f2{a[w][2].x, a[w][2].y}; a3 = fb_f2{a[w][3].x, a[w][3].y};
         }
-        const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y);
-        const float2 t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
-        const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
-        const float2 d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-        const float2 t3 = make_float2(d13.y, -d13.x);  // -i * (a1 - a3)
-        float2 o0 = make_float2(t0.x + t2.x, t0.y + t2.y);
-        float2 o1 = make_float2(t1.x + t3.x, t1.y + t3.y);
-        float2 o2 = make_float2(t0.x - t2.x, t0.y - t2.y);
-        float2 o3 = make_float2(t1.x - t3.x, t1.y - t3.y);
         if (st < 3) {
-          o1 = cmul(o1, tws[st][0]);
-          o2 = cmul(o2, tws[st][1]);
-          o3 = cmul(o3, tws[st][2]);
-#ifndef WEKWS_FBANK_NO_ADDR
+          fb_bfly<true>(a0, a1, a2, a3, tws[st][0], tws[st][1], tws[st][2], o0, o1, o2, o3);
           z[zpos[st][0]] = o0; z[zpos[st][1]] = o1; z[zpos[st][2]] = o2; z[zpos[st][3]] = o3;
         } else {
           // positions 4 lane + m hold X[rev4(4 lane + m)] = X[64 m + rev3(lane)]: stored in natural order
+          fb_bfly<false>(a0, a1, a2, a3, a0, a0, a0, o0, o1, o2, o3);
           z[zout[0]] = o0; z[zout[1]] = o1; z[zout[2]] = o2; z[zout[3]] = o3;
         }
-#else
-          z[pz(base)] = o0; z[pz(base + q)] = o1; z[pz(base + 2 * q)] = o2; z[pz(base + 3 * q)] = o3;
-        } else {
-          z[pz(rev3)] = o0; z[pz(64 + rev3)] = o1; z[pz(128 + rev3)] = o2; z[pz(192 + rev3)] = o3;
-        }
-#endif
       }
       wave_sync();
     }
-    // ---- real-FFT untangle + power (fbank.h:173-175): X[k] = (Zk + conj(Zn))/2 - i w^k (Zk - conj(Zn))/2
+    // ---- real-FFT untangle + power (fbank.h:173-175)
     float pw[FW][4];
 #pragma unroll
     for (int w = 0; w < FW; ++w) {
-      const float2* const z = reinterpret_cast<const float2*>(strip + w * kFbankStrip);
+      const fb_f2* const z = reinterpret_cast<const fb_f2*>(strip + w * kFbankStrip);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int k = lane + 64 * m;
-#ifndef WEKWS_FBANK_NO_ADDR
-        const float2 zk = z[upos[m]];
-        const float2 zn = z[unpos[m]];
-        (void)k;
-#else
-        const float2 zk = z[pz(k)];
-        const float2 zn = z[pz((256 - k) & 255)];
-#endif
-        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        const float2 o = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-        const float2 wo = cmul(twu[m], o);
-        const float xr = e.x + wo.y, xi = e.y - wo.x;  // e - i*wo
-        pw[w][m] = xr * xr + xi * xi;
+      for (int m = 0; m < 4; m += 2) {
+        fb_f2 xa, xb;
+        if (m == 0) fb_untangle2<false>(z[upos[0]], z[unpos[0]], twh[0], z[upos[1]], z[unpos[1]], twh[1], xa, xb);
+        else fb_untangle2<true>(z[upos[2]], z[unpos[2]], twh[0], z[upos[3]], z[unpos[3]], twh[1], xa, xb);
+        pw[w][m] = xa.x * xa.x + xa.y * xa.y;
+        pw[w][m + 1] = xb.x * xb.x + xb.y * xb.y;
       }
     }
     wave_sync();                                          // every lane has read its Z values: the strips are free

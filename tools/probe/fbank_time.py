@@ -11,8 +11,9 @@ from wekws_amd.frontend import Fbank  # noqa: E402
 from wekws_amd.utils import synth  # noqa: E402
 
 dev = torch.device("cuda", 0)
+NB = int(os.environ.get("FBANK_BINS", "40"))
 for B in (1024, 8192):
-    fb = Fbank(num_bins=40, device=dev)
+    fb = Fbank(num_bins=NB, device=dev)
     pcm = torch.from_numpy(synth.synth_pcm(B, 16000, seed=0, kind="noise")).to(dev)
     for _ in range(200):
         fb(pcm)
@@ -26,4 +27,4 @@ for B in (1024, 8192):
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) / 50 * 1e3)
-    print(os.environ.get("WEKWS_HIP_LIB", "product"), f"B={B}: median {np.median(ts):.1f} us  min {min(ts):.1f}", flush=True)
+    print(os.environ.get("WEKWS_HIP_LIB", "product"), f"bins={NB} B={B}: median {np.median(ts):.1f} us  min {min(ts):.1f}", flush=True)

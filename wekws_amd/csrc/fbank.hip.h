@@ -295,11 +295,10 @@ constexpr int kFbankFW = WEKWS_FBANK_FW;   // frames per wave, interleaved throu
 // instruction counts ~40 % vector, ~50 % LDS) but by the chain load -> butterfly -> store -> wave-level sync of every FFT
 // stage; with two independent frames between two syncs each lane has twice the work to cover the LDS round trips, the syncs
 // per frame halve, and the window / twiddle / mel-weight registers serve both frames.  Same arithmetic per frame, bit for bit.
-#ifndef WEKWS_FBANK_MINW
-#define WEKWS_FBANK_MINW 1
-#endif
+// (two slot rounds -- 80 mel bins: 140 registers = three waves per SIMD; capped at 128 = four, 24 bytes of scratch: 548 -> 528 us per
+//  8192 x 1 s, round 6.  Three rounds would spill 136 bytes: left alone.)
 template <int ROUNDS, typename S>
-__global__ __launch_bounds__(64 * kFbankWaves, WEKWS_FBANK_MINW) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
+__global__ __launch_bounds__(64 * kFbankWaves, ROUNDS == 2 ? 4 : 1) void fbank_kernel(const FbankParams P, const S* __restrict__ pcm,
                                                                  int B, int nsamp, int nframes,
                                                                  float* __restrict__ feats) {
   constexpr int FW = kFbankFW;

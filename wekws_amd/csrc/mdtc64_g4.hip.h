@@ -165,6 +165,9 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
   __shared__ __attribute__((aligned(16))) float taps[2][C * 8];   // taps + bias records of the current / next block
+#ifdef WEKWS_G4_STAGGER                                     // (experiment: co-resident workgroups start out of phase)
+  for (int k = int((blockIdx.x >> 8) & 3u) * WEKWS_G4_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(16);
+#endif
   amax_zero<NTHR>(amax_cells, kAmaxCells);
   stage_block_table<NTHR>(blk, P.blocks, P.nblocks);
   // taps of a block: C * 32 bytes copied from the weight image straight into LDS by waves 0 (and 1) (global_load_lds); nobody waits

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
   __shared__ AmaxCell amax_cells[kAmaxCells];
   __shared__ BlockDesc blk[kAmaxMaxBlocks];
   __shared__ __attribute__((aligned(16))) float taps[2][C * 8];   // taps + bias records of the current / next block
-#ifdef WEKWS_G4_STAGGER                                     // (experiment: co-resident workgroups start out of phase)
+#ifdef WEKWS_G4_STAGGER                                     // (A/B builds only, DESIGN.md 3.1b: co-resident workgroups start out of phase)
   for (int k = int((blockIdx.x >> 8) & 3u) * WEKWS_G4_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(16);
 #endif
   amax_zero<NTHR>(amax_cells, kAmaxCells);

@@ -1,0 +1,68 @@
+"""CPU: the built library must not contain the packed-f32 operand-select pattern that gfx950 gets wrong beside MFMA waves.
+
+wekws_amd/csrc/pk_safe.hip.h (measured with tools/probe/pk_opsel_probe4.hip / probe5 on MI355X): a v_pk_fma_f32 / v_pk_mul_f32 /
+v_pk_add_f32 whose LOW result is formed from src0's low half and src1's HIGH half (op_sel:[0,1,...]), both vector registers, returns
+lanes 48..63 of that result without src1's contribution whenever other waves of the SIMD issue MFMAs -- the cause of ds64_g4's "rare
+wrong posteriors" of rounds 4-6.  The compiler emits the form on its own (SLP-vectorised FMA chains), so the check is made on what
+was actually built: every gfx950 code object inside libwekws_hip.so is disassembled and scanned."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "wekws_amd", "lib", "libwekws_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(blob):
+    """gfx950 ELF images of every clang offload bundle in the file (one bundle per translation unit)."""
+    at = blob.find(MAGIC)
+    while at >= 0:
+        (n,) = struct.unpack_from("<Q", blob, at + len(MAGIC))
+        pos = at + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, idlen = struct.unpack_from("<QQQ", blob, pos)
+            ident = blob[pos + 24:pos + 24 + idlen].decode()
+            pos += 24 + idlen
+            if "gfx950" in ident and size:
+                yield blob[at + off:at + off + size]
+        at = blob.find(MAGIC, at + 1)
+
+
+def hazardous(disassembly):
+    bad = []
+    for line in disassembly.splitlines():
+        m = re.search(r"\bv_pk_(fma|mul|add)_f32\s+(\S+), (\S+), (\S+)", line)
+        s = re.search(r"op_sel:\[([01]),([01])", line)
+        if m and s and s[1] == "0" and s[2] == "1" and m[3].startswith("v") and m[4].startswith("v"):
+            bad.append(line.strip())
+    return bad
+
+
+def test_scanner_recognises_the_pattern():
+    assert hazardous("  v_pk_fma_f32 v[6:7], v[0:1], v[40:41], v[6:7] op_sel:[0,1,0]  // 000: AA")
+    assert hazardous("v_pk_add_f32 v[44:45], v[46:47], v[48:49] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+    assert not hazardous("v_pk_fma_f32 v[6:7], v[40:41], v[0:1], v[6:7] op_sel:[1,0,0]")          # the mirror pattern is fine
+    assert not hazardous("v_pk_mul_f32 v[8:9], s[42:43], v[4:5] op_sel:[0,1] op_sel_hi:[0,1]")    # a scalar operand is fine
+    assert not hazardous("v_pk_mul_f32 v[8:9], v[2:3], v[4:5] op_sel_hi:[0,1]")                   # high results are fine
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="library not built or llvm-objdump missing")
+def test_no_hazardous_packed_f32_instruction_in_the_built_library(tmp_path):
+    blob = open(LIB, "rb").read()
+    objs = list(code_objects(blob))
+    assert len(objs) >= 10, "one gfx950 code object per translation unit expected"
+    bad, npk = [], 0
+    for i, co in enumerate(objs):
+        path = tmp_path / f"co{i}.elf"
+        path.write_bytes(co)
+        dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(path)], capture_output=True, text=True, check=True).stdout
+        npk += len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", dis))
+        bad += hazardous(dis)
+    assert npk > 1000, "the disassembly should show the library's packed-f32 instructions"
+    assert not bad, f"{len(bad)} packed-f32 instructions with op_sel:[0,1,..] on vector registers, e.g. {bad[:3]}"

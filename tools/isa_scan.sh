@@ -1,0 +1,26 @@
+#!/bin/bash
+# Development tool: compile every translation unit of the library to gfx950 assembly (build/isa/) and list the packed-f32 instructions
+# with the operand-select pattern of wekws_amd/csrc/pk_safe.hip.h (the test of record works on the built library: tests/test_isa_hazard.py).
+cd "$(dirname "$0")/.."
+mkdir -p build/isa && rm -f build/isa/*.s
+for f in wekws_amd/csrc/*.hip; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 --cuda-device-only -S -o build/isa/$(basename ${f%.hip}).s $f 2> /dev/null &
+done
+wait
+python3 - <<'PY'
+import glob, re
+tot = 0
+for path in sorted(glob.glob('build/isa/*.s')):
+    kern = None
+    for line in open(path):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            kern = m[1]
+            continue
+        m = re.match(r'\s+v_pk_(fma|mul|add)_f32\s+(\S+), (\S+), (\S+)', line)
+        s = re.search(r'op_sel:\[([01]),([01])', line)
+        if m and s and s[1] == '0' and s[2] == '1' and m[3].startswith('v') and m[4].startswith('v'):
+            tot += 1
+            print(path, kern[:80], line.strip())
+print("hazardous packed-f32 instructions:", tot)
+PY

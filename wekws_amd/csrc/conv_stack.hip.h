@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "nonfinite.hip.h"
+#include "pk_safe.hip.h"
 
 namespace wekws {
 

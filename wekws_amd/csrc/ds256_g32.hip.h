@@ -277,13 +277,12 @@ __global__ __launch_bounds__(kW16Threads) void ds256_g32_kernel(const StackParam
       const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0);
       if (b + int(gridDim.x) < A.B) prefetch_x(b + gridDim.x);   // (behind the classifier rows: loads return in order)
       float* dst = part + (wave * 4 + lq) * PS + 2 * NT * l15;
+      const HeadPairs hw(w0, w1);                            // (packed, operand selects spelled out: pk_safe.hip.h)
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        float p0 = w0.x * hv[tt][0], p1 = w1.x * hv[tt][0];
-        p0 = fmaf(w0.y, hv[tt][1], p0); p1 = fmaf(w1.y, hv[tt][1], p1);
-        p0 = fmaf(w0.z, hv[tt][2], p0); p1 = fmaf(w1.z, hv[tt][2], p1);
-        p0 = fmaf(w0.w, hv[tt][3], p0); p1 = fmaf(w1.w, hv[tt][3], p1);
-        *reinterpret_cast<float2*>(dst + 2 * tt) = float2{p0, p1};
+        pk_f32x2 pp{0.f, 0.f};
+        head_fma4(pp, hw.x, hw.y, hw.z, hw.w, hv[tt]);
+        *reinterpret_cast<float2*>(dst + 2 * tt) = float2{pp.x, pp.y};
       }
     }
     __syncthreads();

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                         // the feature maximum is published
+#ifdef WEKWS_D64_EARLY                                        // (diagnosis builds only: the placement that brings the rare wrong posteriors back)
+    if (amax_inputs_bad(amax_cells)) { nf_repair_call(A, blockIdx.x); return; }
+#endif
     float cpre;
     const float sx = pow2_scale(amax_read(amax_cells), &cpre);
     for (int k0 = 0; k0 < nk; k0 += 2) {
@@ -261,15 +264,20 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
       const int K = P.odim;
       const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0b);
       const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0b);
+      const HeadPairs hw(w0, w1);                            // (packed, operand selects spelled out: pk_safe.hip.h)
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        float p0 = 0.f, p1 = 0.f;
-        p0 = fmaf(w0.x, hv[tt][0], p0); p1 = fmaf(w1.x, hv[tt][0], p1);
-        p0 = fmaf(w0.y, hv[tt][1], p0); p1 = fmaf(w1.y, hv[tt][1], p1);
-        p0 = fmaf(w0.z, hv[tt][2], p0); p1 = fmaf(w1.z, hv[tt][2], p1);
-        p0 = fmaf(w0.w, hv[tt][3], p0); p1 = fmaf(w1.w, hv[tt][3], p1);
-        yp[tt][0] = p0; yp[tt][1] = p1;
+        pk_f32x2 pp{0.f, 0.f};
+        head_fma4(pp, hw.x, hw.y, hw.z, hw.w, hv[tt]);
+        yp[tt][0] = pp.x; yp[tt][1] = pp.y;
       }
+#ifdef WEKWS_D64_DUMP                                         // (diagnosis builds only: the head's inputs and partial sums over the returned cache)
+      if (A.out_cache) {
+        float* dbg = A.out_cache + int64_t(b) * C * Pc + threadIdx.x * 16;
+        dbg[0] = yp[0][0]; dbg[1] = yp[0][1]; dbg[2] = hv[0][0]; dbg[3] = hv[0][1]; dbg[4] = hv[0][2]; dbg[5] = hv[0][3];
+        dbg[6] = w0.x; dbg[7] = w0.y; dbg[8] = w0.z; dbg[9] = w0.w; dbg[10] = yp[1][0]; dbg[11] = yp[1][1];
+      }
+#endif
     }
   }
   // ---- keyword head (per-frame linear, one or two outputs; classifier.py:63-67): the 16 partial sums per output (4 waves x 4
@@ -288,6 +296,12 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
     const int t = (th >> 1) - off, k = th & 1;               // thread = (column, output)
     if (th < 2 * TT && t >= 0 && t < T && k < K) {
       float v = W[P.head_b + k];
+#ifdef WEKWS_D64_DUMP
+      if (A.out_cache && th < 28) {                            // columns 0 .. 13 (lane 0's frames), both outputs: the 16 partial rows each
+        float* dbg = A.out_cache + int64_t(b) * C * Pc + 4096 + th * 16;
+        for (int i = 0; i < 16; ++i) dbg[i] = part[i * PS + th];
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < 16; ++i) v += part[i * PS + th];
       if (P.sigmoid) v = sigmoidf_(v);

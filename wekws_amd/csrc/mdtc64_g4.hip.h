@@ -433,14 +433,12 @@ __global__ __launch_bounds__(C * 4, 4) void mdtc_g4_kernel(const StackParams P, 
       const int K = P.odim;
       const float4 w0 = *reinterpret_cast<const float4*>(W + P.head_w + o0b);
       const float4 w1 = *reinterpret_cast<const float4*>(W + P.head_w + (K > 1 ? C : 0) + o0b);
+      const HeadPairs hw(w0, w1);                            // (packed, operand selects spelled out: pk_safe.hip.h)
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        float p0 = yp[tt][0], p1 = yp[tt][1];
-        p0 = fmaf(w0.x, hv[tt][0], p0); p1 = fmaf(w1.x, hv[tt][0], p1);
-        p0 = fmaf(w0.y, hv[tt][1], p0); p1 = fmaf(w1.y, hv[tt][1], p1);
-        p0 = fmaf(w0.z, hv[tt][2], p0); p1 = fmaf(w1.z, hv[tt][2], p1);
-        p0 = fmaf(w0.w, hv[tt][3], p0); p1 = fmaf(w1.w, hv[tt][3], p1);
-        yp[tt][0] = p0; yp[tt][1] = p1;
+        pk_f32x2 pp{yp[tt][0], yp[tt][1]};
+        head_fma4(pp, hw.x, hw.y, hw.z, hw.w, hv[tt]);
+        yp[tt][0] = pp.x; yp[tt][1] = pp.y;
       }
     }
     amax_publish(amax_cells + 3 + bi, hmax);                 // = the input tile of block bi + 1

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                         // the feature maximum is published
-#ifdef WEKWS_D64_EARLY                                        // (diagnosis builds only: the placement that brings the rare wrong posteriors back)
+#ifdef WEKWS_D64_EARLY                                        // (diagnosis builds only: the placement that used to bring the rare wrong posteriors back)
     if (amax_inputs_bad(amax_cells)) { nf_repair_call(A, blockIdx.x); return; }
 #endif
     float cpre;
@@ -253,11 +253,12 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
     __syncthreads();                                         // (B2) maximum published, planes free
   }
 
-  // ---- the backbone's output enters the head: this lane's partial sums over its four channels.  (Computed HERE, behind the
-  //      last block's barrier: held in registers across that barrier -- computed inside the last block, like mdtc64_g4 does --
-  //      ~3 % of the utterances of a large batch came out 1e-2 off whenever several workgroups shared the CU, although the
-  //      tile and the partial sums themselves checked out; tests/test_hip_parity.py::test_ds64_register_resident_kernel compares
-  //      every row of a 4096-utterance batch.)
+  // ---- the backbone's output enters the head: this lane's partial sums over its four channels, as packed FMAs with their operand
+  //      selects spelled out (head_fma4, pk_safe.hip.h).  History: rounds 4-6 saw ~2 % of the utterances of a large batch come out
+  //      1e-2 off in ONE output whenever several workgroups shared the CU, and could only move the effect around (where the sums
+  //      were computed, where the non-finite check sat, the register budget).  Round 6 found it: the compiler had lowered this chain
+  //      to v_pk_fma_f32 ... op_sel:[0,1,0], and gfx950 returns lanes 48..63 of that instruction's low result without the product
+  //      while another workgroup's waves issue MFMAs on the SIMD (tools/probe/d64_dump.py, pk_opsel_probe4.hip).
   {
     const int o0b = o0;
     {
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
       if (A.out_cache) {
         float* dbg = A.out_cache + int64_t(b) * C * Pc + threadIdx.x * 16;
         dbg[0] = yp[0][0]; dbg[1] = yp[0][1]; dbg[2] = hv[0][0]; dbg[3] = hv[0][1]; dbg[4] = hv[0][2]; dbg[5] = hv[0][3];
-        dbg[6] = w0.x; dbg[7] = w0.y; dbg[8] = w0.z; dbg[9] = w0.w; dbg[10] = yp[1][0]; dbg[11] = yp[1][1];
+        dbg[6] = w0.x; dbg[7] = w0.y; dbg[8] = w0.z; dbg[9] = w0.w;
+        if constexpr (NT > 1) { dbg[10] = yp[1][0]; dbg[11] = yp[1][1]; }
       }
 #endif
     }
@@ -310,10 +312,9 @@ __global__ __launch_bounds__(kG4Threads, 4) void ds64_g4_kernel(const StackParam
   }
   // A NaN / Inf feature or cache element (cells [0] / [1], untouched since the top, at or above 0x7f800000): what the kernel
   // computed for this utterance is garbage (and touched nothing else); the utterance is re-computed with the reference's arithmetic
-  // HERE, where nothing is live.  (Measured, round 6: a detection branch with an early exit near the top of this kernel moved its
-  // register allocation and brought back the rare wrong posteriors of round 4 -- several workgroups per CU, ~2 % of the utterances
-  // of a large batch, tools/probe/d64_diag.py -- although no spill and no instruction of the fast path was involved that could be
-  // named; with the branch at the very end the fast path's code is the same as without it, and so are its results.)
+  // HERE, where nothing is live.  (An early exit near the top is equally right since the head's packed FMAs are written out --
+  // -DWEKWS_D64_EARLY builds that placement, the one that used to bring the rare wrong posteriors back: 0 differing utterances in
+  // tools/probe/d64_diag.py now -- but saves nothing for finite inputs.)
   if (amax_inputs_bad(amax_cells)) {                         // (workgroup-uniform, scalar)
     __syncthreads();
     nf_repair_call(A, blockIdx.x);

@@ -8,7 +8,9 @@ for f in wekws_amd/csrc/*.hip; do
 done
 wait
 python3 - <<'PY'
-import glob, re
+import glob, re, sys
+sys.path.insert(0, "tests")
+from test_isa_hazard import hazardous_line
 tot = 0
 for path in sorted(glob.glob('build/isa/*.s')):
     kern = None
@@ -16,10 +18,7 @@ for path in sorted(glob.glob('build/isa/*.s')):
         m = re.match(r'^(_Z\w+):', line)
         if m:
             kern = m[1]
-            continue
-        m = re.match(r'\s+v_pk_(fma|mul|add)_f32\s+(\S+), (\S+), (\S+)', line)
-        s = re.search(r'op_sel:\[([01]),([01])', line)
-        if m and s and s[1] == '0' and s[2] == '1' and m[3].startswith('v') and m[4].startswith('v'):
+        elif 'v_pk_' in line and hazardous_line(line):
             tot += 1
             print(path, kern[:80], line.strip())
 print("hazardous packed-f32 instructions:", tot)

@@ -4,19 +4,21 @@
 // re-arranging code -- profiles/r06_experiments.txt).  Measured on MI355X with tools/probe/pk_opsel_probe4.hip / probe5 (every
 // op_sel / op_sel_hi combination of v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, 4096 workgroups x 100 iterations):
 //
-//   a packed-f32 instruction whose LOW result is formed from  src0's LOW half and src1's HIGH half  (op_sel:[0,1,...]), both of them
-//   vector registers, returns its low result in LANES 48..63 as if src1's high half were zero -- the product missing from an FMA --
-//   whenever other waves of the same SIMD are issuing MFMAs at that moment.  Never without MFMA neighbours, never in lanes 0..47,
-//   never in the high result, never with a scalar register or a constant as src0 or src1, never for the mirror pattern (src0 high,
-//   src1 low).  2 x 10^5 wrong values per 5 x 10^7 in the probe; in ds64_g4 (four workgroups per CU, the head's FMA chain of one
-//   workgroup beside the matrix phase of another) ~2 % of the utterances of a large batch, all in the one output whose chain the
-//   compiler had lowered to  v_pk_fma_f32 d, w, h, d op_sel:[0,1,0].
+//   a packed-f32 instruction whose LOW result is formed from  the LOW half of its first vector-register source and the HIGH half of
+//   its second vector-register source  -- op_sel:[0,1,..] on three registers; op_sel:[0,.,1] when src1 is a constant or a scalar
+//   register (those do not count: probe5, probe7); the third register's select plays no role, nor does op_sel_hi -- returns its low
+//   result in LANES 48..63 as if that second source's high half were zero (the product missing from an FMA) whenever other waves of
+//   the same SIMD are issuing MFMAs at that moment.  Never without MFMA neighbours, never in lanes 0..47, never in the high result,
+//   never for the mirror pattern (first source high, second low), never with a single register source.  2 x 10^5 wrong values per
+//   5 x 10^7 in the probe; in ds64_g4 (four workgroups per CU, the head's FMA chain of one workgroup beside the matrix phase of another)
+//   ~2 % of the utterances of a large batch, all in the one output whose chain the compiler had lowered to
+//   v_pk_fma_f32 d, w, h, d op_sel:[0,1,0]; in the fbank kernel beside an MDTC forward on another stream 1 .. 6 % of the frames.
 //
 // The compiler (ROCm 7.2) emits that form freely -- its SLP vectoriser pairs the two outputs' chains (p0, p1) += (w0, w1) * h[1] and
 // takes h[1] as the high half of the register pair (h[0], h[1]) -- and a kernel without MFMAs of its own meets it as soon as a
 // tenant on another stream puts MFMA waves on its SIMD.  So: (1) the code below spells the commutative operands the safe way round
 // (the selected-high operand first) in inline assembly, where no canonicalisation can turn them back; (2) tests/test_isa_hazard.py
-// disassembles the built library and fails on any packed-f32 instruction with op_sel:[0,1,..] on two vector registers.
+// disassembles the built library and fails on any packed-f32 instruction with that select pattern.
 #pragma once
 #include <hip/hip_runtime.h>
 

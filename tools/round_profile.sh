@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-700 | tail -40 > $out/${tag}_pytest_gpu.txt
 cp $out/parity_errors.json $out/${tag}_parity_errors.json 2>/dev/null
 # headline kernel, both precisions: kernel trace + PMC groups + FETCH_SIZE / WRITE_SIZE passes
 tools/pmc.sh hl python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null

@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/${tag}_pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "^E  |^FAILED|passed|failed" | cut -c1-700 | tail -40 > $out/${tag}_pytest_gpu.txt
 cp $out/parity_errors.json $out/${tag}_parity_errors.json 2>/dev/null
 tools/pmc_min.sh hl python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 > /dev/null
 tools/pmc_min.sh hl32 python bench.py --no-cpu-baseline --no-extras --steps 7 --warmup 2 --precision f32 > /dev/null

@@ -70,3 +70,35 @@ def test_bit_identical_beside_an_mfma_tenant(name, precision, tenant):
         for (y, c), (ys, cs), ch in zip(got, solo, modes):
             assert torch.equal(y.view(torch.int32), ys.view(torch.int32)), (name, precision, ch, rnd, float((y - ys).abs().max()))
             assert torch.equal(c.view(torch.int32), cs.view(torch.int32)), (name, precision, ch, rnd)
+
+
+def test_front_end_and_post_processing_beside_an_mfma_tenant(tenant):
+    """The small kernels either side of the model -- fbank (Hamming / Povey, 40 / 80 bins, float / int16 PCM), MFCC (DCT + lifter),
+    splice + skip, softmax + top-k, the DET reductions -- beside the same tenant: bit-identical to their solo runs."""
+    from wekws_amd import ctc, det
+    from wekws_amd.frontend import Fbank, Mfcc, splice_skip
+    pcm = torch.from_numpy(synth.synth_pcm(384, 16000, seed=12, kind="noise")).cuda()
+    pcm16 = pcm.round().clamp(-32768, 32767).to(torch.int16)
+    logits = torch.from_numpy(np.random.default_rng(5).standard_normal((64, 50, 2599)).astype(np.float32) * 3).cuda()
+    scores = torch.rand(256, 98, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    fb40, fb80, fbp, mf = Fbank(40), Fbank(80), Fbank(80, window="povey"), Mfcc(80, 80)
+
+    def work():
+        f80 = fb80(pcm)
+        p, i = ctc.softmax_topk(logits, 3)
+        mx, am = det.max_pool_scores(scores)
+        return [fb40(pcm), f80, fb40(pcm16), fbp(pcm), mf(pcm), splice_skip(f80, 2, 2, 3), p, i, mx, am]
+
+    solo = [t.clone() for t in work()]
+    tm, tx = tenant
+    torch.cuda.synchronize()
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    for rnd in range(12):
+        with torch.cuda.stream(s_b):
+            for _ in range(8):
+                tm(tx)
+        with torch.cuda.stream(s_a):
+            got = work()
+        torch.cuda.synchronize()
+        for k, (g, r) in enumerate(zip(got, solo)):
+            assert torch.equal(g, r) or torch.equal(g.view(torch.int32), r.view(torch.int32)), (rnd, k)

@@ -30,11 +30,21 @@ def _forward(model, x, chunks):
     return torch.cat(ys, dim=1), c
 
 
-@pytest.fixture(scope="module")
-def tenant():
-    cfg = dict(synth.MODEL_CONFIGS["mdtc_h64"])
+TENANTS = {"mdtc_h64": 512, "gru_2x128": 256, "ds_tcn_h64": 1024}   # model -> batch that leaves room on every CU beside it
+
+
+@pytest.fixture(scope="module", params=sorted(TENANTS))
+def tenant(request):
+    """An MFMA-heavy forward for the second stream: MDTC h64 (four-wave workgroups, matrix and vector phases interleaved across the
+    workgroups of a CU), the GRU layer wavefront (stage workgroups polling each other's rings between MFMA steps), DS-TCN h64."""
+    name = request.param
+    cfg = dict(synth.MODEL_CONFIGS[name])
     m = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 99))
-    x = torch.from_numpy(synth.synth_feats(512, 98, cfg["input_dim"], seed=8)).cuda()
+    B = TENANTS[name]
+    x = torch.from_numpy(synth.synth_feats(B, 98, cfg["input_dim"], seed=8)).cuda()
+    if cfg["backbone"]["type"] == "gru":
+        h0 = torch.zeros(cfg["backbone"]["num_layers"], B, cfg["hidden_dim"], device="cuda")
+        return (lambda xx: m(xx, h0)), x
     return m, x
 
 

@@ -318,11 +318,14 @@ int wekws_hip_fbank_compute_i16(wekws_hip_fbank* f, const int16_t* pcm, int B, i
  *   i = 0 .. wekws_hip_splice_frames(T, right, skip) - 1
  * (the left margin replicates frame 0, the last `right` frames are dropped, then every skip-th frame is kept).
  */
-/* ceil((T - right) / skip), 0 if T <= right */
+/* ceil((T - right) / skip) for T >= right.  T < right (an utterance shorter than its right context): the reference's cut
+ * feats_ctx[:, :T - right] is a negative slice that keeps 2 T - right frames (0 if that is <= 0), whose right-hand blocks are
+ * torch.roll's wrap-around, frame (i * skip + lag) mod T -- reproduced bit for bit: ceil(max(2 T - right, 0) / skip). */
 int wekws_hip_splice_frames(int T, int right, int skip);
 /*
  * feats  (B, T, F) device float32
  * out    (B, wekws_hip_splice_frames(T, right, skip), (left + right + 1) * F) device float32
+ * left >= 1 and left >= T: WEKWS_HIP_EINVAL -- the reference's left-margin loop (init_dataset.py:45-48) raises IndexError there.
  */
 int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out,
                      void* stream);

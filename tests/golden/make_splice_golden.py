@@ -16,7 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
-from tests.golden.splice_cases import CASES, case_input  # noqa: E402
+from tests.golden.splice_cases import CASES, RAISING, case_input  # noqa: E402
 
 SRC = "/root/reference/wekws/dataset/init_dataset.py"
 
@@ -45,6 +45,14 @@ def main():
         out[name + "/lens"] = sample["feats_lengths"].numpy()
         out[name + "/xsum"] = np.float64(np.abs(x.astype(np.float64)).sum())
         print(f"{name:20s} x{x.shape} -> y{y.shape} lens {sample['feats_lengths'].tolist()}")
+    for name, B, T, F, left, right, skip in RAISING:            # what the reference does with left >= T: recorded, not assumed
+        sample = {"feats": torch.from_numpy(case_input(B, T, F)), "feats_lengths": torch.full((B,), T, dtype=torch.int32)}
+        try:
+            skip_fn(ctx(sample, left=left, right=right), skip_rate=skip)
+            out["raises/" + name] = np.int32(0)
+        except IndexError as e:
+            out["raises/" + name] = np.int32(1)
+            print(f"{name:20s} IndexError: {e}")
     path = os.path.join(HERE, "splice_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,5 +1,7 @@
 // Context expansion + frame skip (wekws/dataset/init_dataset.py:24-68) as one HBM-bound gather.
 //   out[b][i][(lag + left) * F + f] = feats[b][max(i * skip + lag, 0)][f]
+// (an utterance SHORTER than its right context, T < right: the reference's cut  feats_ctx[:, :T - right]  is a negative slice and keeps
+// 2 T - right frames whose right-hand blocks come from torch.roll's wrap-around -- frame (i * skip + lag) mod T; reproduced, not judged)
 // One thread per output float4 (or float when F is not a multiple of 4); consecutive threads walk the output row,
 // so both the loads (F-float runs of a source frame) and the stores are coalesced.  Pure data movement: bit-exact.
 #pragma once
@@ -21,6 +23,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const V* __restrict__ feats
   const int64_t b = q / To;
   int t = i * skip + w - left;
   t = t < 0 ? 0 : t;
+  t = t >= T ? t - T : t;                                    // (only when T < right: torch.roll's wrap-around survives the cut; t < 2 T)
   out[e] = feats[(b * T + t) * Fv + f];
 }
 

@@ -1941,14 +1941,20 @@ int wekws_hip_fbank_compute_i16(wekws_hip_fbank* f, const int16_t* pcm, int B, i
 
 // --------------------------------------------- context expansion + frame skip ---------------------------------------------
 int wekws_hip_splice_frames(int T, int right, int skip) {
-  if (skip <= 0 || right < 0 || T <= right) return 0;
-  return (T - right + skip - 1) / skip;  // init_dataset.py:50-51 then :64-65
+  if (skip <= 0 || right < 0 || T <= 0) return 0;
+  // init_dataset.py:50  feats_ctx[:, :T - right]  -- a NEGATIVE bound (an utterance shorter than its right context) is Python's
+  // "all but the last right - T": 2 T - right frames survive -- then :64-65 keeps every skip-th
+  const int kept = T >= right ? T - right : (2 * T > right ? 2 * T - right : 0);
+  return (kept + skip - 1) / skip;
 }
 
 int wekws_hip_splice(const float* feats, int B, int T, int F, int left, int right, int skip, float* out, void* stream_) {
   if (!feats || !out) return fail(WEKWS_HIP_EINVAL, "NULL argument");
   if (B < 0 || T < 0 || F <= 0 || left < 0 || right < 0 || skip <= 0)
     return fail(WEKWS_HIP_EINVAL, "B=%d T=%d F=%d left=%d right=%d skip=%d", B, T, F, left, right, skip);
+  // init_dataset.py:45-48: the left-margin loop reads feats_ctx[:, left] -- the reference raises IndexError for left >= T (any B)
+  if (left >= 1 && left >= T)
+    return fail(WEKWS_HIP_EINVAL, "splice: left context %d >= T = %d (the reference's left-margin loop raises IndexError)", left, T);
   const int To = wekws_hip_splice_frames(T, right, skip);
   if (B == 0 || To == 0) return WEKWS_HIP_OK;
   if ((int64_t(B) * To * (left + right + 1) * F + 255) / 256 > 0x7fffffffLL) return fail(WEKWS_HIP_EINVAL, "splice: too many elements for one launch");

@@ -78,12 +78,16 @@ def splice_skip(feats: torch.Tensor, left: int = 0, right: int = 0, skip: int = 
                 feats_lengths: Optional[torch.Tensor] = None):
     """context_expansion(left, right) followed by frame_skip(skip) (wekws/dataset/init_dataset.py:24-68) as ONE
     gather on the device: (B, T, F) -> (B, ceil((T - right) / skip), (left + right + 1) * F).
-    With ``feats_lengths`` also returns the reference's updated lengths (:51 then :64-65)."""
+    With ``feats_lengths`` also returns the reference's updated lengths (:51 then :64-65).
+    Degenerate lengths behave like the reference: ``left >= T`` raises IndexError (its left-margin loop), ``T < right``
+    returns the ``2 T - right`` wrapped frames its negative slice keeps (include/wekws_hip.h)."""
     if feats.dim() != 3 or not feats.is_cuda or feats.dtype != torch.float32:
         raise ValueError("feats must be a (B, T, F) float32 tensor on a ROCm device (no CPU fallback)")
     lib = _capi.load()
     feats = feats.contiguous()
     B, T, F = (int(v) for v in feats.shape)
+    if left >= 1 and left >= T:                 # init_dataset.py:45-48 reads feats_ctx[:, left]: the reference's own error
+        raise IndexError(f"index {int(left)} is out of bounds for dimension 1 with size {T}")
     To = int(lib.wekws_hip_splice_frames(T, int(right), int(skip)))
     out = torch.empty((B, To, (left + right + 1) * F), dtype=torch.float32, device=feats.device)
     if B and To:

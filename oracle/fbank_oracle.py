@@ -78,3 +78,43 @@ def has_empty_filter(num_bins=40, sample_rate=16000, frame_length=400):
         if not np.any((m > left) & (m < right)):
             return True
     return False
+
+
+def fbank_f64(wave, num_bins=40, sample_rate=16000, frame_length=400, frame_shift=160, window=0):
+    """The same pipeline evaluated in float64 (tables as the reference builds them: float32 mel weights, the window rounded to
+    float32; per-frame arithmetic and the FFT in double): what both the reference's float32 recurrence-twiddle FFT and the HIP
+    kernel's exactly-rounded one approximate.  Used by the fuzz tests to tell the reference's own rounding noise from a defect."""
+    wave = np.ascontiguousarray(wave, dtype=np.float32)
+    nf = num_frames(wave.size, frame_length, frame_shift)
+    n = 1
+    while n < frame_length:
+        n *= 2
+    nb = n // 2
+    f32 = np.float32
+    mel = lambda f: f32(1127.0) * np.log(f32(1.0) + f32(f) / f32(700.0), dtype=np.float32)   # noqa: E731
+    lo, hi = mel(f32(20.0)), mel(f32(sample_rate // 2))
+    delta = f32((hi - lo) / f32(num_bins + 1))
+    width = f32(sample_rate) / f32(n)
+    m = np.array([mel(width * f32(i)) for i in range(nb)], np.float32)
+    W = np.zeros((num_bins, nb), np.float32)
+    for b in range(num_bins):
+        left, center, right = f32(lo + f32(b) * delta), f32(lo + f32(b + 1) * delta), f32(lo + f32(b + 2) * delta)
+        inside = (m > left) & (m < right)
+        up = (m - left) / (center - left)
+        down = (right - m) / (right - center)
+        W[b] = np.where(inside, np.where(m <= center, up, down), f32(0)).astype(np.float32)
+    a = 2.0 * np.pi / (frame_length - 1)
+    i = np.arange(frame_length, dtype=np.float64)
+    win = (0.54 - 0.46 * np.cos(a * i)) if window == 0 else np.power(0.5 - 0.5 * np.cos(a * i), 0.85)
+    win = win.astype(np.float32).astype(np.float64)
+    out = np.empty((nf, num_bins), np.float64)
+    for f in range(nf):
+        x = wave[f * frame_shift:f * frame_shift + frame_length].astype(np.float64)
+        x = x - x.mean()
+        c = np.float64(np.float32(0.97))                             # fbank.h:122-127 (the constant is 0.97f)
+        x = np.concatenate([[x[0] - c * x[0]], x[1:] - c * x[:-1]])
+        spec = np.fft.fft(np.concatenate([x * win, np.zeros(n - frame_length)]))[:nb]
+        power = spec.real ** 2 + spec.imag ** 2
+        e = W.astype(np.float64) @ power
+        out[f] = np.log(np.maximum(e, np.finfo(np.float32).eps))
+    return out

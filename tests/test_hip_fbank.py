@@ -156,12 +156,8 @@ def test_80_bin_tolerance_end_to_end(error_report):
     assert worst_f <= TOL80 and worst_y <= 1e-4, (worst_f, worst_y)
 
 
-@pytest.mark.parametrize("seed", range(3))
-def test_random_framings_against_the_c_oracle(seed):
-    """Seeded fuzz of the extractor's configuration space (fbank.h:33-97 takes any bin count / frame length; feature_pipeline.cc
-    any sample count): random sample rates, frame lengths 65 .. 512, shifts, bin counts, windows, batch sizes and lengths around
-    the framing boundaries, float and int16 input, against the plain-C oracle (bit-exact against the compiled reference front-end,
-    tests/test_fbank_oracle.py)."""
+def framing_cases(seed):
+    """The seeded configurations of test_random_framings_against_the_c_oracle (also walked by tools/probe/fbank_fuzz_diag.py)."""
     rng = np.random.default_rng(4200 + seed)
     for trial in range(10):
         sr = int(rng.choice([16000, 16000, 8000, 4000]))
@@ -174,12 +170,33 @@ def test_random_framings_against_the_c_oracle(seed):
         nsamp = max(0, flen + (nf - 1) * shift + int(rng.integers(0, shift))) if nf else int(rng.integers(0, flen))
         kind = str(rng.choice(["noise", "sine"]))
         pcm = synth.synth_pcm(B, max(nsamp, 1), seed=trial, kind=kind)[:, :nsamp]
+        yield (seed, trial, sr, flen, shift, bins, window, B, nsamp, kind), pcm
+
+
+def framing_bound(ref, tol):
+    """Allowed |got - ref| per bin: the module's tolerance plus float32's resolution of the frame's PEAK amplitude as seen from the
+    bin -- 4 eps exp((peak - ref) / 2) in log energy (a bin 60 dB below the frame's peak holds 1/1000 of its amplitude: one part in
+    2^23 of the peak is 1.2e-4 of the bin).  Both extractors are float32 pipelines with different FFTs (the reference: radix-2,
+    recurrence twiddles, fft.cc:11-119; the kernel: radix-4, exactly rounded twiddles), so that is how close they can be; measured
+    over 2,300 seeds = 121,480 utterances (tools/probe/fuzz_all.py, profiles/r06_experiments.txt): the factor needed is <= 1.64."""
+    eps = float(np.finfo(np.float32).eps)
+    return tol + 4.0 * eps * np.exp((ref.max(axis=-1, keepdims=True) - ref).astype(np.float64) / 2)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 558, 917, 2175, 2208, 2221, 2235])
+def test_random_framings_against_the_c_oracle(seed):
+    """Seeded fuzz of the extractor's configuration space (fbank.h:33-97 takes any bin count / frame length; feature_pipeline.cc
+    any sample count): random sample rates, frame lengths 65 .. 512, shifts, bin counts, windows, batch sizes and lengths around
+    the framing boundaries, float and int16 input, against the plain-C oracle (bit-exact against the compiled reference front-end,
+    tests/test_fbank_oracle.py), every bin within framing_bound.  Seeds >= 558: the configurations of a 2,300-seed run that come
+    closest to the bound (pure tones through short FFTs; 558 and 917 are the worst at <= 40 / > 40 bins)."""
+    for what, pcm in framing_cases(seed):
+        _, trial, sr, flen, shift, bins, window, B, nsamp, kind = what
         if fbank_oracle.has_empty_filter(bins, sr, flen):   # the reference's constructor CHECK-fails (fbank.h:81): refused, not wrong
             with pytest.raises(Exception, match="covers no FFT bin"):
                 Fbank(num_bins=bins, sample_rate=sr, frame_length=flen, frame_shift=shift, window=window)
             continue
         fb = Fbank(num_bins=bins, sample_rate=sr, frame_length=flen, frame_shift=shift, window=window)
-        what = (seed, trial, sr, flen, shift, bins, window, B, nsamp, kind)
         got = fb(torch.from_numpy(np.ascontiguousarray(pcm)).cuda()).cpu().numpy()
         assert got.shape == (B, fbank_oracle.num_frames(nsamp, flen, shift), bins), what
         tol = TOL if bins <= 40 else TOL80
@@ -187,12 +204,8 @@ def test_random_framings_against_the_c_oracle(seed):
             ref = fbank_oracle.fbank(pcm[i], bins, sr, flen, shift, 0 if window == "hamming" else 1)
             assert got[i].shape == ref.shape, (what, i)
             if ref.size:
-                # bins within 60 dB (13.8 in natural-log energy) of the frame's peak: the module's tolerance; below that the
-                # value is the rounding noise of the FFT itself (the reference's float32 sine-table recurrence vs exactly
-                # rounded twiddles, see the module docstring): 20 x
-                err = np.abs(got[i] - ref)
-                near = ref >= ref.max(axis=-1, keepdims=True) - 13.8
-                assert float(err[near].max()) <= tol and float(err.max()) <= 20 * tol, (what, i, float(err[near].max()), float(err.max()))
+                over = np.abs(got[i] - ref) - framing_bound(ref, tol)
+                assert float(over.max()) <= 0.0, (what, i, float(over.max()), float(np.abs(got[i] - ref).max()))
         if nsamp:
             i16 = torch.from_numpy(np.ascontiguousarray(pcm).astype(np.int16)).cuda()
             assert torch.equal(fb(i16), fb(i16.float())), what

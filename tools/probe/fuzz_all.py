@@ -1,5 +1,6 @@
 """Development tool (GPU box): the suite's seeded random tests over seed ranges the suite does not run.
-    python tools/probe/fuzz_all.py LO HI [minutes]   -- every fuzz test for seeds LO .. HI-1, stopping after `minutes`"""
+    python tools/probe/fuzz_all.py LO HI [minutes [names]]   -- the fuzz tests (all, or those whose name contains one of the comma-separated
+    `names`) for seeds LO .. HI-1; every test gets an equal share of `minutes`"""
 import sys
 import time
 
@@ -15,13 +16,13 @@ budget = float(sys.argv[3]) * 60 if len(sys.argv) > 3 else 1e9
 tests = [("model shapes", t_par.test_random_model_shapes_against_the_oracle), ("fsmn shapes", t_par.test_random_fsmn_shapes_against_the_oracle),
          ("fbank framings", t_fb.test_random_framings_against_the_c_oracle), ("det shapes", t_det.test_random_det_shapes),
          ("splice shapes", t_spl.test_random_splice_shapes), ("topk shapes", t_top.test_random_topk_shapes)]
+if len(sys.argv) > 4:
+    tests = [t for t in tests if any(k in t[0] for k in sys.argv[4].split(","))]
 t0 = time.time()
-for name, fn in tests:
+for k, (name, fn) in enumerate(tests):
     bad = n = 0
     for seed in range(lo, hi):
-        if time.time() - t0 > budget * (tests.index((name, fn)) + 1) / len(tests) and name != "model shapes":
-            break
-        if name == "model shapes" and time.time() - t0 > budget * 0.6:
+        if time.time() - t0 > budget * (k + 1) / len(tests):
             break
         n += 1
         try:

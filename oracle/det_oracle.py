@@ -48,7 +48,13 @@ def false_alarms(score_list, threshold, window_shift):
 def det_stats(keyword_table, filler_table, filler_duration, step=0.01, window_shift=50):
     """The (threshold, false_alarm_per_hour, false_reject_rate) rows of compute_det.py:79-106."""
     rows = []
-    false_reject_rate = false_alarm_per_hour = 0.0
+    # compute_det.py:97-104 assigns the two rates only under `if len(keyword_table) != 0` / `if filler_duration != 0` and then formats
+    # them: with no keyword utterance / no filler audio the reference dies with NameError at its first row (arguments are evaluated
+    # left to right: false_alarm_per_hour first)
+    if filler_duration == 0:
+        raise NameError("name 'false_alarm_per_hour' is not defined")
+    if len(keyword_table) == 0:
+        raise NameError("name 'false_reject_rate' is not defined")
     for threshold in thresholds(step):
         num_false_reject = sum(1 for sl in keyword_table.values() if float(max(sl)) < threshold)
         num_false_alarm = sum(false_alarms(sl, threshold, window_shift) for sl in filler_table.values())

@@ -27,3 +27,24 @@ def test_det_oracle_matches_reference_loop(case):
     for b in range(B):
         if lengths[b]:
             assert s[b, am[b, kw], kw] == mx[b, kw] and not (s[b, :am[b, kw], kw] == mx[b, kw]).any()
+
+
+@pytest.mark.parametrize("empty", ["keywords", "filler_audio", "both"])
+def test_empty_tables_die_like_the_reference(empty):
+    """compute_det.py:97-104 assigns the rates only under `if len(keyword_table) != 0` / `if filler_duration != 0` and then formats
+    them: NameError at the first row (false_alarm_per_hour is evaluated first).  The oracle raises the same error; where the reference
+    tree is present its own loop (lifted like tests/golden/make_det_golden.py does) is executed beside it."""
+    import io
+    import types
+    kt = {} if empty in ("keywords", "both") else {"k0": [0.2, 0.9]}
+    dur = 0.0 if empty in ("filler_audio", "both") else 36.0
+    ft = {"f0": [0.1, 0.6, 0.3]}
+    want = "false_reject_rate" if empty == "keywords" else "false_alarm_per_hour"
+    with pytest.raises(NameError, match=want):
+        det_oracle.det_stats(kt, ft, dur)
+    if os.path.exists("/root/reference/wekws/bin/compute_det.py"):
+        from tests.golden.make_det_golden import reference_loop
+        ns = dict(args=types.SimpleNamespace(keyword="KW", step=0.01), window_shift=50, keyword_table=kt, filler_table=ft,
+                  filler_duration=dur, fout=io.StringIO())
+        with pytest.raises(NameError, match=want):
+            exec(reference_loop(), ns)

@@ -113,3 +113,15 @@ def test_random_det_shapes(seed):
         al = det.false_alarm_counts(st, kw, th, ws, lt).cpu().numpy()
         want = np.asarray([[det_oracle.false_alarms(s[b, :lengths[b], kw].tolist(), t, ws) for t in th] for b in range(B)])
         assert np.array_equal(al, want), (seed, B, T, K, kw, ws, step)
+
+
+def test_empty_tables_die_like_the_reference():
+    """No keyword utterance / no filler audio: the reference's stats loop dies with NameError (compute_det.py:97-104; executed beside
+    the oracle in tests/test_det_oracle.py); det_stats raises the same."""
+    s = torch.rand(4, 20, 2, device="cuda")
+    ln = torch.full((4,), 20, dtype=torch.int32)
+    with pytest.raises(NameError, match="false_reject_rate"):
+        det.det_stats(s, ln, [False] * 4, 0, 36.0)
+    with pytest.raises(NameError, match="false_alarm_per_hour"):
+        det.det_stats(s, ln, [True, False, False, True], 0, 0.0)
+    assert len(det.det_stats(s, ln, [True, False, False, True], 0, 36.0)) == len(det.det_thresholds(0.01))

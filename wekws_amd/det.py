@@ -82,15 +82,21 @@ def det_stats(scores: torch.Tensor, lengths: Optional[torch.Tensor], is_keyword:
     (compute_det.py:45-50).  Only the (B,) maxima and the (B, n_thr) counts leave the device.
     text_format=True reproduces the stats file of the reference's score.py -> compute_det.py chain bit for bit: there the
     scores pass through '{:.6f}' text (score.py:134-135) before they are compared."""
+    kw = np.asarray(list(is_keyword), bool)
+    # the reference assigns the two rates only under `if len(keyword_table) != 0` / `if filler_duration != 0` (compute_det.py:97-101)
+    # and then formats them: an evaluation set without a keyword utterance, or without filler audio, dies there with NameError
+    if filler_duration == 0:
+        raise NameError("name 'false_alarm_per_hour' is not defined")
+    if not kw.any():
+        raise NameError("name 'false_reject_rate' is not defined")
     th = det_thresholds(step)
     mx, _ = max_pool_scores(scores, lengths)
     alarms = false_alarm_counts(scores, keyword, th, window_shift, lengths, text_format=text_format).cpu().numpy()
-    kw = np.asarray(list(is_keyword), bool)
     mk = mx[:, keyword].cpu().numpy().astype(np.float64)[kw]
     if text_format:
         mk = round_like_score_file(mk)                       # max and a monotonic rounding commute
     rows = []
-    false_reject_rate = false_alarm_per_hour = 0.0           # (the reference leaves them undefined when a table is empty)
+    false_reject_rate = false_alarm_per_hour = 0.0
     for j, t in enumerate(th):
         num_false_reject = int((mk < t).sum())
         num_false_alarm = int(alarms[~kw, j].sum())

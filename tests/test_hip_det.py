@@ -125,3 +125,10 @@ def test_empty_tables_die_like_the_reference():
     with pytest.raises(NameError, match="false_alarm_per_hour"):
         det.det_stats(s, ln, [True, False, False, True], 0, 0.0)
     assert len(det.det_stats(s, ln, [True, False, False, True], 0, 36.0)) == len(det.det_thresholds(0.01))
+    ln[3] = 0                                                  # a keyword utterance without frames: `max(score_list)` of an empty list
+    with pytest.raises(ValueError, match="empty sequence"):
+        det.det_stats(s, ln, [True, False, False, True], 0, 36.0)
+    with pytest.raises(ValueError, match="empty sequence"):
+        det_oracle.det_stats({"k0": [0.5], "k3": []}, {"f1": [0.1]}, 36.0)
+    ln[3], ln[1] = 20, 0                                       # a filler utterance without frames is fine (its scan loop does nothing)
+    assert len(det.det_stats(s, ln, [True, False, False, True], 0, 36.0)) == len(det.det_thresholds(0.01))

@@ -89,6 +89,8 @@ def det_stats(scores: torch.Tensor, lengths: Optional[torch.Tensor], is_keyword:
         raise NameError("name 'false_alarm_per_hour' is not defined")
     if not kw.any():
         raise NameError("name 'false_reject_rate' is not defined")
+    if lengths is not None and bool((lengths.cpu().numpy()[kw] <= 0).any()):
+        raise ValueError("max() arg is an empty sequence")       # compute_det.py:84 `max(score_list)` of a keyword utterance without frames
     th = det_thresholds(step)
     mx, _ = max_pool_scores(scores, lengths)
     alarms = false_alarm_counts(scores, keyword, th, window_shift, lengths, text_format=text_format).cpu().numpy()

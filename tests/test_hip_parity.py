@@ -444,6 +444,22 @@ def test_pointers_that_are_only_4_byte_aligned(name):
             assert ey <= 2e-5 and ec <= 2e-5 * max(1.0, float(c_ref.abs().max())), (name, T, off, ey, ec)
 
 
+def test_empty_time_axis_and_empty_batch_like_the_reference():
+    """T = 0: the reference's own errors (AssertionError from tcn.py:53 / mdtc.py:112 `assert y.size(2) > self.padding`, RuntimeError from
+    torch.nn.GRU / the FSMN's memory conv -- recorded from the live reference in the build container).  B = 0 with T > 0: the conv
+    backbones return empty outputs of the right shapes, as the reference does."""
+    from wekws_amd import pack
+    for name, err in (("ds_tcn_h256", AssertionError), ("tcn_h64", AssertionError), ("mdtc_h64", AssertionError),
+                      ("gru_2x128", RuntimeError), ("fsmn_small", RuntimeError)):
+        cfg = dict(synth.MODEL_CONFIGS[name])
+        model = build(cfg, synth.synth_state_dict(pack.model_spec(cfg), 1234))
+        with pytest.raises(err):
+            model(torch.zeros(2, 0, cfg["input_dim"], device="cuda"))
+        if err is AssertionError:
+            y, c = model(torch.zeros(0, 5, cfg["input_dim"], device="cuda"))
+            assert tuple(y.shape) == (0, 5, cfg["output_dim"]) and tuple(c.shape) == pack.cache_shape(pack.parse_config(cfg), 0)
+
+
 def test_empty_cache_equals_zero_cache():
     from wekws_amd import pack
     for name in ("ds_tcn_h256", "mdtc_h64", "tcn_h64", "fsmn_small"):

@@ -284,8 +284,13 @@ class KWSModel(nn.Module):
             raise TypeError(f"x must be float32, got {x.dtype}")
         dev = x.device
         B, T = int(x.size(0)), int(x.size(1))
-        if T <= 0:
-            raise ValueError("empty time axis")
+        if T <= 0:                                           # an empty time axis: the reference's own errors, by backbone
+            bb = self._d["backbone"]
+            if bb == pack.BACKBONE["gru"]:
+                raise RuntimeError("Expected sequence length to be larger than 0 in RNN")          # torch.nn.GRU, kws_model.py:73
+            if bb == pack.BACKBONE["fsmn"]:
+                raise RuntimeError("Kernel size can't be greater than actual input size (empty time axis)")   # fsmn.py's memory conv
+            raise AssertionError()                            # tcn.py:53 / mdtc.py:112 `assert y.size(2) > self.padding`
         x = x.contiguous()
         h = self._get_handle(dev)
         lib = _capi.load()
